@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests (fixture loading, sampling identical to make_fixtures.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import anatomask_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name), allow_pickle=False))
+
+
+def tiny_cfg(f):
+    return O.Config(list(f["dims"]), list(f["depth"]), int(f["width"]), tuple(int(v) for v in f["input_size"]),
+                    float(f["mask_ratio"]))
+
+
+def np_volume(B, size, seed):
+    return torch.from_numpy(np.random.RandomState(int(seed)).standard_normal((B, 1, *size)).astype(np.float32))
+
+
+def sample(t, n=96):
+    f = t.detach().float().cpu().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return f[idx].numpy().copy()
+
+
+def checks(t):
+    f = t.detach().double().cpu().reshape(-1)
+    return np.array([f.sum().item(), f.abs().sum().item(), (f * f).sum().item()], dtype=np.float64)
+
+
+def assert_checks(got, want, rtol, what=""):
+    g, w = checks(got), np.asarray(want)
+    # sum can cancel: scale its tolerance by the abs-sum
+    assert abs(g[0] - w[0]) <= rtol * max(w[1], 1e-30), f"{what} sum {g[0]} vs {w[0]}"
+    assert abs(g[1] - w[1]) <= rtol * max(w[1], 1e-30), f"{what} abssum {g[1]} vs {w[1]}"
+    assert abs(g[2] - w[2]) <= 2 * rtol * max(w[2], 1e-30), f"{what} sqsum {g[2]} vs {w[2]}"
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
