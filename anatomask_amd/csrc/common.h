@@ -1,0 +1,97 @@
+// Shared device helpers for the AnatoMask gfx950 kernels.
+// Layout convention everywhere: activations are channels-last [B][D][H][W][C]
+// (C contiguous), dtype T = float or bf16 (stored as uint16), C % 8 == 0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define AM_DT_F32 0
+#define AM_DT_BF16 1
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // round-to-nearest-even; NaN stays NaN (quiet)
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct TT;
+template <> struct TT<float> {
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct TT<bf16_t> {
+  static constexpr int EPC = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 16-byte chunk <-> floats
+template <typename T> __device__ __forceinline__ void chunk_to_f(const u32x4& c, float* f);
+template <> __device__ __forceinline__ void chunk_to_f<float>(const u32x4& c, float* f) {
+  f[0] = __uint_as_float(c[0]); f[1] = __uint_as_float(c[1]); f[2] = __uint_as_float(c[2]); f[3] = __uint_as_float(c[3]);
+}
+template <> __device__ __forceinline__ void chunk_to_f<bf16_t>(const u32x4& c, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(c[i] << 16); f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ u32x4 f_to_chunk(const float* f);
+template <> __device__ __forceinline__ u32x4 f_to_chunk<float>(const float* f) {
+  u32x4 c; c[0] = __float_as_uint(f[0]); c[1] = __float_as_uint(f[1]); c[2] = __float_as_uint(f[2]); c[3] = __float_as_uint(f[3]); return c;
+}
+template <> __device__ __forceinline__ u32x4 f_to_chunk<bf16_t>(const float* f) {
+  u32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = (uint32_t)f2bf(f[2 * i]) | ((uint32_t)f2bf(f[2 * i + 1]) << 16);
+  return c;
+}
+
+// One "chunk MMA": D(16 cout x 16 voxel) += A(16 x KC) * B(KC x 16) where each lane supplies one
+// 16-byte chunk of A (row = lane&15) and of B (col = lane&15), chunk index g = lane>>4.
+//   bf16: KC = 32, one v_mfma_f32_16x16x32_bf16 (lane's 8 elements are k = 8g..8g+7)
+//   f32 : KC = 16, four v_mfma_f32_16x16x4_f32 (step s uses element s of every lane: k = 4g+s);
+//         exact f32 fma chain, same rate as the f32 VALU peak (MI355X_MICROARCH.md "FP32-input MFMA").
+template <typename T> __device__ __forceinline__ f32x4 mma_chunk(const u32x4& a, const u32x4& b, f32x4 acc);
+template <> __device__ __forceinline__ f32x4 mma_chunk<bf16_t>(const u32x4& a, const u32x4& b, f32x4 acc) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mma_chunk<float>(const u32x4& a, const u32x4& b, f32x4 acc) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]), acc, 0, 0, 0);
+  return acc;
+}
+
+__device__ __forceinline__ float warp_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double warp_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-activity lookup: mask is uint8 [B][fd][fh][fw]; a voxel (d,h,w) at a resolution whose
+// blocks are (1<<bs) voxels wide is active iff mask[b][d>>bs][h>>bs][w>>bs] != 0.
+struct MaskView {
+  const uint8_t* m;  // nullptr => everything active
+  int fd, fh, fw, bs;
+  __device__ __forceinline__ bool active(int b, int d, int h, int w) const {
+    if (!m) return true;
+    return m[((b * fd + (d >> bs)) * fh + (h >> bs)) * fw + (w >> bs)] != 0;
+  }
+};
+
+#define AM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

@@ -1,0 +1,706 @@
+// HBM-bound streaming kernels of the AnatoMask step (gfx950, VALU only): pooled sparse InstanceNorm /
+// BatchNorm statistics + fused apply (+LeakyReLU / ReLU6 / residual / mask-token fill), their
+// backward passes, the Cin=1 stem convolutions, the 1x1 projection, weight (un)packing.
+// Every kernel walks channels-last rows with one 16-byte chunk per lane (coalesced: consecutive
+// lanes take consecutive chunks of consecutive voxels) and touches only voxels of active patches.
+#include "common.h"
+#include "../../include/anatomask_hip.h"
+
+namespace {
+
+constexpr int VPW = 2048;   // voxels per workgroup for the row-walking kernels
+
+struct Geo {                 // a channels-last tensor [B][D][H][W][C] and its (optional) patch mask
+  int B, D, H, W, C;
+  MaskView mask;
+  __device__ __forceinline__ bool active(long v) const {
+    if (!mask.m) return true;
+    const int w = v % W; long t = v / W; const int h = t % H; t /= H; const int d = t % D; const int b = t / D;
+    return mask.active(b, d, h, w);
+  }
+  __device__ __forceinline__ long nvox() const { return (long)B * D * H * W; }
+};
+
+// thread -> (voxel lane, chunk lane); CPV chunks per voxel; VPP voxels per pass
+template <typename T> struct Walk {
+  int cpv, vpp, cl, vl; bool live;
+  __device__ __forceinline__ Walk(int C) {
+    cpv = C / TT<T>::EPC; vpp = 256 / cpv; cl = threadIdx.x % cpv; vl = threadIdx.x / cpv; live = vl < vpp;
+  }
+};
+
+// ------------------------------------------------------------------ statistics (forward)
+// sums[c][0] += sum x, sums[c][1] += sum x^2 over active voxels (double atomics, one per WG per channel)
+template <typename T>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x, Geo g, double* __restrict__ sums) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 2 * 8];
+  Walk<T> wk(g.C);
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) s1[i] = s2[i] = 0.f;
+  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  if (wk.live)
+    for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+      if (!g.active(v)) continue;
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + v * g.C + wk.cl * EPC), f);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+    }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { red[(threadIdx.x * 2) * 8 + i] = s1[i]; red[(threadIdx.x * 2 + 1) * 8 + i] = s2[i]; }
+  __syncthreads();
+  if (threadIdx.x < wk.cpv) {                      // one thread per chunk lane folds the voxel lanes
+    double a1[EPC], a2[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) a1[i] = a2[i] = 0.0;
+    for (int vl = 0; vl < wk.vpp; ++vl) {
+      const int t = vl * wk.cpv + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { a1[i] += red[(t * 2) * 8 + i]; a2[i] += red[(t * 2 + 1) * 8 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+      const int c = threadIdx.x * EPC + i;
+      atomicAdd(&sums[c * 2], a1[i]); atomicAdd(&sums[c * 2 + 1], a2[i]);
+    }
+  }
+}
+
+// count of active voxels implied by the mask (dense: B*D*H*W)
+__global__ void mask_count_kernel(const uint8_t* mask, int n, int voxels_per_patch, double* out) {
+  __shared__ double part[4];
+  double c = 0;
+  for (int i = threadIdx.x; i < n; i += 256) c += mask[i] ? 1.0 : 0.0;
+  c = warp_sum_d(c);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (part[0] + part[1] + part[2] + part[3]) * voxels_per_patch;
+}
+
+// mean / rstd / folded scale+shift; optional BatchNorm running-stat update (momentum, unbiased var)
+__global__ void norm_finalize_kernel(const double* sums, const double* count_ptr, double count_host, int C,
+                                     const float* gamma, const float* beta, float eps, float* mean, float* rstd,
+                                     float* scale, float* shift, float* run_mean, float* run_var, float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = count_ptr ? count_ptr[0] : count_host;
+  const double m = sums[2 * c] / n;
+  double var = sums[2 * c + 1] / n - m * m;
+  if (var < 0) var = 0;
+  const float rs = (float)(1.0 / sqrt(var + (double)eps));
+  mean[c] = (float)m; rstd[c] = rs;
+  const float sc = gamma[c] * rs;
+  scale[c] = sc; shift[c] = beta[c] - (float)m * sc;
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * (n / (n - 1.0)));
+  }
+}
+
+// eval-mode BatchNorm: fold running stats
+__global__ void norm_fold_running_kernel(int C, const float* gamma, const float* beta, const float* run_mean,
+                                         const float* run_var, float eps, float* scale, float* shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(run_var[c] + eps);
+  scale[c] = sc; shift[c] = beta[c] - run_mean[c] * sc;
+}
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == AM_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+  if (act == AM_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+  return v;
+}
+__device__ __forceinline__ float act_grad(float out, int act) {   // derivative from the SAVED OUTPUT
+  if (act == AM_ACT_LRELU) return out > 0.f ? 1.f : 0.01f;
+  if (act == AM_ACT_RELU6) return (out > 0.f && out < 6.f) ? 1.f : 0.f;
+  return 1.f;
+}
+
+// ------------------------------------------------------------------ apply (forward)
+// y = act(x*scale + shift [+ res | + stem 1x1 shortcut]) on active voxels;
+// fill != nullptr: inactive voxels get the mask token (densify, P/AnatoMask.py:160-163), output dense.
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, Geo g, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act, const T* __restrict__ res,
+                                                         const float* __restrict__ stem_x, const float* __restrict__ stem_w,
+                                                         const float* __restrict__ stem_b, const float* __restrict__ fill,
+                                                         T* __restrict__ y) {
+  constexpr int EPC = TT<T>::EPC;
+  Walk<T> wk(g.C);
+  if (!wk.live) return;
+  float sc[EPC], sh[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { sc[i] = scale[wk.cl * EPC + i]; sh[i] = shift[wk.cl * EPC + i]; }
+  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+    const size_t off = (size_t)v * g.C + wk.cl * EPC;
+    float o[EPC];
+    if (g.active(v)) {
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + off), f);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) o[i] = f[i] * sc[i] + sh[i];
+      if (res) {
+        float r[EPC];
+        chunk_to_f<T>(*(const u32x4*)(res + off), r);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) o[i] += r[i];
+      }
+      if (stem_x) {
+        const float xv = stem_x[v];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) o[i] += stem_w[wk.cl * EPC + i] * xv + stem_b[wk.cl * EPC + i];
+      }
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) o[i] = act_fwd(o[i], act);
+    } else if (fill) {
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) o[i] = fill[wk.cl * EPC + i];
+    } else {
+      continue;
+    }
+    *(u32x4*)(y + off) = f_to_chunk<T>(o);
+  }
+}
+
+// ------------------------------------------------------------------ backward: reduce
+// dpre = dout * act'(out);  bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout (token grad)}
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                              const T* __restrict__ x, Geo g, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, int act, int fill,
+                                                              double* __restrict__ bsum) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 3 * 8];
+  Walk<T> wk(g.C);
+  float s1[EPC], s2[EPC], s3[EPC], mu[EPC], rs[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { s1[i] = s2[i] = s3[i] = 0.f; mu[i] = rs[i] = 0.f; }
+  if (wk.live) {
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) { mu[i] = mean[wk.cl * EPC + i]; rs[i] = rstd[wk.cl * EPC + i]; }
+    const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+    for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+      const size_t off = (size_t)v * g.C + wk.cl * EPC;
+      const bool a = g.active(v);
+      if (!a && !fill) continue;
+      float d[EPC];
+      chunk_to_f<T>(*(const u32x4*)(dout + off), d);
+      if (!a) {
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) s3[i] += d[i];
+        continue;
+      }
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + off), f);
+      if (act != AM_ACT_NONE) {
+        float o[EPC];
+        chunk_to_f<T>(*(const u32x4*)(out + off), o);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+      }
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { s1[i] += d[i]; s2[i] += d[i] * (f[i] - mu[i]) * rs[i]; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) {
+    red[(threadIdx.x * 3) * 8 + i] = s1[i]; red[(threadIdx.x * 3 + 1) * 8 + i] = s2[i]; red[(threadIdx.x * 3 + 2) * 8 + i] = s3[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < wk.cpv) {
+    double a1[EPC], a2[EPC], a3[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) a1[i] = a2[i] = a3[i] = 0.0;
+    for (int vl = 0; vl < wk.vpp; ++vl) {
+      const int t = vl * wk.cpv + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { a1[i] += red[(t * 3) * 8 + i]; a2[i] += red[(t * 3 + 1) * 8 + i]; a3[i] += red[(t * 3 + 2) * 8 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+      const int c = threadIdx.x * EPC + i;
+      atomicAdd(&bsum[c * 3], a1[i]); atomicAdd(&bsum[c * 3 + 1], a2[i]);
+      if (fill) atomicAdd(&bsum[c * 3 + 2], a3[i]);
+    }
+  }
+}
+
+// per-channel coefficients of the apply pass + parameter gradients (accumulated into fp32 grads)
+__global__ void norm_bwd_finalize_kernel(const double* bsum, const double* count_ptr, double count_host, int C,
+                                         const float* gamma, const float* rstd, float* k0, float* k1, float* k2,
+                                         float* dgamma, float* dbeta, float* dtoken) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double n = count_ptr ? count_ptr[0] : count_host;
+  const float gr = gamma[c] * rstd[c];
+  k0[c] = gr;                                  // dx = k0*dpre - k1 - k2*xhat
+  k1[c] = gr * (float)(bsum[3 * c] / n);
+  k2[c] = gr * (float)(bsum[3 * c + 1] / n);
+  if (dgamma) dgamma[c] += (float)bsum[3 * c + 1];
+  if (dbeta) dbeta[c] += (float)bsum[3 * c];
+  if (dtoken) dtoken[c] += (float)bsum[3 * c + 2];
+}
+
+// ------------------------------------------------------------------ backward: apply
+// dx = k0*dpre - k1 - k2*xhat on active voxels; optionally store dpre (gradient of the residual branch)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                             const T* __restrict__ x, Geo g, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const float* __restrict__ k0,
+                                                             const float* __restrict__ k1, const float* __restrict__ k2, int act,
+                                                             T* __restrict__ dx, T* __restrict__ dres) {
+  constexpr int EPC = TT<T>::EPC;
+  Walk<T> wk(g.C);
+  if (!wk.live) return;
+  float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) {
+    const int c = wk.cl * EPC + i;
+    mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c];
+  }
+  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+    if (!g.active(v)) continue;
+    const size_t off = (size_t)v * g.C + wk.cl * EPC;
+    float d[EPC], f[EPC];
+    chunk_to_f<T>(*(const u32x4*)(dout + off), d);
+    chunk_to_f<T>(*(const u32x4*)(x + off), f);
+    if (act != AM_ACT_NONE) {
+      float o[EPC];
+      chunk_to_f<T>(*(const u32x4*)(out + off), o);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+    }
+    if (dres) *(u32x4*)(dres + off) = f_to_chunk<T>(d);
+    float r[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) r[i] = c0[i] * d[i] - c1[i] - c2[i] * (f[i] - mu[i]) * rs[i];
+    *(u32x4*)(dx + off) = f_to_chunk<T>(r);
+  }
+}
+
+// ------------------------------------------------------------------ generic per-channel sum (bias grads)
+template <typename T>
+__global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, Geo g, float* __restrict__ out) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 8];
+  Walk<T> wk(g.C);
+  float s1[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) s1[i] = 0.f;
+  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  if (wk.live)
+    for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+      if (!g.active(v)) continue;
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + v * g.C + wk.cl * EPC), f);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) s1[i] += f[i];
+    }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) red[threadIdx.x * 8 + i] = s1[i];
+  __syncthreads();
+  if (threadIdx.x < wk.cpv) {
+    float a1[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) a1[i] = 0.f;
+    for (int vl = 0; vl < wk.vpp; ++vl)
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) atomicAdd(&out[threadIdx.x * EPC + i], a1[i]);
+  }
+}
+
+// ------------------------------------------------------------------ elementwise add  y = a + b (dense)
+template <typename T>
+__global__ void add_kernel(const T* a, const T* b, T* y, size_t nchunk) {
+  constexpr int EPC = TT<T>::EPC;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (size_t)gridDim.x * 256) {
+    float fa[EPC], fb[EPC];
+    chunk_to_f<T>(((const u32x4*)a)[i], fa); chunk_to_f<T>(((const u32x4*)b)[i], fb);
+#pragma unroll
+    for (int k = 0; k < EPC; ++k) fa[k] += fb[k];
+    ((u32x4*)y)[i] = f_to_chunk<T>(fa);
+  }
+}
+
+// ------------------------------------------------------------------ stem: Cin = 1 convolution (k = 1 or 3)
+// y[v][c] = b[c] + sum_t w[c][t] * xm[v + t - pad],  xm = x on active patches, 0 elsewhere / outside.
+// 27 broadcast input reads per voxel (L1-resident stencil), one 16-byte chunk of channels per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, Geo g, int k,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            T* __restrict__ y) {
+  constexpr int EPC = TT<T>::EPC;
+  extern __shared__ float wl[];                              // [C][k^3]
+  const int nt = k * k * k, pad = k / 2;
+  for (int i = threadIdx.x; i < g.C * nt; i += 256) wl[i] = w[i];
+  __syncthreads();
+  Walk<T> wk(g.C);
+  if (!wk.live) return;
+  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+    const int ww = v % g.W; long t = v / g.W; const int hh = t % g.H; t /= g.H; const int dd = t % g.D; const int b = t / g.D;
+    if (!g.mask.active(b, dd, hh, ww)) continue;
+    float o[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) o[i] = bias ? bias[wk.cl * EPC + i] : 0.f;
+    int ti = 0;
+    for (int td = 0; td < k; ++td) for (int th = 0; th < k; ++th) for (int tw = 0; tw < k; ++tw, ++ti) {
+      const int id = dd + td - pad, ih = hh + th - pad, iw = ww + tw - pad;
+      float xv = 0.f;
+      if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
+        xv = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) o[i] += wl[(wk.cl * EPC + i) * nt + ti] * xv;
+    }
+    *(u32x4*)(y + (size_t)v * g.C + wk.cl * EPC) = f_to_chunk<T>(o);
+  }
+}
+
+// dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy, Geo g, int k,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+  constexpr int EPC = TT<T>::EPC;
+  extern __shared__ float acc_l[];                           // [C][k^3 + 1]
+  const int nt = k * k * k, pad = k / 2;
+  for (int i = threadIdx.x; i < g.C * (nt + 1); i += 256) acc_l[i] = 0.f;
+  __syncthreads();
+  Walk<T> wk(g.C);
+  if (wk.live) {
+    const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+    for (int tg = 0; tg < nt; tg += 9) {                     // 9 taps at a time keeps the accumulators in registers
+      float a[9][EPC], sb[EPC];
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) a[q][i] = 0.f;
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) sb[i] = 0.f;
+      for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+        const int ww = v % g.W; long t = v / g.W; const int hh = t % g.H; t /= g.H; const int dd = t % g.D; const int b = t / g.D;
+        if (!g.mask.active(b, dd, hh, ww)) continue;
+        float d[EPC];
+        chunk_to_f<T>(*(const u32x4*)(dy + (size_t)v * g.C + wk.cl * EPC), d);
+        if (tg == 0) {
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) sb[i] += d[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+          const int ti = tg + q;
+          if (ti < nt) {
+            const int td = ti / (k * k), th = (ti / k) % k, tw = ti % k;
+            const int id = dd + td - pad, ih = hh + th - pad, iw = ww + tw - pad;
+            float xv = 0.f;
+            if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
+              xv = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) a[q][i] += d[i] * xv;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 9; ++q)
+        if (tg + q < nt)
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) atomicAdd(&acc_l[(wk.cl * EPC + i) * (nt + 1) + tg + q], a[q][i]);
+      if (tg == 0)
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) atomicAdd(&acc_l[(wk.cl * EPC + i) * (nt + 1) + nt], sb[i]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < g.C * (nt + 1); i += 256) {
+    const int c = i / (nt + 1), t = i % (nt + 1);
+    if (t < nt) atomicAdd(&dw[c * nt + t], acc_l[i]);
+    else if (db) atomicAdd(&db[c], acc_l[i]);
+  }
+}
+
+// ------------------------------------------------------------------ 1x1 projection C -> 1 (P/decoder3D.py:51,61)
+template <typename T>
+__global__ __launch_bounds__(256) void proj_fwd_kernel(const T* __restrict__ x, long nvox, int C, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ rec) {
+  constexpr int EPC = TT<T>::EPC;
+  const long v = (long)blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvox) return;
+  float s = b[0];
+  for (int c = 0; c < C; c += EPC) {
+    float f[EPC];
+    chunk_to_f<T>(*(const u32x4*)(x + (size_t)v * C + c), f);
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) s += f[i] * w[c + i];
+  }
+  rec[v] = s;
+}
+
+// dx[v][c] = drec[v]*w[c];  dw[c] += sum_v drec[v]*x[v][c];  db += sum_v drec[v]
+template <typename T>
+__global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, const float* __restrict__ drec, long nvox, int C,
+                                                       const float* __restrict__ w, T* __restrict__ dx, float* __restrict__ dw,
+                                                       float* __restrict__ db) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 8];
+  __shared__ float redb[4];
+  Walk<T> wk(C);
+  float sw[EPC], wv[EPC], sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { sw[i] = 0.f; wv[i] = wk.live ? w[wk.cl * EPC + i] : 0.f; }
+  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, nvox);
+  if (wk.live)
+    for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+      const float d = drec[v];
+      const size_t off = (size_t)v * C + wk.cl * EPC;
+      float f[EPC], o[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + off), f);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { sw[i] += d * f[i]; o[i] = d * wv[i]; }
+      *(u32x4*)(dx + off) = f_to_chunk<T>(o);
+      if (wk.cl == 0) sb += d;
+    }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) red[threadIdx.x * 8 + i] = sw[i];
+  sb = warp_sum(sb);
+  if ((threadIdx.x & 63) == 0) redb[threadIdx.x >> 6] = sb;
+  __syncthreads();
+  if (threadIdx.x < wk.cpv) {
+    float a1[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) a1[i] = 0.f;
+    for (int vl = 0; vl < wk.vpp; ++vl)
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) atomicAdd(&dw[threadIdx.x * EPC + i], a1[i]);
+  }
+  if (threadIdx.x == 0) atomicAdd(db, redb[0] + redb[1] + redb[2] + redb[3]);
+}
+
+// ------------------------------------------------------------------ weight (un)packing
+// dst[t][r][k] = src[r*sr + k*sk + t]   (fp32 master -> compute dtype, MFMA row-fragment layout)
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int K, int taps, long sr, long sk) {
+  const long n = (long)taps * R * K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int k = i % K; long t = i / K; const int r = t % R; const int tp = t / R;
+    TT<T>::st(dst + i, src[r * sr + k * sk + tp]);
+  }
+}
+// dst[r*sr + k*sk + t] (+)= src[t][r][k]
+__global__ void unpack_grad_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int taps, long sr, long sk, int accumulate) {
+  const long n = (long)taps * R * K;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {   // i walks dst order: coalesced writes
+    const int tp = i % taps; long t = i / taps;
+    long r, k;
+    if (sr > sk) { k = t % K; r = t / K; } else { r = t % R; k = t / R; }
+    const float v = src[((long)tp * R + r) * K + k];
+    float* d = dst + r * sr + k * sk + tp;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+inline int nblk(long nvox) { return (int)((nvox + VPW - 1) / VPW); }
+inline Geo mkgeo(int B, int D, int H, int W, int C, const uint8_t* mask, int bs, int fd, int fh, int fw) {
+  Geo g; g.B = B; g.D = D; g.H = H; g.W = W; g.C = C; g.mask = MaskView{mask, fd, fh, fw, bs}; return g;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == AM_DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+#define CHK_C(C) do { if ((C) % 8 || (C) > 2048 || (C) <= 0) return -1; } while (0)
+
+extern "C" {
+
+int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
+                  int fw, double* sums, void* stream) {
+  CHK_C(C);
+  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
+  const int nb = nblk((long)B * D * H * W);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(chan_stats_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, sums),
+             hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, sums));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out, void* stream) {
+  hipLaunchKernelGGL(mask_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, n, voxels_per_patch, out);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_norm_finalize(const double* sums, const double* count_ptr, double count_host, int C, const float* gamma,
+                     const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift, float* run_mean,
+                     float* run_var, float momentum, void* stream) {
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count_ptr, count_host,
+                     C, gamma, beta, eps, mean, rstd, scale, shift, run_mean, run_var, momentum);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_norm_fold_running(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
+                         float* scale, float* shift, void* stream) {
+  hipLaunchKernelGGL(norm_fold_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, run_mean,
+                     run_var, eps, scale, shift);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
+                  int fw, const float* scale, const float* shift, int act, const void* res, const float* stem_x,
+                  const float* stem_w, const float* stem_b, const float* fill, void* y, void* stream) {
+  CHK_C(C);
+  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblk((long)B * D * H * W);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(norm_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,
+                                (const float*)res, stem_x, stem_w, stem_b, fill, (float*)y),
+             hipLaunchKernelGGL(norm_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, scale, shift, act,
+                                (const bf16_t*)res, stem_x, stem_w, stem_b, fill, (bf16_t*)y));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
+                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
+                       int fill, double* bsum, void* stream) {
+  CHK_C(C);
+  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C, st);
+  const int nb = nblk((long)B * D * H * W);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
+                                (const float*)x, g, mean, rstd, act, fill, bsum),
+             hipLaunchKernelGGL(norm_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,
+                                (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
+                         const float* rstd, float* k0, float* k1, float* k2, float* dgamma, float* dbeta, float* dtoken,
+                         void* stream) {
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bsum, count_ptr,
+                     count_host, C, gamma, rstd, k0, k1, k2, dgamma, dbeta, dtoken);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
+                      const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
+                      const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, void* stream) {
+  CHK_C(C);
+  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblk((long)B * D * H * W);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
+                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres),
+             hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
+                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
+                int fw, float* out_accum, void* stream) {
+  CHK_C(C);
+  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblk((long)B * D * H * W);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(chan_sum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, out_accum),
+             hipLaunchKernelGGL(chan_sum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, out_accum));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nchunk = (size_t)n_elems / (dtype == AM_DT_BF16 ? 8 : 4);
+  int nb = (int)((nchunk + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(add_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, nchunk),
+             hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, nchunk));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int C, int ksize, const uint8_t* mask, int bshift,
+                     int fd, int fh, int fw, const float* w, const float* bias, void* y, void* stream) {
+  CHK_C(C);
+  if (ksize != 1 && ksize != 3) return -2;
+  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblk((long)B * D * H * W);
+  const size_t sm = sizeof(float) * C * ksize * ksize * ksize;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_conv_fwd_kernel<float>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (float*)y),
+             hipLaunchKernelGGL(stem_conv_fwd_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (bf16_t*)y));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
+                       const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum, void* stream) {
+  CHK_C(C);
+  if (ksize != 1 && ksize != 3) return -2;
+  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblk((long)B * D * H * W);
+  const size_t sm = sizeof(float) * C * (ksize * ksize * ksize + 1);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(stem_conv_wgrad_kernel<float>, dim3(nb), dim3(256), sm, st, x, (const float*)dy, g, ksize, dw_accum, db_accum),
+             hipLaunchKernelGGL(stem_conv_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, (const bf16_t*)dy, g, ksize, dw_accum, db_accum));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b, float* rec, void* stream) {
+  CHK_C(C);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = (int)((nvox + 255) / 256);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(proj_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, nvox, C, w, b, rec),
+             hipLaunchKernelGGL(proj_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, nvox, C, w, b, rec));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, void* dx, float* dw_accum,
+                float* db_accum, void* stream) {
+  CHK_C(C);
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = nblk(nvox);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(proj_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, drec, nvox, C, w, (float*)dx, dw_accum, db_accum),
+             hipLaunchKernelGGL(proj_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, w, (bf16_t*)dx, dw_accum, db_accum));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)taps * R * K;
+  int nb = (int)((n + 255) / 256); if (nb > 8192) nb = 8192;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, src, (float*)dst, R, K, taps, stride_r, stride_k),
+             hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_unpack_grad(const float* src_packed, float* dst, int R, int K, int taps, long stride_r, long stride_k, int accumulate,
+                   void* stream) {
+  const long n = (long)taps * R * K;
+  int nb = (int)((n + 255) / 256); if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(unpack_grad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src_packed, dst, R, K, taps, stride_r, stride_k, accumulate);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""ctypes binding of libanatomask_hip.so (the C ABI declared in include/anatomask_hip.h).
+
+The HIP library is the product path: if it is missing this module raises at import of the
+symbol table -- there is no CPU or torch fallback anywhere in the package."""
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libanatomask_hip.so")
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "anatomask_hip.h")
+
+DT_F32, DT_BF16 = 0, 1
+CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
+ACT_NONE, ACT_LRELU, ACT_RELU6 = 0, 1, 2
+
+_CT = {"int": C.c_int, "long": C.c_long, "float": C.c_float, "double": C.c_double}
+
+
+def declared_functions(header: str = HEADER):
+    """Parse `int am_xxx(args);` prototypes from the header -> {name: [ctypes argtypes]}."""
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\bint\s+(am_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        types = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    types.append(C.c_void_p)
+                else:
+                    types.append(_CT[a.replace("const ", "").split(" ")[0]])
+        out[name] = types
+    return out
+
+
+class HipLib:
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not built: run `python -m anatomask_amd.build` (no fallback path exists)")
+        self._lib = C.CDLL(path)
+        self.functions = declared_functions()
+        for name, argtypes in self.functions.items():
+            fn = getattr(self._lib, name)       # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+            setattr(self, name[3:], self._wrap(name, fn))
+
+    @staticmethod
+    def _wrap(name, fn):
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise RuntimeError(f"{name} failed with code {rc}")
+        call.__name__ = name
+        return call
+
+
+_LIB = None
+
+
+def lib() -> HipLib:
+    global _LIB
+    if _LIB is None:
+        _LIB = HipLib()
+    return _LIB

@@ -1,0 +1,278 @@
+"""Thin torch-tensor front end of the C ABI: every function takes device tensors (channels-last
+[B,D,H,W,C]; fp32 or bf16), extracts raw pointers + the current HIP stream, and calls the HIP
+library.  torch is used for memory and streams only; no arithmetic happens here."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+from .hip import ACT_LRELU, ACT_NONE, ACT_RELU6, CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD  # noqa: F401
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return hip.DT_F32
+    if t.dtype == torch.bfloat16:
+        return hip.DT_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class MaskInfo:
+    """uint8 patch mask [B, fd, fh, fw] (1 = active)."""
+
+    def __init__(self, mask_u8: torch.Tensor):
+        assert mask_u8.dtype == torch.uint8 and mask_u8.dim() == 4 and mask_u8.is_contiguous()
+        self.t = mask_u8
+        self.B, self.fd, self.fh, self.fw = mask_u8.shape
+
+    @staticmethod
+    def from_bool(active_b1fff: torch.Tensor, device) -> "MaskInfo":
+        m = active_b1fff.reshape(active_b1fff.shape[0], *active_b1fff.shape[-3:]).to(device=device, dtype=torch.uint8).contiguous()
+        return MaskInfo(m)
+
+
+def _mk(mask: Optional[MaskInfo]):
+    if mask is None:
+        return None, 1, 1, 1
+    return mask.t.data_ptr(), mask.fd, mask.fh, mask.fw
+
+
+# ------------------------------------------------------------------ weights
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_dgrad: bool) -> torch.Tensor:
+    """torch-layout fp32 weight -> packed [taps][rows][K] in `dtype`.
+    Conv3d weight (Cout,Cin,k,k,k); ConvTranspose3d weight (Cin,Cout,k,k,k).
+    forward: rows = output channels, K = input channels; dgrad: swapped."""
+    d0, d1 = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3] * w.shape[4]
+    cout, cin = (d1, d0) if transposed_conv else (d0, d1)
+    s_out, s_in = (taps, d1 * taps) if transposed_conv else (d1 * taps, taps)
+    if not for_dgrad:
+        R, K, sr, sk = cout, cin, s_out, s_in
+    else:
+        R, K, sr, sk = cin, cout, s_in, s_out
+    out = torch.empty(taps, R, K, device=w.device, dtype=dtype)
+    hip.lib().pack_weight(_dt(out), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, _stream())
+    return out
+
+
+def unpack_grad(dw_packed: torch.Tensor, grad_out: torch.Tensor, transposed_conv: bool, accumulate: bool):
+    """packed fp32 [taps][Cy][Cx] (Cy = forward-output channels) -> torch-layout gradient."""
+    taps, R, K = dw_packed.shape
+    d1 = grad_out.shape[1]
+    if transposed_conv:      # weight (Cin=Cx, Cout=Cy, taps)
+        sr, sk = taps, d1 * taps
+    else:                    # weight (Cout=Cy, Cin=Cx, taps)
+        sr, sk = d1 * taps, taps
+    hip.lib().unpack_grad(dw_packed.data_ptr(), grad_out.data_ptr(), R, K, taps, sr, sk, int(accumulate), _stream())
+
+
+# ------------------------------------------------------------------ convolutions
+def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], out_spatial: Tuple[int, int, int],
+           ksize: int, stride: int, in_mask: Optional[MaskInfo] = None, in_bshift: int = 0,
+           out_mask: Optional[MaskInfo] = None, out_bshift: int = 0, out: Optional[torch.Tensor] = None,
+           accumulate: bool = False) -> torch.Tensor:
+    B, Di, Hi, Wi, Cin = x.shape
+    Cout = w_packed.shape[1]
+    assert w_packed.shape[2] == Cin and w_packed.dtype == x.dtype, (w_packed.shape, x.shape)
+    Do, Ho, Wo = out_spatial
+    if out is None:
+        out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
+    mk = in_mask or out_mask
+    mp, fd, fh, fw = _mk(mk)
+    hip.lib().conv3d(mode, _dt(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
+                     B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
+                     in_mask.t.data_ptr() if in_mask else None, in_bshift,
+                     out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate), _stream())
+    return out
+
+
+def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int,
+                 x_mask: Optional[MaskInfo] = None, x_bshift: int = 0, y_mask: Optional[MaskInfo] = None,
+                 y_bshift: int = 0) -> torch.Tensor:
+    B, Dx, Hx, Wx, Cx = x.shape
+    _, Dy, Hy, Wy, Cy = dy.shape
+    taps = ksize ** 3
+    dw = torch.zeros(taps, Cy, Cx, device=x.device, dtype=torch.float32)
+    mk = x_mask or y_mask
+    mp, fd, fh, fw = _mk(mk)
+    hip.lib().conv3d_wgrad(mode, _dt(x), ksize, stride, x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
+                           B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy,
+                           x_mask.t.data_ptr() if x_mask else None, x_bshift,
+                           y_mask.t.data_ptr() if y_mask else None, y_bshift, fd, fh, fw, _stream())
+    return dw
+
+
+def stem_conv_fwd(x_b1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mask: Optional[MaskInfo], bshift: int,
+                  dtype: torch.dtype) -> torch.Tensor:
+    """x_b1: fp32 [B,D,H,W]; w: (C,1,k,k,k) fp32."""
+    B, D, H, W = x_b1.shape
+    Cc, k = w.shape[0], w.shape[2]
+    y = torch.empty(B, D, H, W, Cc, device=x_b1.device, dtype=dtype)
+    mp, fd, fh, fw = _mk(mask)
+    hip.lib().stem_conv_fwd(_dt(y), x_b1.data_ptr(), B, D, H, W, Cc, k, mp, bshift, fd, fh, fw, w.data_ptr(), _p(bias),
+                            y.data_ptr(), _stream())
+    return y
+
+
+def stem_conv_wgrad(x_b1: torch.Tensor, dy: torch.Tensor, ksize: int, mask: Optional[MaskInfo], bshift: int,
+                    dw_accum: torch.Tensor, db_accum: Optional[torch.Tensor]):
+    B, D, H, W, Cc = dy.shape
+    mp, fd, fh, fw = _mk(mask)
+    hip.lib().stem_conv_wgrad(_dt(dy), x_b1.data_ptr(), dy.data_ptr(), B, D, H, W, Cc, ksize, mp, bshift, fd, fh, fw,
+                              dw_accum.data_ptr(), _p(db_accum), _stream())
+
+
+# ------------------------------------------------------------------ norms
+class NormStats:
+    """Per-channel statistics + folded coefficients of one norm instance (all fp32, length C)."""
+
+    def __init__(self, C: int, device):
+        self.sums = torch.empty(C, 2, device=device, dtype=torch.float64)
+        self.buf = torch.empty(4, C, device=device, dtype=torch.float32)
+        self.mean, self.rstd, self.scale, self.shift = self.buf[0], self.buf[1], self.buf[2], self.buf[3]
+        self.count_ptr: Optional[torch.Tensor] = None
+        self.count_host: float = 0.0
+
+
+def chan_stats(x: torch.Tensor, mask: Optional[MaskInfo], bshift: int, st: NormStats):
+    B, D, H, W, Cc = x.shape
+    mp, fd, fh, fw = _mk(mask)
+    hip.lib().chan_stats(_dt(x), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw, st.sums.data_ptr(), _stream())
+
+
+def mask_count(mask: MaskInfo, voxels_per_patch: int, out: torch.Tensor):
+    hip.lib().mask_count(mask.t.data_ptr(), mask.t.numel(), voxels_per_patch, out.data_ptr(), _stream())
+
+
+def norm_finalize(st: NormStats, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
+                  run_mean: Optional[torch.Tensor] = None, run_var: Optional[torch.Tensor] = None, momentum: float = 0.1):
+    Cc = gamma.numel()
+    hip.lib().norm_finalize(st.sums.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), beta.data_ptr(),
+                            eps, st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                            _p(run_mean), _p(run_var), momentum, _stream())
+
+
+def norm_fold_running(st: NormStats, gamma, beta, run_mean, run_var, eps: float):
+    hip.lib().norm_fold_running(gamma.numel(), gamma.data_ptr(), beta.data_ptr(), run_mean.data_ptr(), run_var.data_ptr(), eps,
+                                st.scale.data_ptr(), st.shift.data_ptr(), _stream())
+
+
+def norm_apply(x: torch.Tensor, st: NormStats, act: int, mask: Optional[MaskInfo] = None, bshift: int = 0,
+               res: Optional[torch.Tensor] = None, stem: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None,
+               fill: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    B, D, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    mp, fd, fh, fw = _mk(mask)
+    sx, sw, sb = stem if stem is not None else (None, None, None)
+    hip.lib().norm_apply(_dt(x), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw, st.scale.data_ptr(), st.shift.data_ptr(),
+                         act, _p(res), _p(sx), _p(sw), _p(sb), _p(fill), out.data_ptr(), _stream())
+    return out
+
+
+class NormBwdScratch:
+    def __init__(self, C: int, device):
+        self.bsum = torch.empty(C, 3, device=device, dtype=torch.float64)
+        self.k = torch.empty(3, C, device=device, dtype=torch.float32)
+
+
+def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tensor, st: NormStats, gamma: torch.Tensor, act: int,
+                  mask: Optional[MaskInfo], bshift: int, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
+                  dtoken: Optional[torch.Tensor] = None, fill: bool = False, dx: Optional[torch.Tensor] = None,
+                  dres: Optional[torch.Tensor] = None, scratch: Optional[NormBwdScratch] = None) -> torch.Tensor:
+    """Backward of y = act(norm(x) [+res]) (or the densify fill).  Returns dx; accumulates dgamma/dbeta/dtoken."""
+    B, D, H, W, Cc = x.shape
+    sc = scratch or NormBwdScratch(Cc, x.device)
+    mp, fd, fh, fw = _mk(mask)
+    L = hip.lib()
+    s = _stream()
+    L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
+                      st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), sc.bsum.data_ptr(), s)
+    L.norm_bwd_finalize(sc.bsum.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
+                        sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), s)
+    if dx is None:
+        dx = torch.empty_like(x)
+    L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
+                     st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
+                     dx.data_ptr(), _p(dres), s)
+    return dx
+
+
+def chan_sum(x: torch.Tensor, mask: Optional[MaskInfo], bshift: int, out_accum: torch.Tensor):
+    B, D, H, W, Cc = x.shape
+    mp, fd, fh, fw = _mk(mask)
+    hip.lib().chan_sum(_dt(x), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw, out_accum.data_ptr(), _stream())
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty_like(a)
+    hip.lib().add(_dt(a), a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream())
+    return out
+
+
+# ------------------------------------------------------------------ proj / loss / sampler / optimizer
+def proj_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    B, D, H, W, Cc = x.shape
+    rec = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32)
+    hip.lib().proj_fwd(_dt(x), x.data_ptr(), B * D * H * W, Cc, w.data_ptr(), b.data_ptr(), rec.data_ptr(), _stream())
+    return rec
+
+
+def proj_bwd(x: torch.Tensor, drec: torch.Tensor, w: torch.Tensor, dw_accum: torch.Tensor, db_accum: torch.Tensor) -> torch.Tensor:
+    B, D, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    hip.lib().proj_bwd(_dt(x), x.data_ptr(), drec.data_ptr(), B * D * H * W, Cc, w.data_ptr(), dx.data_ptr(), dw_accum.data_ptr(),
+                       db_accum.data_ptr(), _stream())
+    return dx
+
+
+def patch_loss_fwd(inp: torch.Tensor, rec: torch.Tensor, mask: MaskInfo, normalized: bool, want_loss: bool = True):
+    """inp/rec fp32 [B,D,H,W] -> (l2m [B,L], pmean, prstd, lossinfo[2] or None)."""
+    B, D, H, W = inp.shape
+    L = mask.fd * mask.fh * mask.fw
+    l2m = torch.empty(B, L, device=inp.device, dtype=torch.float32)
+    pm = torch.empty(B, L, device=inp.device, dtype=torch.float32)
+    pr = torch.empty(B, L, device=inp.device, dtype=torch.float32)
+    info = torch.empty(2, device=inp.device, dtype=torch.float32) if want_loss else None
+    hip.lib().patch_loss_fwd(inp.data_ptr(), rec.data_ptr(), mask.t.data_ptr(), B, D, H, W, int(normalized), l2m.data_ptr(),
+                             pm.data_ptr(), pr.data_ptr(), _p(info), _stream())
+    return l2m, pm, pr, info
+
+
+def patch_loss_bwd(inp, rec, mask: MaskInfo, pm, pr, info, gout: Optional[torch.Tensor]) -> torch.Tensor:
+    B, D, H, W = inp.shape
+    drec = torch.empty_like(rec)
+    hip.lib().patch_loss_bwd(inp.data_ptr(), rec.data_ptr(), mask.t.data_ptr(), B, D, H, W, pm.data_ptr(), pr.data_ptr(),
+                             info.data_ptr(), _p(gout), drec.data_ptr(), _stream())
+    return drec
+
+
+def mask_sampler(loss: torch.Tensor, keys: torch.Tensor, len_keep: int, len_loss: int) -> torch.Tensor:
+    B, L = loss.shape
+    out = torch.empty(B, L, device=loss.device, dtype=torch.uint8)
+    hip.lib().mask_sampler(loss.data_ptr(), keys.data_ptr(), B, L, len_keep, len_loss, out.data_ptr(), _stream())
+    return out
+
+
+def sumsq(g: torch.Tensor, out: torch.Tensor):
+    hip.lib().sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream())
+
+
+def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, ema_decay, gnorm_out):
+    hip.lib().adamw_ema(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(ema), n, lr, betas[0], betas[1], eps, wd, step,
+                        _p(sumsq_t), max_norm, ema_decay, _p(gnorm_out), _stream())
+
+
+def ema(ema_t: torch.Tensor, p: torch.Tensor, decay: float):
+    hip.lib().ema(ema_t.data_ptr(), p.data_ptr(), p.numel(), decay, _stream())

@@ -1,0 +1,128 @@
+/* anatomask_hip.h -- C ABI of libanatomask_hip.so (gfx950 / MI355X).
+ *
+ * The reference (ricklisz/AnatoMask) is 100 % Python on torch/cuDNN: it has NO FFI or plugin layer
+ * (SURVEY.md 8b).  The drop-in boundary for its hot path is therefore this library: plain pointers,
+ * sizes and a hipStream_t (passed as void*), no torch types.  Each entry point names the reference
+ * code it replaces (paths relative to nnunetv2/training/nnUNetTrainer/variants/pretrain/ = P/).
+ *
+ * Conventions
+ *  - activations: channels-last [B][D][H][W][C], dtype AM_DT_F32 (float) or AM_DT_BF16 (uint16 bits),
+ *    C % 8 == 0, 16-byte aligned base pointers.  C == 1 tensors (input volume, reconstruction) are fp32.
+ *  - patch mask: uint8 [B][fd][fh][fw] (1 = visible/active); a tensor whose voxels are (1<<bshift)
+ *    per patch edge is "block-sparse": kernels read inactive voxels as 0 and never rely on what is
+ *    stored there.  mask == NULL means dense.
+ *  - every function is asynchronous on `stream`, never allocates, never synchronises, returns 0 or
+ *    a negative argument error / positive hipError_t.
+ *  - packed conv weights: [tap][rows][K] in the compute dtype, rows = channels of the tensor WRITTEN,
+ *    K = channels of the tensor READ, tap = (td*k + th)*k + tw of the original kernel.
+ */
+#ifndef ANATOMASK_HIP_H
+#define ANATOMASK_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AM_DT_F32 0
+#define AM_DT_BF16 1
+
+#define AM_CONV_FWD 0     /* y[o]  = sum_t x[o*stride + t - k/2] W_t        (k = 1|3, stride 1|2)            */
+#define AM_CONV_DGRAD 1   /* dx[i] = sum_t dy[(i + k/2 - t)/stride] W_t^T   (data gradient of AM_CONV_FWD)   */
+#define AM_CONVT_FWD 2    /* y[o]  = sum_t x[(o + 1 - t)/2] W_t             (ConvTranspose3d k4 s2 p1)       */
+#define AM_CONVT_DGRAD 3  /* dx[i] = sum_t dy[2i - 1 + t] W_t^T                                              */
+
+#define AM_ACT_NONE 0
+#define AM_ACT_LRELU 1    /* LeakyReLU(0.01)  P/STUNet_head.py:84,89 */
+#define AM_ACT_RELU6 2    /* ReLU6            P/decoder3D.py:21      */
+
+int am_version(void);
+
+/* Convolutions on the matrix cores.
+ * Replaces: SparseConv3d / sp_conv_forward P/encoder3D.py:12-15,27-28 (in_mask/out_mask set),
+ * densify_proj Conv3d P/AnatoMask.py:63-65, UNetBlock convs + ConvTranspose3d P/decoder3D.py:19-22,
+ * and their autograd data gradients (loss.backward() P/pretrain_AntoMask.py:435). */
+int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed, const float* bias, void* y,
+              int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
+              const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift, int fd, int fh, int fw,
+              int accumulate, void* stream);
+
+/* Weight gradient (autograd of the above).  mode = AM_CONV_FWD or AM_CONVT_FWD.  x = forward input
+ * [B][Dx][Hx][Wx][Cx], dy = gradient of the forward output [B][Dy][Hy][Wy][Cy];
+ * dw_packed fp32 [tap][Cy][Cx] is ACCUMULATED into (zero it first). */
+int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, const void* dy, float* dw_packed,
+                    int B, int Dx, int Hx, int Wx, int Cx, int Dy, int Hy, int Wy, int Cy,
+                    const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift, int fd, int fh, int fw,
+                    void* stream);
+
+/* dst[t][r][k] = src[r*stride_r + k*stride_k + t]: torch-layout fp32 master weights -> packed compute-dtype. */
+int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, void* stream);
+/* dst[r*stride_r + k*stride_k + t] (+)= src[t][r][k]: packed fp32 gradient -> torch layout. */
+int am_unpack_grad(const float* src_packed, float* dst, int R, int K, int taps, long stride_r, long stride_k, int accumulate,
+                   void* stream);
+
+/* Cin = 1 stem convolutions (STUNet stage 0 conv1 k3 / conv3 k1 on the masked input volume,
+ * P/STUNet_head.py:81,92 under P/encoder3D.py:12-15) and their weight/bias gradients. */
+int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int C, int ksize, const uint8_t* mask, int bshift,
+                     int fd, int fh, int fw, const float* w, const float* bias, void* y, void* stream);
+int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
+                       const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum, void* stream);
+
+/* Pooled sparse InstanceNorm (P/encoder3D.py:138-165: statistics over ALL active voxels of the local
+ * batch) and BatchNorm3d (P/decoder3D.py:21-22) share these: stats -> finalize -> apply. */
+int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
+                  int fw, double* sums /* [C][2], zeroed inside */, void* stream);
+int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out, void* stream);
+int am_norm_finalize(const double* sums, const double* count_ptr, double count_host, int C, const float* gamma,
+                     const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                     float* run_mean /* NULL or BN running stats, updated */, float* run_var, float momentum, void* stream);
+int am_norm_fold_running(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
+                         float* scale, float* shift, void* stream);   /* eval-mode BN (teacher) */
+/* y = act(x*scale + shift [+ res] [+ stem_w*stem_x + stem_b]); fill != NULL: inactive voxels := mask token
+ * (densify, P/AnatoMask.py:158-163).  Fuses norm + LeakyReLU/ReLU6 + residual add (P/STUNet_head.py:96-103). */
+int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
+                  int fw, const float* scale, const float* shift, int act, const void* res, const float* stem_x,
+                  const float* stem_w, const float* stem_b, const float* fill, void* y, void* stream);
+/* backward: bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout}, dpre = dout*act'(out) */
+int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
+                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
+                       int fill, double* bsum /* [C][3], zeroed inside */, void* stream);
+int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
+                         const float* rstd, float* k0, float* k1, float* k2, float* dgamma_accum, float* dbeta_accum,
+                         float* dtoken_accum, void* stream);
+int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
+                      const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
+                      const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, void* stream);
+int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
+                int fw, float* out_accum, void* stream);   /* conv bias gradients */
+int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream);   /* x + to_dec[i], P/decoder3D.py:59 */
+
+/* 1x1 projection C -> 1 (P/decoder3D.py:51,61) and its backward. rec/drec are fp32 [B][D][H][W]. */
+int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b, float* rec, void* stream);
+int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, void* dx, float* dw_accum,
+                float* db_accum, void* stream);
+
+/* Per-patch reconstruction loss without materialising patchify (P/AnatoMask.py:190-202,221-228;
+ * teacher variant normalized=0: P/pretrain_AntoMask.py:423-425).  l2m = per-patch MSE * non_active (B*L);
+ * lossinfo[0] = loss, lossinfo[1] = 1/(count+1e-8). */
+int am_patch_loss_fwd(const float* inp, const float* rec, const uint8_t* active, int B, int D, int H, int W, int normalized,
+                      float* l2m, float* pmean, float* prstd, float* lossinfo, void* stream);
+int am_patch_loss_bwd(const float* inp, const float* rec, const uint8_t* active, int B, int D, int H, int W, const float* pmean,
+                      const float* prstd, const float* lossinfo, const float* gout, float* drec, void* stream);
+
+/* Reconstruction-guided hard-mask sampler, SparK.generate_mask P/AnatoMask.py:81-128 (mask output),
+ * key-driven: the len_loss highest-loss patches are never visible, of the rest the len_keep smallest
+ * keys are.  No host round trip (the reference does .cpu().numpy() per sample, :112-114). */
+int am_mask_sampler(const float* loss, const float* keys, int B, int L, int len_keep, int len_loss, uint8_t* mask, void* stream);
+
+/* clip_grad_norm_(max_norm) + AdamW + ModelEma.update fused over a flat fp32 parameter buffer
+ * (P/pretrain_AntoMask.py:437-440; torch.optim.AdamW; timm.utils.ModelEma). n % 4 == 0. */
+int am_sumsq(const float* g, long n, double* out, void* stream);
+int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, long n, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int step, const double* sumsq /* NULL: no clipping */,
+                 double max_norm, double ema_decay, float* gnorm_out, void* stream);
+int am_ema(float* ema, const float* p, long n, double decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,23 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/anatomask_hip.h declares
+(no compute calls without a GPU)."""
+import ctypes
+import os
+
+from anatomask_amd import build, hip
+
+
+def test_library_builds_and_exports_all_declared_symbols():
+    path = build.build(verbose=False)
+    assert os.path.exists(path)
+    decl = hip.declared_functions()
+    assert len(decl) >= 25, sorted(decl)
+    lib = ctypes.CDLL(path)
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert lib.am_version() >= 1
+
+
+def test_binding_fails_loudly_without_library(tmp_path):
+    import pytest
+    with pytest.raises(RuntimeError):
+        hip.HipLib(str(tmp_path / "missing.so"))

@@ -1,0 +1,387 @@
+"""GPU: every HIP op (through the C ABI) against the CPU oracle ops on the same seeded inputs.
+Tolerances (stated per dtype):
+  fp32 path (exact-f32 MFMA, fp32 storage):   <= 2e-4 of the tensor's max |value|  (reduction order only)
+  bf16 path (bf16 storage, fp32 accumulate):  <= 2e-2 of max |value|, inputs pre-rounded to bf16 on both sides
+Integer/bool outputs (sampler masks) are bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import anatomask_oracle as O
+from tests.helpers import load, tiny_cfg
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from anatomask_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, dtype):            # round through the storage dtype so both sides see identical inputs
+    return t.to(dtype).float()
+
+
+def to_cl(t, dtype):        # NCDHW cpu fp32 -> channels-last device tensor
+    return t.permute(0, 2, 3, 4, 1).contiguous().to(device=DEV, dtype=dtype)
+
+
+def from_cl(t):             # channels-last device -> NCDHW cpu fp32
+    return t.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def close(got, want, tol, what="", mask=None):
+    got, want = got.double(), want.double()
+    if mask is not None:
+        got, want = got * mask, want * mask
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
+
+
+def mk_mask(B, f, keep, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    L = f[0] * f[1] * f[2]
+    idx = torch.rand(B, L, generator=g).argsort(1)[:, :keep]
+    return torch.zeros(B, L, dtype=torch.bool).scatter_(1, idx, True).view(B, 1, *f)
+
+
+# ------------------------------------------------------------------ convolutions
+CONV_CASES = [  # Cin, Cout, k, stride
+    (16, 24, 3, 1), (40, 64, 3, 1), (32, 32, 3, 2), (16, 32, 1, 2), (64, 16, 1, 1), (8, 8, 3, 1), (96, 48, 3, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("sparse", [False, True])
+def test_conv_fwd_dgrad_wgrad(ops, dtype, case, sparse):
+    cin, cout, k, s = case
+    B, f = 2, (2, 3, 2)
+    bs_out = 2                                   # output blocks are 4 voxels wide
+    so = tuple(v << bs_out for v in f)           # (8, 12, 8)
+    si = tuple(v * s for v in so)
+    x = q(rnd(B, cin, *si, seed=1), dtype)
+    w = q(rnd(cout, cin, k, k, k, seed=2, scale=1.0 / np.sqrt(cin * k ** 3)), dtype)
+    bias = rnd(cout, seed=3)
+    dy = q(rnd(B, cout, *so, seed=4), dtype)
+    mask = mk_mask(B, f, 5) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    bs_in = bs_out + (1 if s == 2 else 0)
+    if sparse:
+        x = x * O.upsample_mask(mask, si).float()
+        dy = dy * O.upsample_mask(mask, so).float()
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, bias, stride=s, padding=k // 2)
+    mo = O.upsample_mask(mask, so).float() if sparse else None
+    if sparse:
+        yr = yr * mo
+    yr.backward(dy)
+    # forward
+    wp = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=False)
+    y = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, bias.to(DEV), so, k, s, in_mask=mi, in_bshift=bs_in, out_mask=mi, out_bshift=bs_out)
+    close(from_cl(y), yr.detach(), TOL[dtype], "conv fwd", mo)
+    # data gradient (written only / zero outside active input blocks)
+    wpd = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=True)
+    dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), wpd, None, si, k, s, in_mask=mi, in_bshift=bs_out, out_mask=mi, out_bshift=bs_in)
+    mi_in = O.upsample_mask(mask, si).float() if sparse else None
+    close(from_cl(dx), xr.grad, TOL[dtype], "conv dgrad", mi_in)
+    # accumulate flag
+    dx2 = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), wpd, None, si, k, s, in_mask=mi, in_bshift=bs_out, out_mask=mi, out_bshift=bs_in,
+                     out=dx.clone(), accumulate=True)
+    close(from_cl(dx2), 2 * xr.grad, 2 * TOL[dtype], "conv dgrad accumulate", mi_in)
+    # weight gradient
+    dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dtype), to_cl(dy, dtype), k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out)
+    dw = torch.zeros_like(w, device=DEV)
+    ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+    close(dw.cpu(), wr.grad, TOL[dtype], "conv wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ch", [(32, 32), (16, 16), (64, 64)])
+def test_conv_transpose(ops, dtype, ch):
+    cin, cout = ch
+    B, si = 2, (4, 6, 8)
+    so = tuple(2 * v for v in si)
+    x = q(rnd(B, cin, *si, seed=1), dtype)
+    w = q(rnd(cin, cout, 4, 4, 4, seed=2, scale=1.0 / np.sqrt(cin * 8)), dtype)
+    bias = rnd(cout, seed=3)
+    dy = q(rnd(B, cout, *so, seed=4), dtype)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv_transpose3d(xr, wr, bias, stride=2, padding=1)
+    yr.backward(dy)
+    wp = ops.pack_weight(w.to(DEV), dtype, transposed_conv=True, for_dgrad=False)
+    y = ops.conv3d(ops.CONVT_FWD, to_cl(x, dtype), wp, bias.to(DEV), so, 4, 2)
+    close(from_cl(y), yr.detach(), TOL[dtype], "convT fwd")
+    wpd = ops.pack_weight(w.to(DEV), dtype, transposed_conv=True, for_dgrad=True)
+    dx = ops.conv3d(ops.CONVT_DGRAD, to_cl(dy, dtype), wpd, None, si, 4, 2)
+    close(from_cl(dx), xr.grad, TOL[dtype], "convT dgrad")
+    dwp = ops.conv3d_wgrad(ops.CONVT_FWD, to_cl(x, dtype), to_cl(dy, dtype), 4, 2)
+    dw = torch.zeros_like(w, device=DEV)
+    ops.unpack_grad(dwp, dw, transposed_conv=True, accumulate=False)
+    close(dw.cpu(), wr.grad, TOL[dtype], "convT wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_odd_extent(ops, dtype):
+    """Grids that are not multiples of the 4x8x8 brick (the reference recipe's 7x7x8 stage-4 grid)."""
+    B, cin, cout, sp = 1, 32, 48, (7, 7, 8)
+    x = q(rnd(B, cin, *sp, seed=1), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=2, scale=0.05), dtype)
+    yr = F.conv3d(x, w, None, padding=1)
+    wp = ops.pack_weight(w.to(DEV), dtype, False, False)
+    y = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, sp, 3, 1)
+    close(from_cl(y), yr, TOL[dtype], "conv odd extent")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k", [1, 3])
+def test_stem_conv(ops, dtype, k):
+    B, C, f = 2, 16, (2, 2, 3)
+    sp = tuple(v * 4 for v in f)
+    mask = mk_mask(B, f, 5)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    x = rnd(B, 1, *sp, seed=1)
+    w = rnd(C, 1, k, k, k, seed=2, scale=0.3).requires_grad_(True)
+    b = rnd(C, seed=3).requires_grad_(True)
+    dy = q(rnd(B, C, *sp, seed=4), dtype) * O.upsample_mask(mask, sp).float()
+    yr = O.sparse_conv3d(x * O.upsample_mask(mask, sp).float(), w, b, 1, mask)
+    yr.backward(dy)
+    y = ops.stem_conv_fwd(x[:, 0].contiguous().to(DEV), w.detach().to(DEV), b.detach().to(DEV), mi, 2, dtype)
+    close(from_cl(y), yr.detach(), TOL[dtype], "stem fwd", O.upsample_mask(mask, sp).float())
+    dw = torch.zeros(C, k ** 3, device=DEV); db = torch.zeros(C, device=DEV)
+    ops.stem_conv_wgrad(x[:, 0].contiguous().to(DEV), to_cl(dy, dtype), k, mi, 2, dw, db)
+    close(dw.cpu().view_as(w), w.grad, 5e-4, "stem wgrad")
+    close(db.cpu(), b.grad, 5e-4, "stem bgrad")
+
+
+# ------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [16, 40, 96])
+def test_sparse_instance_norm_fwd_bwd(ops, dtype, C):
+    B, f = 2, (2, 2, 3)
+    sp = tuple(v * 4 for v in f)
+    mask = torch.zeros(B, 1, *f, dtype=torch.bool)
+    mask.view(B, -1)[0, :3] = True; mask.view(B, -1)[1, 2:9] = True          # unequal counts per sample
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    mf = O.upsample_mask(mask, sp).float()
+    x = (q(rnd(B, C, *sp, seed=1), dtype) * mf).requires_grad_(True)
+    res = (q(rnd(B, C, *sp, seed=5), dtype) * mf).requires_grad_(True)
+    gam, bet = (1 + 0.2 * rnd(C, seed=2)).requires_grad_(True), (0.1 * rnd(C, seed=3)).requires_grad_(True)
+    dout = q(rnd(B, C, *sp, seed=4), dtype) * mf
+    yr = F.leaky_relu(O.sparse_instance_norm(x, gam, bet, 1e-5, mask) + res, 0.01)
+    yr.backward(dout)
+    st = ops.NormStats(C, DEV)
+    cnt = torch.zeros(1, device=DEV, dtype=torch.float64)
+    ops.mask_count(mi, 64, cnt)
+    assert cnt.item() == mf[:, 0].sum().item()
+    st.count_ptr = cnt
+    xd = to_cl(x.detach(), dtype)
+    ops.chan_stats(xd, mi, 2, st)
+    ops.norm_finalize(st, gam.detach().to(DEV), bet.detach().to(DEV), 1e-5)
+    y = ops.norm_apply(xd, st, ops.ACT_LRELU, mi, 2, res=to_cl(res.detach(), dtype))
+    close(from_cl(y), yr.detach(), TOL[dtype], "IN fwd", mf)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dres = torch.empty_like(xd)
+    # feed the oracle's own output so both sides take identical LeakyReLU gates
+    dx = ops.norm_backward(to_cl(dout, dtype), to_cl(yr.detach(), dtype), xd, st, gam.detach().to(DEV), ops.ACT_LRELU, mi, 2, dg, db, dres=dres)
+    close(from_cl(dx), x.grad, 2 * TOL[dtype], "IN dx", mf)
+    close(from_cl(dres), res.grad, TOL[dtype], "IN dres", mf)
+    close(dg.cpu(), gam.grad, 2 * TOL[dtype], "IN dgamma")
+    close(db.cpu(), bet.grad, 2 * TOL[dtype], "IN dbeta")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm_train_eval_relu6(ops, dtype):
+    B, C, sp = 2, 24, (6, 8, 10)
+    x = q(rnd(B, C, *sp, seed=1) * 2 + 1.5, dtype).requires_grad_(True)
+    p = {"bn.weight": (1 + 0.2 * rnd(C, seed=2)).requires_grad_(True), "bn.bias": (0.5 * rnd(C, seed=3)).requires_grad_(True),
+         "bn.running_mean": 0.1 * rnd(C, seed=6), "bn.running_var": 1 + 0.1 * rnd(C, seed=7).abs(),
+         "bn.num_batches_tracked": torch.zeros((), dtype=torch.long)}
+    nb = {}
+    yr = F.relu6(O.batch_norm3d(p, "bn", x, True, nb))
+    dout = q(rnd(B, C, *sp, seed=4), dtype)
+    yr.backward(dout)
+    st = ops.NormStats(C, DEV)
+    st.count_host = float(B * sp[0] * sp[1] * sp[2])
+    xd = to_cl(x.detach(), dtype)
+    rm, rv = p["bn.running_mean"].clone().to(DEV), p["bn.running_var"].clone().to(DEV)
+    ops.chan_stats(xd, None, 0, st)
+    ops.norm_finalize(st, p["bn.weight"].detach().to(DEV), p["bn.bias"].detach().to(DEV), 1e-5, rm, rv, 0.1)
+    y = ops.norm_apply(xd, st, ops.ACT_RELU6)
+    close(from_cl(y), yr.detach(), TOL[dtype], "BN train fwd")
+    close(rm.cpu(), nb["bn.running_mean"], 1e-5, "running_mean"); close(rv.cpu(), nb["bn.running_var"], 1e-5, "running_var")
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.norm_backward(to_cl(dout, dtype), to_cl(yr.detach(), dtype), xd, st, p["bn.weight"].detach().to(DEV), ops.ACT_RELU6, None, 0, dg, db)
+    close(from_cl(dx), x.grad, 2 * TOL[dtype], "BN dx")
+    close(dg.cpu(), p["bn.weight"].grad, 2 * TOL[dtype], "BN dgamma"); close(db.cpu(), p["bn.bias"].grad, 2 * TOL[dtype], "BN dbeta")
+    # eval: running statistics
+    ye = O.batch_norm3d(p, "bn", x.detach(), False, None)
+    ops.norm_fold_running(st, p["bn.weight"].detach().to(DEV), p["bn.bias"].detach().to(DEV), p["bn.running_mean"].to(DEV),
+                          p["bn.running_var"].to(DEV), 1e-5)
+    close(from_cl(ops.norm_apply(xd, st, ops.ACT_NONE)), ye, TOL[dtype], "BN eval")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_densify_fill_fwd_bwd(ops, dtype):
+    B, C, f = 2, 32, (2, 3, 2)
+    sp = tuple(v * 2 for v in f)
+    mask = mk_mask(B, f, 5)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    mb = O.upsample_mask(mask, sp)
+    x = (q(rnd(B, C, *sp, seed=1), dtype) * mb.float()).requires_grad_(True)
+    gam, bet = (1 + 0.2 * rnd(C, seed=2)).requires_grad_(True), (0.1 * rnd(C, seed=3)).requires_grad_(True)
+    tok = (0.02 * rnd(1, C, 1, 1, 1, seed=8)).requires_grad_(True)
+    yr = torch.where(mb, O.sparse_instance_norm(x, gam, bet, 1e-6, mask), tok.expand(B, C, *sp))
+    dout = q(rnd(B, C, *sp, seed=4), dtype)
+    yr.backward(dout)
+    st = ops.NormStats(C, DEV)
+    cnt = torch.zeros(1, device=DEV, dtype=torch.float64)
+    ops.mask_count(mi, 8, cnt); st.count_ptr = cnt
+    xd = to_cl(x.detach(), dtype)
+    ops.chan_stats(xd, mi, 1, st)
+    ops.norm_finalize(st, gam.detach().to(DEV), bet.detach().to(DEV), 1e-6)
+    y = ops.norm_apply(xd, st, ops.ACT_NONE, mi, 1, fill=tok.detach().view(-1).to(DEV))
+    close(from_cl(y), yr.detach(), TOL[dtype], "densify fwd")
+    dg, db, dt = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx = ops.norm_backward(to_cl(dout, dtype), None, xd, st, gam.detach().to(DEV), ops.ACT_NONE, mi, 1, dg, db, dtoken=dt, fill=True)
+    close(from_cl(dx), x.grad, 2 * TOL[dtype], "densify dx", mb.float())
+    close(dt.cpu(), tok.grad.view(-1), 2 * TOL[dtype], "token grad")
+    close(dg.cpu(), gam.grad, 2 * TOL[dtype], "densify dgamma")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_shortcut_fused_apply(ops, dtype):
+    """norm2 + (1x1 stem shortcut) + LeakyReLU of STUNet stage 0 fused in one pass."""
+    B, C, f = 1, 16, (2, 2, 2)
+    sp = tuple(v * 4 for v in f)
+    mask = mk_mask(B, f, 4); mi = ops.MaskInfo.from_bool(mask, DEV); mf = O.upsample_mask(mask, sp).float()
+    inp = rnd(B, 1, *sp, seed=9)
+    x = q(rnd(B, C, *sp, seed=1), dtype) * mf
+    gam, bet, w3, b3 = 1 + 0.2 * rnd(C, seed=2), 0.1 * rnd(C, seed=3), rnd(C, 1, 1, 1, 1, seed=5), rnd(C, seed=6)
+    yr = F.leaky_relu(O.sparse_instance_norm(x, gam, bet, 1e-5, mask) + O.sparse_conv3d(inp * mf, w3, b3, 1, mask), 0.01)
+    st = ops.NormStats(C, DEV); cnt = torch.zeros(1, device=DEV, dtype=torch.float64); ops.mask_count(mi, 64, cnt); st.count_ptr = cnt
+    xd = to_cl(x, dtype)
+    ops.chan_stats(xd, mi, 2, st); ops.norm_finalize(st, gam.to(DEV), bet.to(DEV), 1e-5)
+    y = ops.norm_apply(xd, st, ops.ACT_LRELU, mi, 2, stem=(inp[:, 0].contiguous().to(DEV), w3.view(-1).to(DEV), b3.to(DEV)))
+    close(from_cl(y), yr, TOL[dtype], "stem-shortcut apply", mf)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_chan_sum_add_proj(ops, dtype):
+    B, C, sp = 2, 32, (4, 6, 8)
+    x = q(rnd(B, C, *sp, seed=1), dtype)
+    xd = to_cl(x, dtype)
+    out = torch.zeros(C, device=DEV)
+    ops.chan_sum(xd, None, 0, out)
+    close(out.cpu(), x.sum(dim=(0, 2, 3, 4)), 2 * TOL[dtype], "chan_sum")
+    y2 = ops.add(xd, xd)
+    close(from_cl(y2), 2 * x, TOL[dtype], "add")
+    w, b = rnd(1, C, 1, 1, 1, seed=2).requires_grad_(True), rnd(1, seed=3).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    rr = F.conv3d(xr, w, b)
+    drec = rnd(B, 1, *sp, seed=4)
+    rr.backward(drec)
+    rec = ops.proj_fwd(xd, w.detach().view(-1).to(DEV), b.detach().to(DEV))
+    close(rec.cpu(), rr.detach()[:, 0], 1e-4, "proj fwd")
+    dw, db = torch.zeros(C, device=DEV), torch.zeros(1, device=DEV)
+    dx = ops.proj_bwd(xd, drec[:, 0].contiguous().to(DEV), w.detach().view(-1).to(DEV), dw, db)
+    close(from_cl(dx), xr.grad, TOL[dtype], "proj dx")
+    close(dw.cpu(), w.grad.view(-1), 5e-4, "proj dw"); close(db.cpu(), b.grad, 5e-4, "proj db")
+
+
+# ------------------------------------------------------------------ loss / sampler / optimizer
+@pytest.mark.parametrize("normalized", [True, False])
+def test_patch_loss_fwd_bwd(ops, normalized):
+    cfg = O.Config([8] * 6, [1] * 6, 8, (32, 48, 32))
+    B = 2
+    mask = mk_mask(B, cfg.fmap, cfg.len_keep)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    inp = rnd(B, 1, *cfg.input_size, seed=1) * 1.7 + 0.3
+    rec = rnd(B, 1, *cfg.input_size, seed=2).requires_grad_(True)
+    ip, rp = O.patchify(cfg, inp), O.patchify(cfg, rec)
+    if normalized:
+        loss, rl = O.forward_loss(ip, rp, mask)
+        loss.backward()
+    else:
+        rl = O.teacher_patch_loss(ip, rp, mask)
+    l2m, pm, pr, info = ops.patch_loss_fwd(inp[:, 0].contiguous().to(DEV), rec.detach()[:, 0].contiguous().to(DEV), mi, normalized)
+    close(l2m.cpu(), rl.detach(), 1e-5, "per-patch l2")
+    if normalized:
+        assert abs(info[0].item() - loss.item()) <= 1e-5 * abs(loss.item())
+        drec = ops.patch_loss_bwd(inp[:, 0].contiguous().to(DEV), rec.detach()[:, 0].contiguous().to(DEV), mi, pm, pr, info, None)
+        close(drec.cpu(), rec.grad[:, 0], 1e-5, "drec")
+
+
+def test_mask_sampler_golden_and_invariants(ops):
+    f = load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    for tag in "abc":
+        ep, tot, ll = (int(v) for v in f[f"gm_{tag}_ep"])
+        m = ops.mask_sampler(torch.from_numpy(f[f"gm_{tag}_loss"]).to(DEV), torch.from_numpy(f[f"gm_{tag}_keys"]).to(DEV), cfg.len_keep, ll)
+        assert np.array_equal(m.cpu().numpy().astype(bool).reshape(f[f"gm_{tag}_mask"].shape), f[f"gm_{tag}_mask"]), tag   # bit-exact
+    # full-size invariants (192^3: L = 1728) + oracle equality on random draws
+    cfg = O.Config([8] * 6, [1] * 6, 8, (192, 192, 192))
+    B, L = 3, cfg.L
+    g = torch.Generator().manual_seed(5)
+    loss, keys = torch.rand(B, L, generator=g), torch.randn(B, L, generator=g)
+    for ll in (0, 1, 259, L - cfg.len_keep):
+        m = ops.mask_sampler(loss.to(DEV), keys.to(DEV), cfg.len_keep, ll).cpu().bool()
+        assert (m.sum(1) == cfg.len_keep).all()
+        if ll:
+            hard = loss.argsort(1)[:, L - ll:]
+            assert not m.gather(1, hard).any()
+        assert torch.equal(m.view(B, 1, *cfg.fmap), O.generate_mask_from_keys(cfg, loss, keys, ll))
+    # ragged / degenerate sizes
+    for L2, keep in ((1, 1), (27, 11), (1000, 300)):
+        m = ops.mask_sampler(torch.rand(2, L2).to(DEV), torch.rand(2, L2).to(DEV), keep, 0)
+        assert (m.sum(1) == keep).all()
+
+
+def test_adamw_ema_clip(ops):
+    n = 4 * 50000
+    p0, g = rnd(n, seed=1), rnd(n, seed=2) * 0.5
+    P = {"w": p0.clone()}; E = {"w": p0.clone()}; state = {}
+    pd, md, vd, ed = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV), p0.clone().to(DEV)
+    ss = torch.zeros(1, device=DEV, dtype=torch.float64); gn = torch.zeros(1, device=DEV)
+    for step in range(1, 4):
+        gs = {"w": (g * step).clone()}
+        tot = O.clip_grad_norm(gs, 12.0)
+        O.adamw_step(P, gs, state, step, 1e-3)
+        O.ema_update(E, P, 0.99)
+        gd = (g * step).to(DEV)
+        ops.sumsq(gd, ss)
+        ops.adamw_ema(pd, gd, md, vd, ed, n, 1e-3, (0.9, 0.999), 1e-8, 1e-5, step, ss, 12.0, 0.99, gn)
+        assert abs(gn.item() - tot.item()) <= 1e-5 * tot.item()
+        assert (pd.cpu() - P["w"]).abs().max().item() <= 2e-6
+        assert (ed.cpu() - E["w"]).abs().max().item() <= 2e-6
+    e2 = p0.clone().to(DEV)
+    ops.ema(e2, pd, 0.5)
+    assert (e2.cpu() - (0.5 * p0 + 0.5 * pd.cpu())).abs().max().item() <= 1e-6
+
+
+def test_pack_unpack_roundtrip(ops):
+    w = rnd(24, 16, 3, 3, 3, seed=1).to(DEV)
+    for tc in (False, True):
+        wp = ops.pack_weight(w, torch.float32, tc, False)
+        cout, cin = (16, 24) if tc else (24, 16)
+        assert wp.shape == (27, cout, cin)
+        back = torch.zeros_like(w)
+        ops.unpack_grad(wp.contiguous(), back, tc, False)
+        assert torch.equal(back, w)
+        ref = (w.permute(2, 3, 4, 1, 0) if tc else w.permute(2, 3, 4, 0, 1)).reshape(27, cout, cin)
+        assert torch.equal(wp, ref)
+        wd = ops.pack_weight(w, torch.float32, tc, True)
+        assert torch.equal(wd, ref.transpose(1, 2))
