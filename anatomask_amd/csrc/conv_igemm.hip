@@ -232,8 +232,11 @@ template <typename T, int BD, int BH, int BW, int NS>
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
   auto kern = conv_igemm_kernel<T, BD, BH, BW, NS>;
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  static size_t attr_lds = 48 * 1024;             // raise the dynamic-LDS cap only when a launch needs it
+  if (P.lds > attr_lds) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds) == hipSuccess) attr_lds = P.lds;
+    (void)hipGetLastError();
+  }
   dim3 grid(a.B * a.nbd * a.nbh * a.nbw, (a.Cout + 16 * NS - 1) / (16 * NS), a.nclass);
   hipLaunchKernelGGL(kern, grid, dim3(256), P.lds, st, a);
   AM_CHECK_LAUNCH();

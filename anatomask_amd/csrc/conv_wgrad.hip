@@ -182,10 +182,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 template <typename T, int BD, int BH, int BW>
 int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
   auto kern = conv_wgrad_kernel<T, BD, BH, BW>;
-  static bool attr_set = false;
-  if (!attr_set) { hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
   const size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + 16) + maxvox * (KT * sizeof(T) + 16);
   if (lds > 160 * 1024) return -3;
+  static size_t attr_lds = 48 * 1024;
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_lds = lds;
+    (void)hipGetLastError();
+  }
   dim3 grid(split, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), a.ngroup);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   AM_CHECK_LAUNCH();

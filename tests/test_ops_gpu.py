@@ -43,8 +43,9 @@ def from_cl(t):             # channels-last device -> NCDHW cpu fp32
 
 def close(got, want, tol, what="", mask=None):
     got, want = got.double(), want.double()
-    if mask is not None:
-        got, want = got * mask, want * mask
+    if mask is not None:                      # inactive voxels are don't-care (may hold stale/garbage bits)
+        keep = mask.expand_as(want) > 0
+        got, want = torch.where(keep, got, torch.zeros_like(got)), torch.where(keep, want, torch.zeros_like(want))
     scale = want.abs().max().item() + 1e-30
     err = (got - want).abs().max().item()
     assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (tol {tol})"
