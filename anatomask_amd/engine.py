@@ -1,0 +1,300 @@
+"""Forward / backward orchestration of SparK(STUNet) on the HIP kernels.
+
+This is the host side of the hot path: a hand-written tape (no torch.autograd inside) that strings
+the C-ABI kernels together in the order of the reference's forward
+(P/AnatoMask.py:137-176 -> P/encoder3D.py:366 -> P/STUNet_head.py:67-103 -> P/AnatoMask.py:158-168
+-> P/decoder3D.py:55-63) and of its autograd backward (loss.backward(), P/pretrain_AntoMask.py:435).
+
+Data layout in HBM: every activation is channels-last [B,D,H,W,C] in the compute dtype (bf16 or
+fp32).  Encoder tensors are block-sparse: only voxels of active 16^3 patches are ever written or
+read (kernels consult the uint8 patch mask; nothing relies on the content of inactive voxels).
+Parameters / gradients are torch-layout fp32 tensors (views into flat buffers owned by SparK).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU6, CONV_DGRAD, CONV_FWD, CONVT_DGRAD, CONVT_FWD, MaskInfo, NormStats
+
+ENC = "sparse_encoder.sp_cnn.conv_blocks_context"
+DEC = "dense_decoder.dec"
+
+
+@dataclass
+class Spec:
+    """Static model description (what P/pretrain_AntoMask.py:184-215 hard-codes)."""
+    dims: Sequence[int]
+    depth: Sequence[int]
+    width: int
+    input_size: Tuple[int, int, int]
+    in_ch: int = 1
+    out_ch: int = 1
+    downsample: int = 16
+    n_stage: int = 5
+    enc_chs: List[int] = field(init=False)
+    dec_chs: List[int] = field(init=False)
+    fmap: Tuple[int, int, int] = field(init=False)
+
+    def __post_init__(self):
+        assert self.in_ch == 1 and self.out_ch == 1, "the AnatoMask recipe is single-channel CT (P/pretrain_AntoMask.py:188)"
+        assert all(s % self.downsample == 0 for s in self.input_size)
+        self.enc_chs = list(self.dims[:5])
+        n = 4
+        self.dec_chs = [self.width // 2 ** i for i in range(n + 1)]
+        self.fmap = tuple(s // self.downsample for s in self.input_size)
+        assert all(c % 8 == 0 for c in self.enc_chs + self.dec_chs), "channel counts must be multiples of 8"
+
+    def stage_spatial(self, s: int) -> Tuple[int, int, int]:
+        return tuple(v >> s for v in self.input_size)
+
+
+class Tape:
+    """What the student forward keeps for its backward."""
+
+    def __init__(self):
+        self.enc: List[dict] = []          # one dict per BasicResBlock, forward order
+        self.dens: List[dict] = []         # one per densify level (coarse -> fine)
+        self.dec: List[dict] = []          # one per UNetBlock
+        self.last: Optional[torch.Tensor] = None
+        self.counts: Dict[int, torch.Tensor] = {}
+
+
+def _counts(mask: MaskInfo, levels: Sequence[int]) -> Dict[int, torch.Tensor]:
+    """active-voxel counts (device doubles) per block shift."""
+    out = {}
+    buf = torch.empty(len(levels), device=mask.t.device, dtype=torch.float64)
+    for i, bs in enumerate(levels):
+        ops.mask_count(mask, (1 << bs) ** 3, buf[i:i + 1])
+        out[bs] = buf[i:i + 1]
+    return out
+
+
+def _sparse_norm(x, mask, bs, counts, gamma, beta, eps) -> NormStats:
+    st = NormStats(x.shape[-1], x.device)
+    st.count_ptr = counts[bs]
+    ops.chan_stats(x, mask, bs, st)
+    ops.norm_finalize(st, gamma, beta, eps)
+    return st
+
+
+def _batch_norm(x, W, prefix, train: bool) -> NormStats:
+    st = NormStats(x.shape[-1], x.device)
+    if train:
+        st.count_host = float(x.numel() // x.shape[-1])
+        ops.chan_stats(x, None, 0, st)
+        ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"],
+                          W[f"{prefix}.running_var"], 0.1)
+        W[f"{prefix}.num_batches_tracked"].add_(1)
+    else:
+        ops.norm_fold_running(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], W[f"{prefix}.running_mean"],
+                              W[f"{prefix}.running_var"], 1e-5)
+    return st
+
+
+class PackCache:
+    """Compute-dtype MFMA-layout copies of the conv weights, rebuilt when the fp32 master changes."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+        self.store: Dict[Tuple[str, bool], torch.Tensor] = {}
+
+    def invalidate(self):
+        self.store.clear()
+
+    def get(self, W, name: str, transposed: bool, dgrad: bool) -> torch.Tensor:
+        key = (name, dgrad)
+        t = self.store.get(key)
+        if t is None:
+            t = ops.pack_weight(W[name], self.dtype, transposed, dgrad)
+            self.store[key] = t
+        return t
+
+
+# ====================================================================================== forward
+def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
+            tape: Optional[Tape] = None, want_feats: bool = False):
+    """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps)."""
+    dt = pk.dtype
+    B = inp.shape[0]
+    counts = _counts(mask, range(5))
+    if tape is not None:
+        tape.counts = counts
+    feats = []
+    x = None
+    # ------------------------------------------------------------------ sparse encoder
+    for s in range(spec.n_stage):
+        bs = 4 - s
+        sp = spec.stage_spatial(s)
+        for b in range(spec.depth[s]):
+            p = f"{ENC}.{s}.{b}"
+            first = b == 0
+            stride = 2 if (first and s > 0) else 1
+            rec_ = {"p": p, "s": s, "first": first, "stride": stride, "x": x}
+            if s == 0 and first:
+                y1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt)
+            else:
+                y1 = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv1.weight", False, False), W[f"{p}.conv1.bias"], sp, 3, stride,
+                                in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs)
+            st1 = _sparse_norm(y1, mask, bs, counts, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], 1e-5)
+            a1 = ops.norm_apply(y1, st1, ACT_LRELU, mask, bs)
+            y2 = ops.conv3d(CONV_FWD, a1, pk.get(W, f"{p}.conv2.weight", False, False), W[f"{p}.conv2.bias"], sp, 3, 1,
+                            in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
+            st2 = _sparse_norm(y2, mask, bs, counts, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], 1e-5)
+            if s == 0 and first:      # 1x1 Cin=1 shortcut folded into the apply pass
+                out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs,
+                                     stem=(inp, W[f"{p}.conv3.weight"].view(-1), W[f"{p}.conv3.bias"]))
+            elif first:
+                sc = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv3.weight", False, False), W[f"{p}.conv3.bias"], sp, 1, stride,
+                                in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs)
+                out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, res=sc)
+            else:
+                out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, res=x)
+            if tape is not None:
+                rec_.update(y1=y1, st1=st1, a1=a1, y2=y2, st2=st2, out=out)
+                tape.enc.append(rec_)
+            x = out
+        feats.append(x)
+    # ------------------------------------------------------------------ densify (level 4 is dead: P/decoder3D.py:57-60)
+    n_dec = len(spec.dec_chs) - 1
+    to_dec = []
+    for i in range(n_dec):
+        f = feats[4 - i]
+        st = _sparse_norm(f, mask, i, counts, W[f"densify_norms.{i}.weight"], W[f"densify_norms.{i}.bias"], 1e-6)
+        d = ops.norm_apply(f, st, ACT_NONE, mask, i, fill=W[f"mask_tokens.{i}"].view(-1))
+        pw = f"densify_projs.{i}.weight"
+        if pw in W:
+            k = W[pw].shape[-1]
+            pr = ops.conv3d(CONV_FWD, d, pk.get(W, pw, False, False), W[f"densify_projs.{i}.bias"], tuple(d.shape[1:4]), k, 1)
+        else:
+            pr = d
+        to_dec.append(pr)
+        if tape is not None:
+            tape.dens.append({"i": i, "f": f, "st": st, "d": d, "k": W[pw].shape[-1] if pw in W else 0})
+    # ------------------------------------------------------------------ dense decoder
+    x = to_dec[0]
+    for i in range(n_dec):
+        q = f"{DEC}.{i}"
+        so = tuple(2 * v for v in x.shape[1:4])
+        u = ops.conv3d(CONVT_FWD, x, pk.get(W, f"{q}.up_sample.weight", True, False), W[f"{q}.up_sample.bias"], so, 4, 2)
+        c1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1)
+        st1 = _batch_norm(c1, W, f"{q}.conv.1", train)
+        r = ops.norm_apply(c1, st1, ACT_RELU6)
+        c2 = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1)
+        st2 = _batch_norm(c2, W, f"{q}.conv.4", train)
+        nxt = to_dec[i + 1] if i + 1 < n_dec else None       # x = x + to_dec[i+1] fused into the BN apply
+        o = ops.norm_apply(c2, st2, ACT_NONE, res=nxt)
+        if tape is not None:
+            tape.dec.append({"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2})
+        x = o
+    rec = ops.proj_fwd(x, W["dense_decoder.proj.weight"].view(-1), W["dense_decoder.proj.bias"])
+    if tape is not None:
+        tape.last = x
+    return (rec, feats) if want_feats else rec
+
+
+# ====================================================================================== backward
+def _wgrad_into(G, name, mode, x, dy, k, stride, transposed=False, **masks):
+    dwp = ops.conv3d_wgrad(mode, x, dy, k, stride, **masks)
+    ops.unpack_grad(dwp, G[name], transposed, accumulate=True)
+
+
+def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo,
+             tape: Tape, drec: torch.Tensor, after_group=None):
+    """Accumulates parameter gradients into G (fp32, torch layout).  `after_group(tag)` is called when
+    all gradients of a parameter group ('decoder', 'densify', 'stage{s}') are final (DDP overlap hook)."""
+    counts = tape.counts
+    n_dec = len(spec.dec_chs) - 1
+    # ---- projection
+    g = ops.proj_bwd(tape.last, drec, W["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.weight"].view(-1),
+                     G["dense_decoder.proj.bias"])
+    # ---- decoder, fine -> coarse.  g = grad wrt block output (= grad wrt to_dec[i+1] too)
+    dproj: List[Optional[torch.Tensor]] = [None] * n_dec
+    for i in reversed(range(n_dec)):
+        t = tape.dec[i]
+        q = t["q"]
+        if i + 1 < n_dec:
+            dproj[i + 1] = g
+        dc2 = ops.norm_backward(g, None, t["c2"], t["st2"], W[f"{q}.conv.4.weight"], ACT_NONE, None, 0,
+                                G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"])
+        so = tuple(t["r"].shape[1:4])
+        dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1)
+        _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
+        dc1 = ops.norm_backward(dr, t["r"], t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
+                                G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"])
+        du = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1)
+        _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
+        si = tuple(t["xin"].shape[1:4])
+        g = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2)
+        _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
+        ops.chan_sum(du, None, 0, G[f"{q}.up_sample.bias"])
+    dproj[0] = g
+    if after_group:
+        after_group("decoder")
+    # ---- densify: grads wrt the encoder feature maps (active voxels only)
+    dfeat: List[Optional[torch.Tensor]] = [None] * spec.n_stage
+    for i in range(n_dec):
+        t = tape.dens[i]
+        dp = dproj[i]
+        if t["k"]:
+            pw = f"densify_projs.{i}.weight"
+            dd = ops.conv3d(CONV_DGRAD, dp, pk.get(W, pw, False, True), None, tuple(dp.shape[1:4]), t["k"], 1)
+            _wgrad_into(G, pw, CONV_FWD, t["d"], dp, t["k"], 1)
+            ops.chan_sum(dp, None, 0, G[f"densify_projs.{i}.bias"])
+        else:
+            dd = dp
+        dfeat[4 - i] = ops.norm_backward(dd, None, t["f"], t["st"], W[f"densify_norms.{i}.weight"], ACT_NONE, mask, i,
+                                         G[f"densify_norms.{i}.weight"], G[f"densify_norms.{i}.bias"],
+                                         dtoken=G[f"mask_tokens.{i}"].view(-1), fill=True)
+    if after_group:
+        after_group("densify")
+    # ---- encoder, deep -> shallow.  gstage[s] = gradient wrt the stage-s output map (active voxels only)
+    gstage: List[Optional[torch.Tensor]] = list(dfeat)
+    by_stage: Dict[int, List[dict]] = {}
+    for t in tape.enc:
+        by_stage.setdefault(t["s"], []).append(t)
+    for s in reversed(range(spec.n_stage)):
+        bs = 4 - s
+        gout = gstage[s]
+        assert gout is not None
+        for t in reversed(by_stage[s]):
+            p = t["p"]
+            y2, a1, y1, out, x = t["y2"], t["a1"], t["y1"], t["out"], t["x"]
+            dpre = torch.empty_like(y2)                      # gradient of the shortcut branch
+            dy2 = ops.norm_backward(gout, out, y2, t["st2"], W[f"{p}.norm2.weight"], ACT_LRELU, mask, bs,
+                                    G[f"{p}.norm2.weight"], G[f"{p}.norm2.bias"], dres=dpre)
+            sp = tuple(y2.shape[1:4])
+            da1 = ops.conv3d(CONV_DGRAD, dy2, pk.get(W, f"{p}.conv2.weight", False, True), None, sp, 3, 1,
+                             in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
+            _wgrad_into(G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
+            ops.chan_sum(dy2, mask, bs, G[f"{p}.conv2.bias"])
+            dy1 = ops.norm_backward(da1, a1, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
+                                    G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"])
+            ops.chan_sum(dy1, mask, bs, G[f"{p}.conv1.bias"])
+            stride = t["stride"]
+            if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only
+                ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None)
+                ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), G[f"{p}.conv3.bias"])
+                break
+            bsx = bs + (1 if stride == 2 else 0)
+            spx = tuple(x.shape[1:4])
+            _wgrad_into(G, f"{p}.conv1.weight", CONV_FWD, x, dy1, 3, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
+            if t["first"]:
+                # block input = output map of stage s-1: add onto its densify gradient if it has one
+                base = gstage[s - 1]
+                gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, stride,
+                                in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=base, accumulate=base is not None)
+                _wgrad_into(G, f"{p}.conv3.weight", CONV_FWD, x, dpre, 1, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
+                ops.chan_sum(dpre, mask, bs, G[f"{p}.conv3.bias"])
+                ops.conv3d(CONV_DGRAD, dpre, pk.get(W, f"{p}.conv3.weight", False, True), None, spx, 1, stride,
+                           in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=gx, accumulate=True)
+                gstage[s - 1] = gx
+            else:                                            # identity shortcut
+                gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, 1,
+                                in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
+                gout = ops.add(gx, dpre, out=gx)
+        if after_group:
+            after_group(f"stage{s}")

@@ -1,0 +1,131 @@
+"""The fused AnatoMask training step (the hot loop body, P/pretrain_AntoMask.py:418-441) on the HIP engine.
+
+teacher fwd (eval, no grad) -> per-patch raw l2 -> hard-mask sampler -> student fwd -> normalised masked MSE
+-> backward -> [RCCL gradient all-reduce, overlapped] -> clip(12) + AdamW + EMA in one pass.
+Everything stays on the device: no .item(), no numpy round trip, no host synchronisation inside a step
+(the reference has ~3 D2H syncs per step plus one per sample in generate_mask).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+from .modules import ModelEma, SparK, ema_decay_for_epoch
+
+
+class AnatoMaskTrainer:
+    def __init__(self, model: SparK, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
+                 clip: float = 12.0, ema_decay: float = 0.999, total_epochs: int = 1000, guide: bool = True, seed: int = 4321,
+                 process_group=None, distributed: Optional[bool] = None):
+        self.model = model
+        model._ensure_flat()
+        model.train()
+        self.teacher = ModelEma(model, decay=ema_decay)
+        self.teacher.ema._ensure_flat()
+        self.lr, self.wd, self.betas, self.eps, self.clip = lr, weight_decay, betas, eps, clip
+        self.total_epochs, self.guide = total_epochs, guide
+        dev = model._flat.device
+        n = model._live_end
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
+        self.gnorm = torch.zeros(1, device=dev)
+        self.step_count = 0
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(seed)
+        self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if self.distributed else 1
+        self._works = []
+        if self.distributed:                      # DDP start-up broadcast (P/pretrain_AnatoMask_DDP.py:239-240)
+            dist.broadcast(model._flat, 0, group=process_group)
+            self.teacher.ema._flat.copy_(model._flat)
+        o = model._offs
+        names = model._pnames
+        first_dec = next(k for k in names if k.startswith("dense_decoder."))
+        first_dens = next(k for k in names if k.startswith("densify_norms.") and k not in model._dead)
+        self._ranges: Dict[str, tuple] = {"decoder": (o[first_dec], o[first_dens]), "densify": (o[first_dens], n)}
+        for s in range(model.spec.n_stage):
+            ks = [k for k in names if k.startswith(f"{engine.ENC}.{s}.")]
+            nxt = o[f"{engine.ENC}.{s + 1}.0.conv1.weight"] if s + 1 < model.spec.n_stage else o[first_dec]
+            self._ranges[f"stage{s}"] = (o[ks[0]], nxt)
+
+    # ------------------------------------------------------------------ gradient exchange (a18)
+    def _after_group(self, tag: str):
+        """Gradient bucket `tag` is final: start its all-reduce now so it overlaps the rest of backward.
+        RCCL runs it on its own stream behind an event on the compute stream."""
+        if not self.distributed:
+            return
+        a, b = self._ranges[tag]
+        if b > a:
+            self._works.append(dist.all_reduce(self.model._gflat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def _finish_exchange(self):
+        if not self.distributed:
+            return
+        for w in self._works:
+            w.wait()
+        self._works.clear()
+        self.model._gflat[:self.model._live_end].mul_(1.0 / self.world)
+
+    # ------------------------------------------------------------------ one step
+    @torch.no_grad()
+    def step(self, inp_bchwd: torch.Tensor, epoch: int = 0, mask1: Optional[torch.Tensor] = None,
+             keys: Optional[torch.Tensor] = None, lr: Optional[float] = None, ema_decay: Optional[float] = None):
+        """inp_bchwd: (B,1,H,W,D) fp32 on the device.  mask1/keys teacher-force the two random draws.
+        Returns device tensors only: {'loss','grad_norm','mask','recon_loss','rec_loss'}."""
+        m, t = self.model, self.teacher.ema
+        spec = m.spec
+        x = inp_bchwd[:, 0].float().contiguous()
+        B = x.shape[0]
+        L = spec.fmap[0] * spec.fmap[1] * spec.fmap[2]
+        dev = x.device
+        # 1. first mask (SparK.mask :419)
+        if mask1 is None:
+            k1 = torch.rand(B, L, device=dev, generator=self.gen)
+            m1 = ops.mask_sampler(torch.zeros(B, L, device=dev), k1, m.len_keep, 0)
+        else:
+            m1 = mask1.reshape(B, L).to(device=dev, dtype=torch.uint8).contiguous()
+        mi1 = ops.MaskInfo(m1.view(B, *spec.fmap))
+        # 2. teacher pass + raw per-patch loss (:421-425)
+        rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False)
+        recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
+        del rec1
+        # 3. hard-mask sampler (:427)
+        ll = m.len_loss_for(L, m.len_keep, epoch, self.total_epochs - 1, self.guide)
+        if keys is None:
+            keys = torch.rand(B, L, device=dev, generator=self.gen)
+        mk = ops.mask_sampler(recon, keys.to(dev).float().contiguous(), m.len_keep, ll)
+        mi = ops.MaskInfo(mk.view(B, *spec.fmap))
+        # 4. student forward + loss (:429-430)
+        tape = engine.Tape()
+        rec = engine.forward(spec, m._W, m._pack, x, mi, train=True, tape=tape)
+        l2m, pm, pr, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
+        drec = ops.patch_loss_bwd(x, rec, mi, pm, pr, info, None)
+        # 5. backward (:435) with overlapped gradient exchange
+        m._gflat.zero_()
+        engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group)
+        del tape
+        self._finish_exchange()
+        # 6. clip + AdamW + EMA (:437-440), one pass over the live parameters
+        self.step_count += 1
+        n = m._live_end
+        decay = self.teacher.decay if ema_decay is None else ema_decay
+        ops.sumsq(m._gflat[:n], self.sumsq)
+        ops.adamw_ema(m._flat, m._gflat, self.m, self.v, t._flat, n, self.lr if lr is None else lr, self.betas, self.eps, self.wd,
+                      self.step_count, self.sumsq, self.clip, decay, self.gnorm)
+        if m._flat.numel() > n:                                   # dead densify[4] tensors: EMA only (no optimizer step)
+            ops.ema(t._flat[n:], m._flat[n:], decay)
+        ops.ema(t._bflat, m._bflat, decay)                        # BN running stats are EMA'd too (timm: every state_dict entry)
+        for (_, e), (_, s_) in zip(t.named_buffers(), m.named_buffers()):
+            if not e.is_floating_point():
+                e.copy_(e * decay + (1. - decay) * s_)
+        m.weights_changed(); t.weights_changed()
+        return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": recon, "rec_loss": l2m}
+
+    def set_epoch(self, i: int):
+        """per-epoch EMA decay ramp (P/pretrain_AntoMask.py:383-386)."""
+        self.teacher.decay = ema_decay_for_epoch(i, self.total_epochs)

@@ -1,0 +1,244 @@
+"""GPU: the whole HIP path (engine + module API + fused trainer) against the reference-generated fixtures
+(tests/golden/*.npz) and the CPU oracle.  Tolerances:
+  fp32 forward quantities (stage maps, rec, per-patch l2, loss): <= 2e-4 relative (fixture-vs-HIP), fp32 floor ~2e-5
+  fp32 gradients end-to-end: <= 5e-2 per tensor (LeakyReLU/ReLU6 gate flips; the reference itself sits 4e-4..2e-2 from fp64)
+  N-step weights: same metrics/bounds as tests/test_oracle_golden.py (Adam amplifies the gate-flip noise)
+  bf16 storage: loss within 2e-2 relative, rec within 5e-2 of its max, N-step loss trajectory within 2e-2
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import anatomask_oracle as O
+from tests.helpers import assert_checks, load, np_volume, rel_err, sample, tiny_cfg
+from tests.test_oracle_golden import GRAD_RTOL, _zero_grad_bias, delta_metrics, mismatch_fraction
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def fwd():
+    return load("forward_tiny.npz")
+
+
+def make_model(cfg, W, dtype=torch.float32):
+    from anatomask_amd import modules as M
+    m = M.build_spark(cfg.dims, cfg.depth, cfg.width, cfg.input_size, cfg.mask_ratio, compute_dtype=dtype)
+    m.load_state_dict({k: v.clone() for k, v in W.items()})
+    return m.to(DEV)
+
+
+def feats_ncdhw(f, mask, cfg):
+    out = []
+    for s, t in enumerate(f):
+        v = t.float().cpu().permute(0, 4, 1, 2, 3)
+        out.append(torch.where(O.upsample_mask(mask, v.shape[2:]), v, torch.zeros(())))
+    return out
+
+
+def test_forward_matches_reference_fixture(fwd):
+    from anatomask_amd import engine, ops
+    cfg = tiny_cfg(fwd)
+    W = O.closed_form_state(cfg)
+    x = np_volume(int(fwd["B"]), cfg.input_size, fwd["x_seed"])
+    mask = torch.from_numpy(fwd["fwd_mask"])
+    m = make_model(cfg, W).train()
+    m._ensure_flat()
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    with torch.no_grad():
+        rec, feats = engine.forward(m.spec, m._W, m._pack, x[:, 0].contiguous().to(DEV), mi, True, None, want_feats=True)
+    for i, f in enumerate(feats_ncdhw(feats, mask, cfg)):
+        assert_checks(f, fwd[f"enc{i}_checks"], 2e-4, f"enc{i}")
+        assert rel_err(sample(f), fwd[f"enc{i}_sample"]) < 2e-4
+    rp = O.patchify(cfg, rec.cpu().unsqueeze(1))
+    assert_checks(rp, fwd["fwd_rec_checks"], 2e-4, "rec")
+    assert rel_err(sample(rp, 256), fwd["fwd_rec_sample"]) < 2e-4
+    # BN running stats after one train forward
+    sd = m.state_dict()
+    for k in fwd:
+        if k.startswith("bn1::"):
+            np.testing.assert_allclose(sd[k[5:]].cpu().numpy(), fwd[k], rtol=1e-4, atol=1e-6)
+    # eval-mode (teacher) forward on fresh weights
+    m2 = make_model(cfg, W).eval()
+    with torch.no_grad():
+        ip, rp2 = m2(x.to(DEV), active_b1ff=mask.to(DEV))
+    assert_checks(rp2.cpu(), fwd["eval_rec_checks"], 2e-4, "eval rec")
+    tl2 = (((rp2 - ip) ** 2).mean(dim=2) * mask.to(DEV).logical_not().int().view(ip.shape[0], -1)).cpu().numpy()
+    assert rel_err(tl2, fwd["eval_teacher_l2"]) < 2e-4
+
+
+def test_module_api_loss_and_grads(fwd):
+    """Reference calling convention: inp,rec = model(x, active_b1ff=mask); loss,_ = model.forward_loss(...); loss.backward()."""
+    cfg = tiny_cfg(fwd)
+    W = O.closed_form_state(cfg)
+    x = np_volume(int(fwd["B"]), cfg.input_size, fwd["x_seed"]).to(DEV)
+    mask = torch.from_numpy(fwd["fwd_mask"]).to(DEV)
+    m = make_model(cfg, W).train()
+    inp, rec = m(x, active_b1ff=mask)
+    assert inp.shape == rec.shape == (x.shape[0], cfg.L, 4096)
+    loss, rec_loss = m.forward_loss(inp, rec, mask)
+    assert abs(loss.item() - float(fwd["fwd_loss"])) < 2e-4 * abs(float(fwd["fwd_loss"]))
+    assert rel_err(rec_loss.detach().cpu().numpy(), fwd["fwd_l2"]) < 2e-4
+    loss.backward()
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    for k, gn in zip(fwd["grad_keys"], fwd["grad_norms"]):
+        g = grads[str(k)]
+        if gn < 0:
+            assert g is None, k                       # dead densify[4] tensors
+            continue
+        if gn < 1e-6:
+            assert float(g.norm()) < 1e-4, k          # analytically zero (conv bias under a norm)
+            continue
+        assert abs(float(g.norm()) - gn) < GRAD_RTOL * gn, (k, float(g.norm()), gn)
+    for k in fwd:
+        if k.startswith("grad::"):
+            scale = np.abs(fwd[k]).max()
+            if scale > 1e-6:
+                assert np.abs(grads[k[6:]].cpu().numpy() - fwd[k]).max() < GRAD_RTOL * scale, k
+        if k.startswith("gradsample::"):
+            assert rel_err(sample(grads[k[12:]], 128), fwd[k]) < GRAD_RTOL, k
+
+
+def test_gradients_vs_oracle_same_box(fwd):
+    """Same check against the CPU oracle evaluated here (cosine + norm per tensor)."""
+    cfg = tiny_cfg(fwd)
+    W = O.closed_form_state(cfg)
+    x = np_volume(2, cfg.input_size, 77)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(5))
+    loss_o, _, g_o, _ = O.student_loss_and_grads(cfg, W, x, mask)
+    m = make_model(cfg, W).train()
+    inp, rec = m(x.to(DEV), active_b1ff=mask.to(DEV))
+    loss, _ = m.forward_loss(inp, rec, mask.to(DEV))
+    loss.backward()
+    assert abs(loss.item() - float(loss_o)) < 2e-4 * abs(float(loss_o))
+    for k, p in m.named_parameters():
+        if g_o[k] is None or float(g_o[k].norm()) < 1e-6:
+            continue
+        a, b = p.grad.cpu().double().flatten(), g_o[k].double().flatten()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > (0.995 if a.numel() >= 256 else 0.97) and abs(float(a.norm() / b.norm()) - 1) < GRAD_RTOL, (k, cos, float(a.norm()), float(b.norm()))
+
+
+def _run_trainer(dtype, r, f, teacher_force_student_mask=False):
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    cfg = tiny_cfg(f)
+    W0 = O.closed_form_state(cfg)
+    m = make_model(cfg, W0, dtype)
+    ep, tot = (int(v) for v in r["epoch"])
+    tr = AnatoMaskTrainer(m, lr=float(r["lr"]), ema_decay=float(r["ema_decay"]), total_epochs=tot + 1, distributed=False)
+    out, snap = [], None
+    for s in range(int(r["N"])):
+        x = np_volume(int(f["B"]), cfg.input_size, r["x_seeds"][s]).to(DEV)
+        keys = torch.from_numpy(r["keys"][s])
+        if teacher_force_student_mask:               # keys = 0 for the reference's visible set, ties by id
+            keys = torch.from_numpy(1.0 - r["mask"][s].reshape(keys.shape).astype(np.float32))
+        o = tr.step(x, epoch=ep, mask1=torch.from_numpy(r["mask1"][s]), keys=keys)
+        out.append({k: v.clone().cpu() for k, v in o.items()})
+        if s == 0:
+            snap = ({k: v.detach().cpu().clone() for k, v in m.state_dict().items()},
+                    {k: v.detach().cpu().clone() for k, v in tr.teacher.ema.state_dict().items()})
+    return cfg, W0, m, tr, out, snap
+
+
+def test_trainer_n_steps_fp32_matches_reference():
+    r, f = load("train_tiny.npz"), load("forward_tiny.npz")
+    cfg, W0, m, tr, out, snap = _run_trainer(torch.float32, r, f)
+    names = [str(n) for n in r["names"]]
+    for s, o in enumerate(out):
+        assert np.array_equal(o["mask"].numpy().astype(bool).reshape(r["mask"][s].shape), r["mask"][s]), f"sampler mask diverged at step {s}"
+        assert abs(o["loss"].item() - r["losses"][s]) < 3e-4 * abs(r["losses"][s]), (s, o["loss"].item(), r["losses"][s])
+        assert abs(o["grad_norm"].item() - r["grad_norms"][s]) < 5e-2 * r["grad_norms"][s], (s, o["grad_norm"].item())
+        assert rel_err(o["recon_loss"].numpy(), r["recon"][s]) < 1e-3
+    errs, mfs, mfe = [], [], []
+    for k in names:                                                   # strict after ONE step
+        if "step1delta::" + k not in r or _zero_grad_bias(k) or np.linalg.norm(r["step1delta::" + k]) < 1e-9:
+            continue
+        e, c = delta_metrics(snap[0][k] - W0[k], r["step1delta::" + k])
+        errs.append(e)
+        n_el = min(1024, W0[k].numel())
+        mfs.append((mismatch_fraction(snap[0][k] - W0[k], r["step1delta::" + k]) * n_el, n_el))
+        mfe.append((mismatch_fraction(snap[1][k] - W0[k], r["step1ema::" + k]) * n_el, n_el))
+        assert c > 0.7, ("step1", k, e, c)
+    assert np.median(errs) < 5e-3, np.median(errs)
+    for mm in (mfs, mfe):
+        assert sum(a for a, _ in mm) / sum(b for _, b in mm) <= 0.01
+    fsd = {k: v.cpu() for k, v in m.state_dict().items()}
+    esd = {k: v.cpu() for k, v in tr.teacher.ema.state_dict().items()}
+    errs, werrs = [], []
+    for k in names:
+        if "final::" + k in r:
+            assert np.array_equal(fsd[k].numpy(), r["final::" + k]), k
+            assert np.array_equal(esd[k].numpy(), r["ema::" + k]), k
+            continue
+        if _zero_grad_bias(k) or np.linalg.norm(r["finaldelta::" + k]) < 1e-9:
+            continue
+        e, c = delta_metrics(fsd[k] - W0[k], r["finaldelta::" + k])
+        e2, c2 = delta_metrics(esd[k] - W0[k], r["emadelta::" + k])
+        errs.append(e)
+        werrs.append(float((fsd[k] - W0[k]).norm()) * e / (float(W0[k].norm()) + 1e-30))
+        if W0[k].numel() >= 64:
+            assert e < 0.6 and c > 0.8, ("final", k, e, c)
+            assert e2 < 0.6 and c2 > 0.8, ("ema", k, e2, c2)
+    print("HIP fp32 vs reference, update L2 error after N steps: median %.3f max %.3f; weight-level median %.2e max %.2e"
+          % (np.median(errs), max(errs), np.median(werrs), max(werrs)))
+    assert np.median(errs) < 0.15 and np.median(werrs) < 2e-2 and max(werrs) < 0.2
+
+
+def test_trainer_n_steps_bf16_tracks_reference():
+    r, f = load("train_tiny.npz"), load("forward_tiny.npz")
+    cfg, W0, m, tr, out, _ = _run_trainer(torch.bfloat16, r, f, teacher_force_student_mask=True)
+    for s, o in enumerate(out):
+        assert np.array_equal(o["mask"].numpy().astype(bool).reshape(r["mask"][s].shape), r["mask"][s])
+        assert abs(o["loss"].item() - r["losses"][s]) < 2e-2 * abs(r["losses"][s]), (s, o["loss"].item(), r["losses"][s])
+        assert abs(o["grad_norm"].item() - r["grad_norms"][s]) < 0.25 * r["grad_norms"][s], (s, o["grad_norm"].item(), r["grad_norms"][s])
+    assert all(torch.isfinite(v).all() for v in m.state_dict().values())
+
+
+def test_reference_style_driver_loop(fwd):
+    """The unfused drop-in route: torch.optim.AdamW + clip_grad_norm_ + ModelEma.update on our modules,
+    exactly as P/pretrain_AntoMask.py:418-441 drives them; one step compared with the fused trainer."""
+    from anatomask_amd import modules as M
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    r = load("train_tiny.npz")
+    cfg = tiny_cfg(fwd)
+    W0 = O.closed_form_state(cfg)
+    ep, tot = (int(v) for v in r["epoch"])
+    x = np_volume(int(fwd["B"]), cfg.input_size, r["x_seeds"][0]).to(DEV)
+    mask1 = torch.from_numpy(r["mask1"][0]).to(DEV)
+    model_without_ddp = make_model(cfg, W0)
+    model_ema = M.ModelEma(model_without_ddp, decay=float(r["ema_decay"]), device=DEV, resume="")
+    model = M.LocalDDP(model_without_ddp)
+    optimizer = torch.optim.AdamW(M.get_param_groups(model_without_ddp, nowd_keys={"cls_token", "pos_embed", "mask_token", "gamma"}),
+                                  lr=float(r["lr"]), weight_decay=1e-5, betas=(0.9, 0.999))
+    model.train()
+    with torch.no_grad():
+        inp1, rec1 = model_ema.ema(x, active_b1ff=mask1)
+        l2_loss = ((rec1 - inp1) ** 2).mean(dim=2, keepdim=False)
+        recon_loss = l2_loss * mask1.logical_not().int().view(mask1.shape[0], -1)
+    mask, _ = model_ema.ema.generate_mask(recon_loss, guide=True, epoch=ep, total_epoch=tot, keys=torch.from_numpy(r["keys"][0]).to(DEV))
+    assert np.array_equal(mask.cpu().numpy(), r["mask"][0])
+    inpp, recc = model(x, active_b1ff=mask, vis=False)
+    loss, _ = model.module.forward_loss(inpp, recc, mask)
+    optimizer.zero_grad()
+    loss.backward()
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 12).item()
+    optimizer.step()
+    model_without_ddp.weights_changed()
+    model_ema.update(model)
+    assert abs(loss.item() - r["losses"][0]) < 3e-4 * abs(r["losses"][0])
+    assert abs(gn - r["grad_norms"][0]) < 5e-2 * r["grad_norms"][0]
+    # the fused trainer takes the same step
+    m2 = make_model(cfg, W0)
+    tr = AnatoMaskTrainer(m2, lr=float(r["lr"]), ema_decay=float(r["ema_decay"]), total_epochs=tot + 1, distributed=False)
+    tr.step(x, epoch=ep, mask1=mask1, keys=torch.from_numpy(r["keys"][0]))
+    flips = tot_el = 0
+    for (k, a), (_, b) in zip(model_without_ddp.state_dict().items(), m2.state_dict().items()):
+        if a.is_floating_point() and not _zero_grad_bias(k) and k not in model_without_ddp._dead:
+            d = (a - b).abs().flatten()
+            flips += int((d > 1e-4).sum()); tot_el += d.numel()       # |update| = lr = 1e-3: count sign flips
+    assert flips / tot_el < 5e-3, flips / tot_el
+    # checkpoint keys as the reference writes them (P/pretrain_AntoMask.py:472-479)
+    keys = list(model.state_dict().keys())
+    assert all(k.startswith("module.") for k in keys) and len(keys) == 131
+    assert "module.sparse_encoder.sp_cnn.conv_blocks_context.0.0.conv1.weight" in keys
