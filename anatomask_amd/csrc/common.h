@@ -95,3 +95,6 @@ struct MaskView {
 };
 
 #define AM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+// launch with a clean error slate: hipGetLastError() is per-thread sticky and torch's own probing calls
+// can leave a benign error behind that would otherwise be mis-attributed to our launch
+#define AM_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

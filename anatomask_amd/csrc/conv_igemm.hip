@@ -238,7 +238,7 @@ int launch(Plan& P, hipStream_t st) {
     (void)hipGetLastError();
   }
   dim3 grid(a.B * a.nbd * a.nbh * a.nbw, (a.Cout + 16 * NS - 1) / (16 * NS), a.nclass);
-  hipLaunchKernelGGL(kern, grid, dim3(256), P.lds, st, a);
+  AM_LAUNCH(kern, grid, dim3(256), P.lds, st, a);
   AM_CHECK_LAUNCH();
   return 0;
 }

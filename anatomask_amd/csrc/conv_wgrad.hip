@@ -190,7 +190,7 @@ int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
     (void)hipGetLastError();
   }
   dim3 grid(split, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), a.ngroup);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  AM_LAUNCH(kern, grid, dim3(256), lds, st, a);
   AM_CHECK_LAUNCH();
   return 0;
 }

@@ -198,9 +198,9 @@ int am_patch_loss_fwd(const float* inp, const float* rec, const uint8_t* active,
   if (D % 16 || H % 16 || W % 16) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int fd = D / 16, fh = H / 16, fw = W / 16;
-  hipLaunchKernelGGL(patch_loss_fwd_kernel, dim3(B * fd * fh * fw), dim3(256), 0, st, inp, rec, active, D, H, W, fd, fh, fw,
+  AM_LAUNCH(patch_loss_fwd_kernel, dim3(B * fd * fh * fw), dim3(256), 0, st, inp, rec, active, D, H, W, fd, fh, fw,
                      normalized, l2m, pmean, prstd);
-  if (lossinfo) hipLaunchKernelGGL(patch_loss_reduce_kernel, dim3(1), dim3(256), 0, st, l2m, active, B * fd * fh * fw, lossinfo);
+  if (lossinfo) AM_LAUNCH(patch_loss_reduce_kernel, dim3(1), dim3(256), 0, st, l2m, active, B * fd * fh * fw, lossinfo);
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -209,7 +209,7 @@ int am_patch_loss_bwd(const float* inp, const float* rec, const uint8_t* active,
                       const float* prstd, const float* lossinfo, const float* gout, float* drec, void* stream) {
   if (D % 16 || H % 16 || W % 16) return -1;
   const int fd = D / 16, fh = H / 16, fw = W / 16;
-  hipLaunchKernelGGL(patch_loss_bwd_kernel, dim3(B * fd * fh * fw), dim3(256), 0, (hipStream_t)stream, inp, rec, active, D, H, W,
+  AM_LAUNCH(patch_loss_bwd_kernel, dim3(B * fd * fh * fw), dim3(256), 0, (hipStream_t)stream, inp, rec, active, D, H, W,
                      fd, fh, fw, pmean, prstd, lossinfo, gout, drec);
   AM_CHECK_LAUNCH();
   return 0;
@@ -218,7 +218,7 @@ int am_patch_loss_bwd(const float* inp, const float* rec, const uint8_t* active,
 int am_mask_sampler(const float* loss, const float* keys, int B, int L, int len_keep, int len_loss, uint8_t* mask, void* stream) {
   if (L > 4096 || len_keep > L || len_loss < 0 || len_loss + len_keep > L) return -1;
   int NP = 1; while (NP < L) NP <<= 1;
-  hipLaunchKernelGGL(mask_sampler_kernel, dim3(B), dim3(256), NP * 9, (hipStream_t)stream, loss, keys, L, NP, len_keep, len_loss, mask);
+  AM_LAUNCH(mask_sampler_kernel, dim3(B), dim3(256), NP * 9, (hipStream_t)stream, loss, keys, L, NP, len_keep, len_loss, mask);
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -227,7 +227,7 @@ int am_sumsq(const float* g, long n, double* out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(out, 0, sizeof(double), st);
   int nb = (int)((n / 4 + 255) / 256); if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, g, n, out);
+  AM_LAUNCH(sumsq_kernel, dim3(nb), dim3(256), 0, st, g, n, out);
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -237,7 +237,7 @@ int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long 
   if (n % 4) return -1;
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);   // as torch: python doubles
   int nb = (int)((n / 4 + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, (float)lr, (float)beta1, (float)beta2,
+  AM_LAUNCH(adamw_ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, (float)lr, (float)beta1, (float)beta2,
                      (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2), sumsq, (float)max_norm, (float)ema_decay, gnorm_out);
   AM_CHECK_LAUNCH();
   return 0;
@@ -245,7 +245,7 @@ int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long 
 
 int am_ema(float* ema, const float* p, long n, double decay, void* stream) {
   int nb = (int)((n + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ema, p, n, (float)decay);
+  AM_LAUNCH(ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ema, p, n, (float)decay);
   AM_CHECK_LAUNCH();
   return 0;
 }

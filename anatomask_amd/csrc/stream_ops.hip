@@ -525,14 +525,14 @@ int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, c
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
   const int nb = nblk((long)B * D * H * W);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(chan_stats_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, sums),
-             hipLaunchKernelGGL(chan_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, sums));
+  DISPATCH_T(dtype, AM_LAUNCH(chan_stats_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, sums),
+             AM_LAUNCH(chan_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, sums));
   AM_CHECK_LAUNCH();
   return 0;
 }
 
 int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out, void* stream) {
-  hipLaunchKernelGGL(mask_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, n, voxels_per_patch, out);
+  AM_LAUNCH(mask_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, n, voxels_per_patch, out);
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -540,7 +540,7 @@ int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out,
 int am_norm_finalize(const double* sums, const double* count_ptr, double count_host, int C, const float* gamma,
                      const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift, float* run_mean,
                      float* run_var, float momentum, void* stream) {
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count_ptr, count_host,
+  AM_LAUNCH(norm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count_ptr, count_host,
                      C, gamma, beta, eps, mean, rstd, scale, shift, run_mean, run_var, momentum);
   AM_CHECK_LAUNCH();
   return 0;
@@ -548,7 +548,7 @@ int am_norm_finalize(const double* sums, const double* count_ptr, double count_h
 
 int am_norm_fold_running(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
                          float* scale, float* shift, void* stream) {
-  hipLaunchKernelGGL(norm_fold_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, run_mean,
+  AM_LAUNCH(norm_fold_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, gamma, beta, run_mean,
                      run_var, eps, scale, shift);
   AM_CHECK_LAUNCH();
   return 0;
@@ -562,9 +562,9 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
   hipStream_t st = (hipStream_t)stream;
   const int nb = nblk((long)B * D * H * W);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(norm_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,
+             AM_LAUNCH(norm_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,
                                 (const float*)res, stem_x, stem_w, stem_b, fill, (float*)y),
-             hipLaunchKernelGGL(norm_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, scale, shift, act,
+             AM_LAUNCH(norm_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, scale, shift, act,
                                 (const bf16_t*)res, stem_x, stem_w, stem_b, fill, (bf16_t*)y));
   AM_CHECK_LAUNCH();
   return 0;
@@ -579,9 +579,9 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
   hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C, st);
   const int nb = nblk((long)B * D * H * W);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
+             AM_LAUNCH(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
                                 (const float*)x, g, mean, rstd, act, fill, bsum),
-             hipLaunchKernelGGL(norm_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,
+             AM_LAUNCH(norm_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,
                                 (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum));
   AM_CHECK_LAUNCH();
   return 0;
@@ -590,7 +590,7 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
 int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
                          const float* rstd, float* k0, float* k1, float* k2, float* dgamma, float* dbeta, float* dtoken,
                          void* stream) {
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bsum, count_ptr,
+  AM_LAUNCH(norm_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bsum, count_ptr,
                      count_host, C, gamma, rstd, k0, k1, k2, dgamma, dbeta, dtoken);
   AM_CHECK_LAUNCH();
   return 0;
@@ -604,9 +604,9 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
   hipStream_t st = (hipStream_t)stream;
   const int nb = nblk((long)B * D * H * W);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
+             AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
                                 (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres),
-             hipLaunchKernelGGL(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
+             AM_LAUNCH(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
                                 (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres));
   AM_CHECK_LAUNCH();
   return 0;
@@ -618,8 +618,8 @@ int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, con
   Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
   hipStream_t st = (hipStream_t)stream;
   const int nb = nblk((long)B * D * H * W);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(chan_sum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, out_accum),
-             hipLaunchKernelGGL(chan_sum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, out_accum));
+  DISPATCH_T(dtype, AM_LAUNCH(chan_sum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, out_accum),
+             AM_LAUNCH(chan_sum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, out_accum));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -628,8 +628,8 @@ int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void*
   hipStream_t st = (hipStream_t)stream;
   const size_t nchunk = (size_t)n_elems / (dtype == AM_DT_BF16 ? 8 : 4);
   int nb = (int)((nchunk + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(add_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, nchunk),
-             hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, nchunk));
+  DISPATCH_T(dtype, AM_LAUNCH(add_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)y, nchunk),
+             AM_LAUNCH(add_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, nchunk));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -642,8 +642,8 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
   hipStream_t st = (hipStream_t)stream;
   const int nb = nblk((long)B * D * H * W);
   const size_t sm = sizeof(float) * C * ksize * ksize * ksize;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(stem_conv_fwd_kernel<float>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (float*)y),
-             hipLaunchKernelGGL(stem_conv_fwd_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (bf16_t*)y));
+  DISPATCH_T(dtype, AM_LAUNCH(stem_conv_fwd_kernel<float>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (float*)y),
+             AM_LAUNCH(stem_conv_fwd_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (bf16_t*)y));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -657,8 +657,8 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
   const int nb = nblk((long)B * D * H * W);
   const size_t sm = sizeof(float) * C * (ksize * ksize * ksize + 1);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(stem_conv_wgrad_kernel<float>, dim3(nb), dim3(256), sm, st, x, (const float*)dy, g, ksize, dw_accum, db_accum),
-             hipLaunchKernelGGL(stem_conv_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, (const bf16_t*)dy, g, ksize, dw_accum, db_accum));
+             AM_LAUNCH(stem_conv_wgrad_kernel<float>, dim3(nb), dim3(256), sm, st, x, (const float*)dy, g, ksize, dw_accum, db_accum),
+             AM_LAUNCH(stem_conv_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, (const bf16_t*)dy, g, ksize, dw_accum, db_accum));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -667,8 +667,8 @@ int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, cons
   CHK_C(C);
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)((nvox + 255) / 256);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(proj_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, nvox, C, w, b, rec),
-             hipLaunchKernelGGL(proj_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, nvox, C, w, b, rec));
+  DISPATCH_T(dtype, AM_LAUNCH(proj_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, nvox, C, w, b, rec),
+             AM_LAUNCH(proj_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, nvox, C, w, b, rec));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -678,8 +678,8 @@ int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, c
   CHK_C(C);
   hipStream_t st = (hipStream_t)stream;
   const int nb = nblk(nvox);
-  DISPATCH_T(dtype, hipLaunchKernelGGL(proj_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, drec, nvox, C, w, (float*)dx, dw_accum, db_accum),
-             hipLaunchKernelGGL(proj_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, w, (bf16_t*)dx, dw_accum, db_accum));
+  DISPATCH_T(dtype, AM_LAUNCH(proj_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, drec, nvox, C, w, (float*)dx, dw_accum, db_accum),
+             AM_LAUNCH(proj_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, w, (bf16_t*)dx, dw_accum, db_accum));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -688,8 +688,8 @@ int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int tap
   hipStream_t st = (hipStream_t)stream;
   const long n = (long)taps * R * K;
   int nb = (int)((n + 255) / 256); if (nb > 8192) nb = 8192;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, src, (float*)dst, R, K, taps, stride_r, stride_k),
-             hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k));
+  DISPATCH_T(dtype, AM_LAUNCH(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, src, (float*)dst, R, K, taps, stride_r, stride_k),
+             AM_LAUNCH(pack_weight_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -698,7 +698,7 @@ int am_unpack_grad(const float* src_packed, float* dst, int R, int K, int taps, 
                    void* stream) {
   const long n = (long)taps * R * K;
   int nb = (int)((n + 255) / 256); if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(unpack_grad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src_packed, dst, R, K, taps, stride_r, stride_k, accumulate);
+  AM_LAUNCH(unpack_grad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src_packed, dst, R, K, taps, stride_r, stride_k, accumulate);
   AM_CHECK_LAUNCH();
   return 0;
 }

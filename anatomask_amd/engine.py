@@ -116,7 +116,7 @@ class PackCache:
 
 # ====================================================================================== forward
 def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
-            tape: Optional[Tape] = None, want_feats: bool = False):
+            tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False):
     """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps)."""
     dt = pk.dtype
     B = inp.shape[0]
@@ -158,6 +158,8 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
                 tape.enc.append(rec_)
             x = out
         feats.append(x)
+    if encoder_only:
+        return feats
     # ------------------------------------------------------------------ densify (level 4 is dead: P/decoder3D.py:57-60)
     n_dec = len(spec.dec_chs) - 1
     to_dec = []
