@@ -11,43 +11,58 @@
 //     y[o][co] = sum_t sum_ci  x[q*IS + shift_t][ci] * W[widx_t][co][ci]
 // so all taps of a class are wave-uniform.  A workgroup (4 waves) owns a BDxBHxBW brick of q and
 // NT = 16*NS output channels.  Per 64-byte channel slab (32 bf16 / 16 f32 channels) the haloed
-// source brick is staged ONCE into LDS (coalesced 16-byte loads, zero for out-of-range voxels and
-// for voxels of inactive 16^3-patches), then every tap reads its shifted window from LDS
+// source brick is staged ONCE into LDS (branch-free coalesced 16-byte loads; out-of-range voxels and
+// voxels of inactive 16^3-patches become zeros), then every tap reads its shifted window from LDS
 // (the 3x3x3 stencil reuse) and contracts channels on the matrix cores:
-//     D(16 cout x 16 voxel) += A(weights, 16-byte row fragments straight from L1/L2) * B(LDS fragments).
+//     D(16 cout x 16 voxel) += A(weight fragments) * B(voxel fragments), both ds_read_b128 from XOR-swizzled,
+//     bank-conflict-free LDS images.  Weights reach LDS in groups of 3 taps, double-buffered: the next group's
+//     global loads are in flight while the current group's MFMAs issue, and the 4 waves share one copy
+//     (per-wave weight loads from L1/L2 would need 128 B/clk/CU -- twice what the vector memory path delivers).
+// Packed weights are zero-padded to whole tiles, so the inner loop has no bounds logic at all.
 // Accumulators stay in registers across all slabs and taps; the epilogue adds the bias, applies the
-// output patch mask and writes 4 consecutive channels per lane.
+// output patch mask, writes 4 consecutive channels per lane and (optionally) leaves per-workgroup
+// per-channel partial sums (sum, sum of squares) for the norm that follows -- no extra pass over y.
 #include "common.h"
 #include "../../include/anatomask_hip.h"
 
 namespace {
 
 struct ConvArgs {
-  const void* x; const void* w; const float* bias; void* y;
-  int B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout;
+  const void* x; const void* w; const float* bias; void* y; float* partials;
+  int B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, Cinp, Coutp;
   int OS, IS, nclass;
   int nbd, nbh, nbw;          // bricks per dim of the q grid
-  int Qd, Qh, Qw;             // q grid extent per class
   int tap_begin[9];
   int taps[64];               // (sd+8) | (sh+8)<<4 | (sw+8)<<8 | widx<<12
   int mind[8], minh[8], minw[8];
   int ed[8], eh[8], ew[8];    // LDS source-brick extents per class
+  int w_lds_off, tap_lds_off; // byte offsets of the weight-group buffers / tap table inside dynamic LDS
   MaskView in_mask, out_mask;
   int accumulate;
 };
 
-constexpr int ROWB = 64;      // channel-slab bytes staged per voxel
-constexpr int LROW = 80;      // LDS row stride (16 B pad: spreads 16-lane b128 reads over banks)
-constexpr int MAXIT = 16;
+constexpr int ROWB = 64;      // channel-slab bytes staged per voxel / per weight row (unpadded, XOR-swizzled)
+constexpr int TG = 3;         // taps per weight group staged in LDS
 
-template <typename T, int BD, int BH, int BW, int NS>
+// LDS image of a [rows][64 B] tile: 16-byte chunk c of row r lives at r*64 + ((c ^ 2*bit2(r)) * 16).
+// With this swizzle a ds_read_b128 of 16 consecutive rows (any alignment) x 4 chunks is bank-conflict free
+// (brute-forced over the four 16-lane groups of the instruction, MI355X_MICROARCH.md "LDS").
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 6) + ((chunk ^ ((row >> 1) & 2)) << 4); }
+
+template <typename T, int BD, int BH, int BW, int NS, int NIT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
   constexpr int MV = BD * BH * BW;
   constexpr int VS = MV / 64;                           // 16-voxel subtiles per wave
+  constexpr int NT = 16 * NS;                           // output channels per workgroup
+  constexpr int WBUF = TG * NT * ROWB;                  // bytes of one weight-group buffer
+  constexpr int WCH = TG * NT * 4;                      // 16-byte chunks per weight group
+  constexpr int WIT = (WCH + 255) / 256;
   static_assert(MV % 64 == 0, "brick must give each wave whole 16-voxel subtiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* ldsW = lds + a.w_lds_off;
+  int* ldsTap = (int*)(lds + a.tap_lds_off);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
@@ -58,7 +73,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int bd_ = bid % a.nbd; const int b = bid / a.nbd;
   const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-  const int co0 = blockIdx.y * (16 * NS);
+  const int co0 = blockIdx.y * NT;
+  float* part = a.partials ? a.partials + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * a.Cout) * 2 : nullptr;
 
   // ---- skip bricks with no active output voxel (block-sparse outputs) ----
   if (a.out_mask.m) {
@@ -67,37 +83,62 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
       if (od < a.Do && oh < a.Ho && ow < a.Wo && a.out_mask.active(b, od, oh, ow)) any = 1;
     }
-    if (!__syncthreads_or(any)) return;
+    if (!__syncthreads_or(any)) {
+      if (part && tid < NT && co0 + tid < a.Cout) { part[(co0 + tid) * 2] = 0.f; part[(co0 + tid) * 2 + 1] = 0.f; }
+      return;
+    }
   }
 
   const int ED = a.ed[cls], EH = a.eh[cls], EW = a.ew[cls];
   const int nvox = ED * EH * EW;
-  const int nit = (nvox * (ROWB / 16) + 255) >> 8;
   const int i0d = q0d * a.IS + a.mind[cls], i0h = q0h * a.IS + a.minh[cls], i0w = q0w * a.IS + a.minw[cls];
+  const int tb = a.tap_begin[cls], nt = a.tap_begin[cls + 1] - tb;
+  const int ng = (nt + TG - 1) / TG;
 
-  // ---- per-thread staging plan (voxel -> global voxel index), computed once ----
-  int svox[MAXIT];
+  // tap table -> LDS: voxel offset of the tap's window inside the brick | weight slice index << 20
+  if (tid < nt) {
+    const int tp = a.taps[tb + tid];
+    const int sd = (tp & 15) - 8, sh = ((tp >> 4) & 15) - 8, sw = ((tp >> 8) & 15) - 8;
+    ldsTap[tid] = (((sd - a.mind[cls]) * EH + (sh - a.minh[cls])) * EW + (sw - a.minw[cls])) | ((tp >> 12) << 20);
+  }
+
+  // ---- per-thread staging plan for the source brick (branch-free: clamped address + zero select) ----
+  int svox[NIT];
+  unsigned sval = 0;
 #pragma unroll
-  for (int it = 0; it < MAXIT; ++it) {
-    svox[it] = -1;
-    const int idx = tid + it * 256;
-    const int e = idx >> 2;
-    if (it < nit && e < nvox) {
+  for (int it = 0; it < NIT; ++it) {
+    svox[it] = 0;
+    const int e = (tid + it * 256) >> 2;
+    if (e < nvox) {
       const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
       const int id = i0d + ez, ih = i0h + ey, iw = i0w + ex;
-      if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw))
+      if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw)) {
         svox[it] = ((b * a.Di + id) * a.Hi + ih) * a.Wi + iw;
+        sval |= 1u << it;
+      }
     }
+  }
+  // ---- per-thread staging plan for the weight groups: chunk idx -> (tap in group [wave-uniform], cout row, chunk) ----
+  int wsrc[WIT], wdst[WIT];
+#pragma unroll
+  for (int it = 0; it < WIT; ++it) {
+    const int idx = tid + it * 256;
+    const int row = (idx >> 2) % NT, tig = idx / (NT * 4);
+    wsrc[it] = (co0 + row) * a.Cinp + (idx & 3) * EPC;
+    wdst[it] = idx < WCH ? tig * NT * ROWB + swz(row, idx & 3) : -1;
   }
 
   // ---- per-lane fragment bases ----
-  int vb[VS];                                            // LDS voxel index of this lane's voxel, tap shift excluded
+  int vbv[VS];                                           // LDS voxel row of this lane's voxel, tap shift excluded
 #pragma unroll
   for (int j = 0; j < VS; ++j) {
     const int v = wave * (MV / 4) + j * 16 + r16;
     const int lw = v % BW, lh = (v / BW) % BH, ld = v / (BW * BH);
-    vb[j] = ((ld * a.IS) * EH + lh * a.IS) * EW + lw * a.IS;
+    vbv[j] = ((ld * a.IS) * EH + lh * a.IS) * EW + lw * a.IS;
   }
+  int aoff[NS];                                          // swizzled LDS offset of this lane's weight row chunk (tap 0 of a group)
+#pragma unroll
+  for (int i = 0; i < NS; ++i) aoff[i] = swz(i * 16 + r16, g);
   f32x4 acc[NS][VS];
 #pragma unroll
   for (int i = 0; i < NS; ++i)
@@ -106,47 +147,75 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   const T* __restrict__ xg = (const T*)a.x;
   const T* __restrict__ wg = (const T*)a.w;
-  const int tb = a.tap_begin[cls], te = a.tap_begin[cls + 1];
   const int cchunk = (tid & 3) * EPC;                    // this thread's channel offset inside the slab when staging
+  const size_t wtap = (size_t)a.Coutp * a.Cinp;
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
 
-  for (int kc = 0; kc < a.Cin; kc += KC) {
-    __syncthreads();                                     // all fragment reads of the previous slab are done
-    u32x4 stg[MAXIT];
+  // issue the global loads of weight group GI (slab kc) into WR; the tap of a chunk is wave-uniform
+#define AM_WLOAD(WR, GI)                                                                                   \
+  _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
+    const int tt_ = (GI) * TG + (tid + it * 256) / (NT * 4);                                                \
+    const int wi_ = __builtin_amdgcn_readfirstlane(ldsTap[tt_ < nt ? tt_ : nt - 1]) >> 20;                  \
+    WR[it] = *(const u32x4*)(wg + (size_t)wi_ * wtap + kc + wsrc[it]);                                      \
+  }
+#define AM_WSTORE(WR, BUF)                                                                                 \
+  _Pragma("unroll") for (int it = 0; it < WIT; ++it)                                                        \
+    if (wdst[it] >= 0) *(u32x4*)(ldsW + (BUF) * WBUF + wdst[it]) = WR[it];
+
+  for (int kc = 0; kc < (nt > 0 ? a.Cinp : 0); kc += KC) {   // classes without taps (k1 s2 dgrad parities) write zeros
+    __syncthreads();                                     // all fragment reads of the previous slab are done (tap table visible)
+    {
+      const bool cok = kc + cchunk < a.Cin;
+      const int coff = cok ? kc + cchunk : 0;
+      u32x4 stg[NIT], wr0[WIT];
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      stg[it] = u32x4{0u, 0u, 0u, 0u};
-      if (it < nit && svox[it] >= 0 && kc + cchunk < a.Cin)
-        stg[it] = *(const u32x4*)(xg + (size_t)svox[it] * a.Cin + kc + cchunk);
-    }
+      for (int it = 0; it < NIT; ++it) stg[it] = *(const u32x4*)(xg + (size_t)svox[it] * a.Cin + coff);
+      AM_WLOAD(wr0, 0);
 #pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int idx = tid + it * 256;
-      if (it < nit && (idx >> 2) < nvox) *(u32x4*)(lds + (idx >> 2) * LROW + (idx & 3) * 16) = stg[it];
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + it * 256;
+        if ((idx >> 2) < nvox) *(u32x4*)(lds + swz(idx >> 2, idx & 3)) = (cok && ((sval >> it) & 1u)) ? stg[it] : zero4;
+      }
+      AM_WSTORE(wr0, 0);
     }
     __syncthreads();
-    const bool kvalid = (kc + g * EPC) < a.Cin;
-    for (int t = tb; t < te; ++t) {
-      const int tp = a.taps[t];
-      const int sd = (tp & 15) - 8, sh = ((tp >> 4) & 15) - 8, sw = ((tp >> 8) & 15) - 8, widx = tp >> 12;
-      const int tapoff = ((sd - a.mind[cls]) * EH + (sh - a.minh[cls])) * EW + (sw - a.minw[cls]);
-      u32x4 af[NS];
+    for (int gi = 0; gi < ng; ++gi) {
+      const int buf = gi & 1;
+      u32x4 wr[WIT];
+      const bool more = gi + 1 < ng;
+      if (more) { AM_WLOAD(wr, gi + 1); }                // next group's weights fly while this group's MFMAs issue
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int co = co0 + i * 16 + r16;
-        af[i] = u32x4{0u, 0u, 0u, 0u};
-        if (kvalid && co < a.Cout) af[i] = *(const u32x4*)(wg + ((size_t)widx * a.Cout + co) * a.Cin + kc + g * EPC);
+      for (int tl = 0; tl < TG; ++tl) {
+        if (gi * TG + tl < nt) {
+          const int tov = __builtin_amdgcn_readfirstlane(ldsTap[gi * TG + tl]) & 0xFFFFF;
+          u32x4 af[NS];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
+#pragma unroll
+          for (int j = 0; j < VS; ++j) {
+            const int v = vbv[j] + tov;
+            const u32x4 bf = *(const u32x4*)(lds + (v << 6) + ((g << 4) ^ ((v & 4) << 3)));
+#pragma unroll
+            for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+          }
+        }
       }
-#pragma unroll
-      for (int j = 0; j < VS; ++j) {
-        const u32x4 bf = *(const u32x4*)(lds + (vb[j] + tapoff) * LROW + g * 16);
-#pragma unroll
-        for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) { AM_WSTORE(wr, buf ^ 1); }
+      __syncthreads();
     }
   }
+#undef AM_WLOAD
+#undef AM_WSTORE
 
   // ---- epilogue: D row = cout 4g+r, col = voxel r16 ----
   T* __restrict__ yg = (T*)a.y;
+  float ps1[NS][4], ps2[NS][4];
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ps1[i][r] = ps2[i][r] = 0.f;
 #pragma unroll
   for (int j = 0; j < VS; ++j) {
     const int v = wave * (MV / 4) + j * 16 + r16;
@@ -161,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       float o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float vv = acc[i][j][r] + (a.bias ? a.bias[co + r] : 0.f);
+        const float vv = acc[i][j][r] + (a.bias ? a.bias[co + r] : 0.f);
         o[r] = act ? vv : 0.f;
       }
       T* dst = yg + ovox * a.Cout + co;
@@ -176,13 +245,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
         pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
         *(uint2*)dst = pk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = bf2f(f2bf(o[r]));   // statistics of what was actually stored
       }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ps1[i][r] += o[r]; ps2[i][r] += o[r] * o[r]; }
+    }
+  }
+  if (part) {                                            // per-workgroup per-channel partials (no atomics, deterministic)
+    __syncthreads();
+    float* red = (float*)lds;                            // [4 waves][16*NS couts][2]
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = ps1[i][r], s2 = ps2[i][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (r16 == 0) {
+          const int c = i * 16 + g * 4 + r;
+          red[(wave * 16 * NS + c) * 2] = s1; red[(wave * 16 * NS + c) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < 16 * NS && co0 + tid < a.Cout) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { s1 += red[(w * 16 * NS + tid) * 2]; s2 += red[(w * 16 * NS + tid) * 2 + 1]; }
+      part[(co0 + tid) * 2] = s1; part[(co0 + tid) * 2 + 1] = s2;
     }
   }
 }
 
 // host: tap tables ------------------------------------------------------------------------------
-struct Plan { ConvArgs a; int bd, bh, bw; size_t lds; };
+struct Plan { ConvArgs a; int bd, bh, bw; size_t lds; int nit, nt_tile; };
 
 int build_plan(Plan& P, int mode, int k, int stride) {
   ConvArgs& a = P.a;
@@ -223,15 +319,19 @@ int build_plan(Plan& P, int mode, int k, int stride) {
   for (int c = a.nclass; c <= 8; ++c) a.tap_begin[c] = n;
   size_t mxv = 0;
   for (int c = 0; c < a.nclass; ++c) { size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
-  if (mxv * (ROWB / 16) > (size_t)MAXIT * 256) return -3;
-  P.lds = mxv * LROW;
+  P.nit = (int)((mxv * (ROWB / 16) + 255) / 256);
+  size_t brick = mxv * ROWB;
+  if (brick < 4096) brick = 4096;                        // the stats epilogue reuses the head of the brick
+  a.w_lds_off = (int)brick;
+  a.tap_lds_off = a.w_lds_off + 2 * TG * P.nt_tile * ROWB;
+  P.lds = a.tap_lds_off + 64 * sizeof(int);
   return 0;
 }
 
-template <typename T, int BD, int BH, int BW, int NS>
+template <typename T, int BD, int BH, int BW, int NS, int NIT>
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
-  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS>;
+  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT>;
   static size_t attr_lds = 48 * 1024;             // raise the dynamic-LDS cap only when a launch needs it
   if (P.lds > attr_lds) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds) == hipSuccess) attr_lds = P.lds;
@@ -243,39 +343,81 @@ int launch(Plan& P, hipStream_t st) {
   return 0;
 }
 
-template <typename T>
-int dispatch(Plan& P, bool small, hipStream_t st) {
-  const int co = P.a.Cout;
-  if (small) {                                   // 4x4x4 brick (IS == 2: haloed source brick would not fit otherwise)
-    if (co <= 16) return launch<T, 4, 4, 4, 1>(P, st);
-    if (co <= 32) return launch<T, 4, 4, 4, 2>(P, st);
-    return launch<T, 4, 4, 4, 4>(P, st);
+template <typename T, int NS>
+int dispatch_nit(Plan& P, int shape, hipStream_t st) {
+  const int n = P.nit;
+  if (shape == 2) {                              // 4x4x4 brick (IS == 2: the haloed source brick would not fit otherwise)
+    if (n <= 6) return launch<T, 4, 4, 4, NS, 6>(P, st);
+    if (n <= 12) return launch<T, 4, 4, 4, NS, 12>(P, st);
+    if (n <= 16) return launch<T, 4, 4, 4, NS, 16>(P, st);
+    return -3;
   }
-  if (co <= 16) return launch<T, 4, 8, 8, 1>(P, st);
-  if (co <= 32) return launch<T, 4, 8, 8, 2>(P, st);
-  return launch<T, 4, 8, 8, 4>(P, st);
+  if (shape == 1) {                              // 4x4x16: every 16-lane fragment is 16 consecutive voxels (conflict-free reads)
+    if (n <= 4) return launch<T, 4, 4, 16, NS, 4>(P, st);
+    if (n <= 7) return launch<T, 4, 4, 16, NS, 7>(P, st);
+    if (n <= 11) return launch<T, 4, 4, 16, NS, 11>(P, st);
+    return -3;
+  }
+  if (n <= 4) return launch<T, 4, 8, 8, NS, 4>(P, st);          // narrow grids (W < 16)
+  if (n <= 7) return launch<T, 4, 8, 8, NS, 7>(P, st);
+  if (n <= 11) return launch<T, 4, 8, 8, NS, 11>(P, st);
+  return -3;
+}
+
+template <typename T>
+int dispatch(Plan& P, int shape, hipStream_t st) {
+  return P.nt_tile == 32 ? dispatch_nit<T, 2>(P, shape, st) : dispatch_nit<T, 4>(P, shape, st);
 }
 
 }  // namespace
 
+// brick of q-space voxels per workgroup: 0 = 4x8x8 (narrow grids), 1 = 4x4x16, 2 = 4x4x4 (source stride 2)
+static int brick_shape(int mode, int stride, int qw, int* bd, int* bh, int* bw) {
+  const bool small = (mode == AM_CONV_FWD && stride == 2) || mode == AM_CONVT_DGRAD;
+  *bd = 4;
+  if (small) { *bh = 4; *bw = 4; return 2; }
+  if (qw >= 16) { *bh = 4; *bw = 16; return 1; }
+  *bh = 8; *bw = 8; return 0;
+}
+
+extern "C" int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded) {
+  const int tile = rows <= 32 ? 32 : 64;
+  const int kc = dtype == AM_DT_BF16 ? 32 : 16;
+  *rows_padded = (rows + tile - 1) / tile * tile;
+  *k_padded = (k + kc - 1) / kc * kc;
+  return 0;
+}
+
+extern "C" int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int* rows) {
+  const int os = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
+  const int qd = (Do + os - 1) / os, qh = (Ho + os - 1) / os, qw = (Wo + os - 1) / os;
+  int bd, bh, bw;
+  brick_shape(mode, stride, qw, &bd, &bh, &bw);
+  *rows = B * ((qd + bd - 1) / bd) * ((qh + bh - 1) / bh) * ((qw + bw - 1) / bw) * (os == 2 ? 8 : 1);
+  (void)ksize;
+  return 0;
+}
+
 extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed,
                          const float* bias, void* y, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo,
                          int Cout, const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift,
-                         int fd, int fh, int fw, int accumulate, void* stream) {
+                         int fd, int fh, int fw, int accumulate, float* partials, void* stream) {
   if (Cin % 8 || Cout % 8) return -1;
   Plan P;
   ConvArgs& a = P.a;
-  const bool small = (mode == AM_CONV_FWD && stride == 2) || mode == AM_CONVT_DGRAD;
-  P.bd = 4; P.bh = small ? 4 : 8; P.bw = small ? 4 : 8;
+  const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
+  const int shape = brick_shape(mode, stride, (Wo + os_ - 1) / os_, &P.bd, &P.bh, &P.bw);
+  P.nt_tile = Cout <= 32 ? 32 : 64;
   int rc = build_plan(P, mode, ksize, stride);
   if (rc) return rc;
-  a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
+  a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
-  a.Qd = (Do + a.OS - 1) / a.OS; a.Qh = (Ho + a.OS - 1) / a.OS; a.Qw = (Wo + a.OS - 1) / a.OS;
-  a.nbd = (a.Qd + P.bd - 1) / P.bd; a.nbh = (a.Qh + P.bh - 1) / P.bh; a.nbw = (a.Qw + P.bw - 1) / P.bw;
+  am_packed_dims(dtype, Cout, Cin, &a.Coutp, &a.Cinp);
+  const int Qd = (Do + a.OS - 1) / a.OS, Qh = (Ho + a.OS - 1) / a.OS, Qw = (Wo + a.OS - 1) / a.OS;
+  a.nbd = (Qd + P.bd - 1) / P.bd; a.nbh = (Qh + P.bh - 1) / P.bh; a.nbw = (Qw + P.bw - 1) / P.bw;
   a.in_mask = MaskView{in_mask, fd, fh, fw, in_bshift};
   a.out_mask = MaskView{out_mask, fd, fh, fw, out_bshift};
   a.accumulate = accumulate;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, small, st) : dispatch<float>(P, small, st);
+  return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, shape, st) : dispatch<float>(P, shape, st);
 }

@@ -484,13 +484,15 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------ weight (un)packing
-// dst[t][r][k] = src[r*sr + k*sk + t]   (fp32 master -> compute dtype, MFMA row-fragment layout)
+// dst[t][r][k] = src[r*sr + k*sk + t] for r < R, k < K, zero in the padding (dst is [taps][Rp][Kp])
+// (fp32 master -> compute dtype, MFMA row-fragment layout, whole tiles so the conv inner loop needs no bounds)
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int K, int taps, long sr, long sk) {
-  const long n = (long)taps * R * K;
+__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int K, int taps, long sr, long sk,
+                                   int Rp, int Kp) {
+  const long n = (long)taps * Rp * Kp;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int k = i % K; long t = i / K; const int r = t % R; const int tp = t / R;
-    TT<T>::st(dst + i, src[r * sr + k * sk + tp]);
+    const int k = i % Kp; long t = i / Kp; const int r = t % Rp; const int tp = t / Rp;
+    TT<T>::st(dst + i, (r < R && k < K) ? src[r * sr + k * sk + tp] : 0.f);
   }
 }
 // dst[r*sr + k*sk + t] (+)= src[t][r][k]
@@ -503,6 +505,26 @@ __global__ void unpack_grad_kernel(const float* __restrict__ src, float* __restr
     const float v = src[((long)tp * R + r) * K + k];
     float* d = dst + r * sr + k * sk + tp;
     *d = accumulate ? *d + v : v;
+  }
+}
+
+// per-workgroup conv partials [rows][C][2] -> sums[C][2] (double) and/or sum_accum[C] += sum   (one WG per channel)
+__global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int rows, int C, double* __restrict__ sums,
+                                                               float* __restrict__ sum_accum) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float2 v = *(const float2*)(part + ((size_t)r * C + c) * 2);
+    s1 += v.x; s2 += v.y;
+  }
+  s1 = warp_sum_d(s1); s2 = warp_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = s1; sh[4 + (threadIdx.x >> 6)] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = sh[0] + sh[1] + sh[2] + sh[3]; s2 = sh[4] + sh[5] + sh[6] + sh[7];
+    if (sums) { sums[2 * c] = s1; sums[2 * c + 1] = s2; }
+    if (sum_accum) sum_accum[c] += (float)s1;
   }
 }
 
@@ -684,12 +706,20 @@ int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, c
   return 0;
 }
 
-int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, void* stream) {
+int am_partials_reduce(const float* partials, int rows, int C, double* sums, float* sum_accum, void* stream) {
+  AM_LAUNCH(partials_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, sums, sum_accum);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, int Rp, int Kp,
+                   void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  const long n = (long)taps * R * K;
+  if (Rp < R || Kp < K) return -1;
+  const long n = (long)taps * Rp * Kp;
   int nb = (int)((n + 255) / 256); if (nb > 8192) nb = 8192;
-  DISPATCH_T(dtype, AM_LAUNCH(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, src, (float*)dst, R, K, taps, stride_r, stride_k),
-             AM_LAUNCH(pack_weight_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k));
+  DISPATCH_T(dtype, AM_LAUNCH(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, src, (float*)dst, R, K, taps, stride_r, stride_k, Rp, Kp),
+             AM_LAUNCH(pack_weight_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k, Rp, Kp));
   AM_CHECK_LAUNCH();
   return 0;
 }

@@ -73,19 +73,26 @@ def _counts(mask: MaskInfo, levels: Sequence[int]) -> Dict[int, torch.Tensor]:
     return out
 
 
-def _sparse_norm(x, mask, bs, counts, gamma, beta, eps) -> NormStats:
+def _sparse_norm(x, mask, bs, counts, gamma, beta, eps, part=None) -> NormStats:
+    """pooled sparse InstanceNorm statistics; `part` = partial sums left by the producing conv's epilogue."""
     st = NormStats(x.shape[-1], x.device)
     st.count_ptr = counts[bs]
-    ops.chan_stats(x, mask, bs, st)
+    if part is not None:
+        part.reduce(sums=st.sums)
+    else:
+        ops.chan_stats(x, mask, bs, st)
     ops.norm_finalize(st, gamma, beta, eps)
     return st
 
 
-def _batch_norm(x, W, prefix, train: bool) -> NormStats:
+def _batch_norm(x, W, prefix, train: bool, part=None) -> NormStats:
     st = NormStats(x.shape[-1], x.device)
     if train:
         st.count_host = float(x.numel() // x.shape[-1])
-        ops.chan_stats(x, None, 0, st)
+        if part is not None:
+            part.reduce(sums=st.sums)
+        else:
+            ops.chan_stats(x, None, 0, st)
         ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"],
                           W[f"{prefix}.running_var"], 0.1)
         W[f"{prefix}.num_batches_tracked"].add_(1)
@@ -135,15 +142,16 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
             stride = 2 if (first and s > 0) else 1
             rec_ = {"p": p, "s": s, "first": first, "stride": stride, "x": x}
             if s == 0 and first:
-                y1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt)
+                y1, pt1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt), None
             else:
-                y1 = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv1.weight", False, False), W[f"{p}.conv1.bias"], sp, 3, stride,
-                                in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs)
-            st1 = _sparse_norm(y1, mask, bs, counts, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], 1e-5)
+                y1, pt1 = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv1.weight", False, False), W[f"{p}.conv1.bias"], sp, 3, stride,
+                                     in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs,
+                                     want_partials=True)
+            st1 = _sparse_norm(y1, mask, bs, counts, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], 1e-5, pt1)
             a1 = ops.norm_apply(y1, st1, ACT_LRELU, mask, bs)
-            y2 = ops.conv3d(CONV_FWD, a1, pk.get(W, f"{p}.conv2.weight", False, False), W[f"{p}.conv2.bias"], sp, 3, 1,
-                            in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
-            st2 = _sparse_norm(y2, mask, bs, counts, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], 1e-5)
+            y2, pt2 = ops.conv3d(CONV_FWD, a1, pk.get(W, f"{p}.conv2.weight", False, False), W[f"{p}.conv2.bias"], sp, 3, 1,
+                                 in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs, want_partials=True)
+            st2 = _sparse_norm(y2, mask, bs, counts, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], 1e-5, pt2)
             if s == 0 and first:      # 1x1 Cin=1 shortcut folded into the apply pass
                 out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs,
                                      stem=(inp, W[f"{p}.conv3.weight"].view(-1), W[f"{p}.conv3.bias"]))
@@ -182,11 +190,15 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
         q = f"{DEC}.{i}"
         so = tuple(2 * v for v in x.shape[1:4])
         u = ops.conv3d(CONVT_FWD, x, pk.get(W, f"{q}.up_sample.weight", True, False), W[f"{q}.up_sample.bias"], so, 4, 2)
-        c1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1)
-        st1 = _batch_norm(c1, W, f"{q}.conv.1", train)
+        c1, pt1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1, want_partials=train), None
+        if train:
+            c1, pt1 = c1
+        st1 = _batch_norm(c1, W, f"{q}.conv.1", train, pt1)
         r = ops.norm_apply(c1, st1, ACT_RELU6)
-        c2 = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1)
-        st2 = _batch_norm(c2, W, f"{q}.conv.4", train)
+        c2, pt2 = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1, want_partials=train), None
+        if train:
+            c2, pt2 = c2
+        st2 = _batch_norm(c2, W, f"{q}.conv.4", train, pt2)
         nxt = to_dec[i + 1] if i + 1 < n_dec else None       # x = x + to_dec[i+1] fused into the BN apply
         o = ops.norm_apply(c2, st2, ACT_NONE, res=nxt)
         if tape is not None:
@@ -227,12 +239,16 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
         _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
         dc1 = ops.norm_backward(dr, t["r"], t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
                                 G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"])
-        du = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1)
+        du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
+        ptu.reduce(sum_accum=G[f"{q}.up_sample.bias"])           # ConvT bias gradient = per-channel sum of du
         _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
         si = tuple(t["xin"].shape[1:4])
-        g = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2)
+        need_sum = i > 0 and tape.dens[i]["k"]                     # densify_projs[i].bias gradient = sum of this tensor
+        g = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2, want_partials=bool(need_sum))
+        if need_sum:
+            g, ptg = g
+            ptg.reduce(sum_accum=G[f"densify_projs.{i}.bias"])
         _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
-        ops.chan_sum(du, None, 0, G[f"{q}.up_sample.bias"])
     dproj[0] = g
     if after_group:
         after_group("decoder")
@@ -245,7 +261,8 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
             pw = f"densify_projs.{i}.weight"
             dd = ops.conv3d(CONV_DGRAD, dp, pk.get(W, pw, False, True), None, tuple(dp.shape[1:4]), t["k"], 1)
             _wgrad_into(G, pw, CONV_FWD, t["d"], dp, t["k"], 1)
-            ops.chan_sum(dp, None, 0, G[f"densify_projs.{i}.bias"])
+            if i == 0:                                            # (levels >= 1 got it from the ConvT-dgrad epilogue)
+                ops.chan_sum(dp, None, 0, G[f"densify_projs.{i}.bias"])
         else:
             dd = dp
         dfeat[4 - i] = ops.norm_backward(dd, None, t["f"], t["st"], W[f"densify_norms.{i}.weight"], ACT_NONE, mask, i,

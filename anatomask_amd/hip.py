@@ -38,6 +38,8 @@ def declared_functions(header: str = HEADER):
 
 class HipLib:
     def __init__(self, path: str = LIB_PATH):
+        import torch  # noqa: F401  torch's bundled HIP runtime must be the one in the process (same soname as /opt/rocm's):
+        # loading our library first would bring in a second runtime that knows nothing of torch's streams/allocations
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not built: run `python -m anatomask_amd.build` (no fallback path exists)")
         self._lib = C.CDLL(path)

@@ -48,6 +48,27 @@ def _mk(mask: Optional[MaskInfo]):
 
 
 # ------------------------------------------------------------------ weights
+def packed_dims(dtype: torch.dtype, rows: int, k: int):
+    """Same rule as am_packed_dims: rows to the 32/64-channel output tile, K to the 64-byte channel slab."""
+    tile = 32 if rows <= 32 else 64
+    kc = 32 if dtype == torch.bfloat16 else 16
+    return (rows + tile - 1) // tile * tile, (k + kc - 1) // kc * kc
+
+
+class ConvPartials:
+    """Per-workgroup per-channel (sum, sumsq) rows a conv launch leaves behind for the norm / bias-grad that follows."""
+
+    def __init__(self, mode, ksize, stride, B, out_spatial, cout, device):
+        import ctypes
+        n = ctypes.c_int(0)
+        hip.lib().conv3d_partials_rows(mode, ksize, stride, B, *out_spatial, ctypes.addressof(n))
+        self.rows, self.C = n.value, cout
+        self.t = torch.empty(self.rows, cout, 2, device=device, dtype=torch.float32)
+
+    def reduce(self, sums: Optional[torch.Tensor] = None, sum_accum: Optional[torch.Tensor] = None):
+        hip.lib().partials_reduce(self.t.data_ptr(), self.rows, self.C, _p(sums), _p(sum_accum), _stream())
+
+
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_dgrad: bool) -> torch.Tensor:
     """torch-layout fp32 weight -> packed [taps][rows][K] in `dtype`.
     Conv3d weight (Cout,Cin,k,k,k); ConvTranspose3d weight (Cin,Cout,k,k,k).
@@ -60,8 +81,10 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_
         R, K, sr, sk = cout, cin, s_out, s_in
     else:
         R, K, sr, sk = cin, cout, s_in, s_out
-    out = torch.empty(taps, R, K, device=w.device, dtype=dtype)
-    hip.lib().pack_weight(_dt(out), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, _stream())
+    Rp, Kp = packed_dims(dtype, R, K)
+    out = torch.empty(taps, Rp, Kp, device=w.device, dtype=dtype)
+    hip.lib().pack_weight(_dt(out), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, Rp, Kp, _stream())
+    out.logical = (R, K)
     return out
 
 
@@ -80,11 +103,12 @@ def unpack_grad(dw_packed: torch.Tensor, grad_out: torch.Tensor, transposed_conv
 def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], out_spatial: Tuple[int, int, int],
            ksize: int, stride: int, in_mask: Optional[MaskInfo] = None, in_bshift: int = 0,
            out_mask: Optional[MaskInfo] = None, out_bshift: int = 0, out: Optional[torch.Tensor] = None,
-           accumulate: bool = False) -> torch.Tensor:
+           accumulate: bool = False, want_partials: bool = False):
     B, Di, Hi, Wi, Cin = x.shape
-    Cout = w_packed.shape[1]
-    assert w_packed.shape[2] == Cin and w_packed.dtype == x.dtype, (w_packed.shape, x.shape)
+    Cout, Kl = w_packed.logical
+    assert Kl == Cin and w_packed.dtype == x.dtype, (w_packed.logical, x.shape)
     Do, Ho, Wo = out_spatial
+    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device) if want_partials else None
     if out is None:
         out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
     mk = in_mask or out_mask
@@ -92,8 +116,9 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     hip.lib().conv3d(mode, _dt(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
                      B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
                      in_mask.t.data_ptr() if in_mask else None, in_bshift,
-                     out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate), _stream())
-    return out
+                     out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate),
+                     part.t.data_ptr() if part else None, _stream())
+    return (out, part) if want_partials else out
 
 
 def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int,

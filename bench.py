@@ -52,7 +52,7 @@ def dominant_kernel_roofline(B, dev):
     t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (128, 128, 128), 3, 1, out=y))
     flops = 2.0 * B * 128 ** 3 * C * C * 27
     achieved = flops / t / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,8,8,4> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
             "traffic": None, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops}
 

@@ -13,8 +13,9 @@
  *    stored there.  mask == NULL means dense.
  *  - every function is asynchronous on `stream`, never allocates, never synchronises, returns 0 or
  *    a negative argument error / positive hipError_t.
- *  - packed conv weights: [tap][rows][K] in the compute dtype, rows = channels of the tensor WRITTEN,
- *    K = channels of the tensor READ, tap = (td*k + th)*k + tw of the original kernel.
+ *  - packed conv weights: [tap][rows_p][K_p] in the compute dtype, rows = channels of the tensor WRITTEN,
+ *    K = channels of the tensor READ, tap = (td*k + th)*k + tw of the original kernel; rows/K are zero-padded
+ *    to whole MFMA tiles (am_packed_dims) so the inner loop carries no bounds logic.
  */
 #ifndef ANATOMASK_HIP_H
 #define ANATOMASK_HIP_H
@@ -44,7 +45,12 @@ int am_version(void);
 int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed, const float* bias, void* y,
               int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
               const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift, int fd, int fh, int fw,
-              int accumulate, void* stream);
+              int accumulate, float* partials /* NULL or [am_conv3d_partials_rows][Cout][2]: per-workgroup sum / sum-of-squares
+              of the written outputs, feeds the following norm (or a bias gradient) without another pass */, void* stream);
+int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded);
+int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int* rows);
+/* partials [rows][C][2] -> sums[C][2] (double, overwritten; may be NULL) and/or sum_accum[C] += sum (may be NULL) */
+int am_partials_reduce(const float* partials, int rows, int C, double* sums, float* sum_accum, void* stream);
 
 /* Weight gradient (autograd of the above).  mode = AM_CONV_FWD or AM_CONVT_FWD.  x = forward input
  * [B][Dx][Hx][Wx][Cx], dy = gradient of the forward output [B][Dy][Hy][Wy][Cy];
@@ -54,8 +60,9 @@ int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, c
                     const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift, int fd, int fh, int fw,
                     void* stream);
 
-/* dst[t][r][k] = src[r*stride_r + k*stride_k + t]: torch-layout fp32 master weights -> packed compute-dtype. */
-int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, void* stream);
+/* dst[t][r][k] = src[r*stride_r + k*stride_k + t] (zero in the padding): torch-layout fp32 master -> packed [taps][Rp][Kp]. */
+int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, int Rp, int Kp,
+                   void* stream);
 /* dst[r*stride_r + k*stride_k + t] (+)= src[t][r][k]: packed fp32 gradient -> torch layout. */
 int am_unpack_grad(const float* src_packed, float* dst, int R, int K, int taps, long stride_r, long stride_k, int accumulate,
                    void* stream);

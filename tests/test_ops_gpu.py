@@ -378,11 +378,36 @@ def test_pack_unpack_roundtrip(ops):
     for tc in (False, True):
         wp = ops.pack_weight(w, torch.float32, tc, False)
         cout, cin = (16, 24) if tc else (24, 16)
-        assert wp.shape == (27, cout, cin)
+        assert wp.logical == (cout, cin) and wp.shape == (27, *ops.packed_dims(torch.float32, cout, cin))
+        core = wp[:, :cout, :cin].contiguous()
+        assert wp.abs().sum().item() == core.abs().sum().item()          # padding is zero
         back = torch.zeros_like(w)
-        ops.unpack_grad(wp.contiguous(), back, tc, False)
+        ops.unpack_grad(core, back, tc, False)
         assert torch.equal(back, w)
         ref = (w.permute(2, 3, 4, 1, 0) if tc else w.permute(2, 3, 4, 0, 1)).reshape(27, cout, cin)
-        assert torch.equal(wp, ref)
+        assert torch.equal(core, ref)
         wd = ops.pack_weight(w, torch.float32, tc, True)
-        assert torch.equal(wd, ref.transpose(1, 2))
+        assert torch.equal(wd[:, :cin, :cout], ref.transpose(1, 2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("sparse", [False, True])
+def test_conv_epilogue_partials_feed_the_norm(ops, dtype, sparse):
+    """Per-workgroup (sum, sumsq) partials written by the conv epilogue == a separate statistics pass over its output."""
+    B, cin, cout, f = 2, 32, 48, (2, 2, 3)
+    sp = tuple(v * 4 for v in f)
+    mask = mk_mask(B, f, 5) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    x = q(rnd(B, cin, *sp, seed=1), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=2, scale=0.05), dtype)
+    wp = ops.pack_weight(w.to(DEV), dtype, False, False)
+    y, part = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, sp, 3, 1, in_mask=mi, in_bshift=2, out_mask=mi, out_bshift=2,
+                         want_partials=True)
+    st_a, st_b = ops.NormStats(cout, DEV), ops.NormStats(cout, DEV)
+    part.reduce(sums=st_a.sums)
+    ops.chan_stats(y, mi, 2, st_b)
+    ref = st_b.sums.cpu()
+    assert (st_a.sums.cpu() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    acc = torch.ones(cout, device=DEV)
+    part.reduce(sum_accum=acc)
+    assert (acc.cpu() - 1 - ref[:, 0].float()).abs().max().item() <= 1e-4 * ref[:, 0].abs().max().item() + 1e-5
