@@ -36,6 +36,7 @@ struct ConvArgs {
   int taps[64];               // (sd+8) | (sh+8)<<4 | (sw+8)<<8 | widx<<12
   int mind[8], minh[8], minw[8];
   int ed[8], eh[8], ew[8];    // LDS source-brick extents per class
+  int mdiv_w[8], mdiv_hw[8];  // 2^20-scaled reciprocals of ew and ew*eh (exact floor division for e < 1024)
   int w_lds_off, tap_lds_off; // byte offsets of the weight-group buffers / tap table inside dynamic LDS
   MaskView in_mask, out_mask;
   int accumulate;
@@ -105,12 +106,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // ---- per-thread staging plan for the source brick (branch-free: clamped address + zero select) ----
   int svox[NIT];
   unsigned sval = 0;
+  const int mW = a.mdiv_w[cls], mHW = a.mdiv_hw[cls], EHW = EH * EW;
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     svox[it] = 0;
     const int e = (tid + it * 256) >> 2;
     if (e < nvox) {
-      const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
+      const int ez = (e * mHW) >> 20, rem = e - ez * EHW;       // runtime extents: reciprocal multiply instead of
+      const int ey = (rem * mW) >> 20, ex = rem - ey * EW;       // ~35-instruction integer divisions
       const int id = i0d + ez, ih = i0h + ey, iw = i0w + ex;
       if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw)) {
         svox[it] = ((b * a.Di + id) * a.Hi + ih) * a.Wi + iw;
@@ -216,6 +219,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int i = 0; i < NS; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ps1[i][r] = ps2[i][r] = 0.f;
+  f32x4 bia[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int co = co0 + i * 16 + g * 4;
+    bia[i] = (a.bias && co < a.Cout) ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int j = 0; j < VS; ++j) {
     const int v = wave * (MV / 4) + j * 16 + r16;
@@ -227,29 +236,25 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < NS; ++i) {
       const int co = co0 + i * 16 + g * 4;
       if (co >= a.Cout) continue;                        // Cout % 4 == 0 (C % 8 == 0 contract)
-      float o[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float vv = acc[i][j][r] + (a.bias ? a.bias[co + r] : 0.f);
-        o[r] = act ? vv : 0.f;
-      }
+      f32x4 o = acc[i][j] + bia[i];
+      if (!act) o = f32x4{0.f, 0.f, 0.f, 0.f};
       T* dst = yg + ovox * a.Cout + co;
       if (a.accumulate && act) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] += TT<T>::ld(dst + r);
       }
-      if (sizeof(T) == 4) {
-        *(f32x4*)dst = f32x4{o[0], o[1], o[2], o[3]};
+      if constexpr (sizeof(T) == 4) {
+        *(f32x4*)dst = o;
       } else {
-        uint2 pk;
-        pk.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-        pk.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-        *(uint2*)dst = pk;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = bf2f(f2bf(o[r]));   // statistics of what was actually stored
+        typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
+        const bfx4 pk = __builtin_convertvector(o, bfx4);      // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+        *(bfx4*)dst = pk;
+        if (part) o = __builtin_convertvector(pk, f32x4);      // statistics of what was actually stored
       }
+      if (part) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { ps1[i][r] += o[r]; ps2[i][r] += o[r] * o[r]; }
+        for (int r = 0; r < 4; ++r) { ps1[i][r] += o[r]; ps2[i][r] += o[r] * o[r]; }
+      }
     }
   }
   if (part) {                                            // per-workgroup per-channel partials (no atomics, deterministic)
@@ -315,6 +320,8 @@ int build_plan(Plan& P, int mode, int k, int stride) {
     a.ed[c] = (P.bd - 1) * a.IS + (mx[0] - mn[0]) + 1;
     a.eh[c] = (P.bh - 1) * a.IS + (mx[1] - mn[1]) + 1;
     a.ew[c] = (P.bw - 1) * a.IS + (mx[2] - mn[2]) + 1;
+    a.mdiv_w[c] = (1 << 20) / a.ew[c] + 1;
+    a.mdiv_hw[c] = (1 << 20) / (a.ew[c] * a.eh[c]) + 1;
   }
   for (int c = a.nclass; c <= 8; ++c) a.tap_begin[c] = n;
   size_t mxv = 0;
