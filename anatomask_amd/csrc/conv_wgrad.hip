@@ -6,12 +6,15 @@
 // i.e. a GEMM with M = cy (dY channels), N = cx (X channels), K = voxels.  Taps are processed in
 // groups that share the dY operand: conv k3 -> 3 groups of 9 taps (same d-shift: the X brick needs
 // no d-halo), ConvT -> the 8 output-parity classes of 8 taps.  A workgroup owns (group, 64 cy, 64 cx),
-// walks a strided set of q-bricks, stages dY-brick and haloed X-brick channels-last in LDS and
-// contracts over voxels.  The contraction index (voxel) is NOT the contiguous one in memory, so bf16
-// fragments are fetched with ds_read_b64_tr_b16 (hardware transpose read: 4 voxels x 16 channels per
-// 16-lane group); f32 fragments are plain 4-byte LDS reads for v_mfma_f32_16x16x4_f32.
+// walks a strided set of q-bricks, stages dY-brick and haloed X-brick channels-last in LDS (branch-free
+// loads from a per-thread plan computed once) and contracts over voxels.  The contraction index (voxel)
+// is NOT the contiguous one in memory, so bf16 fragments are fetched with ds_read_b64_tr_b16 (hardware
+// transpose read: 4 voxels x 16 channels per 16-lane group); f32 fragments are plain 4-byte LDS reads for
+// v_mfma_f32_16x16x4_f32.  The tap count is a template parameter: per k-step every fragment read of all
+// taps is issued before the first MFMA, so LDS latency is paid once per k-step, not once per tap.
 // Partial sums leave the workgroup as f32 atomics into the packed [tap][cy][cx] gradient
 // (64-byte runs per 16 lanes; order-dependent in the last bits, like any split-K atomic reduce).
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/anatomask_hip.h"
 
@@ -26,28 +29,27 @@ struct WgArgs {
   int taps[64];
   int mind[8], minh[8], minw[8];
   int ed[8], eh[8], ew[8];
+  int mdiv_w[8], mdiv_hw[8];  // 2^20-scaled reciprocals of ew and ew*eh
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
+  int dbg;                    // AM_WG_DBG ablation bits (timing experiments only): 1 no flush, 2 no contraction, 4 no global loads
 };
 
-constexpr int CT = 64, KT = 64, TG = 9;
-
-template <typename T> struct Frag;   // A/B operand of one k-step for a 16-channel subtile
-template <> struct Frag<bf16_t> { typedef s16x8 type; static constexpr int KSTEP = 32; };
-template <> struct Frag<float> { typedef float type; static constexpr int KSTEP = 4; };
+constexpr int CT = 64, KT = 64;
 
 __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-template <typename T, int BD, int BH, int BW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int MV = BD * BH * BW;
-  constexpr int KSTEP = Frag<T>::KSTEP;
+  constexpr int KSTEP = sizeof(T) == 2 ? 32 : 4;
   constexpr int RSY = CT * sizeof(T) + 16;               // LDS row strides (bytes)
   constexpr int RSX = KT * sizeof(T) + 16;
   constexpr int CPR = CT / EPC;                          // 16-byte chunks per row
+  constexpr int NITY = (MV * CPR + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* ldsY = lds;
   unsigned char* ldsX = lds + MV * RSY;
@@ -60,28 +62,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   const int pd = (a.pofs[grp] >> 2) & 1, ph = (a.pofs[grp] >> 1) & 1, pw = a.pofs[grp] & 1;
   const int ED = a.ed[grp], EH = a.eh[grp], EW = a.ew[grp];
   const int nvox = ED * EH * EW;
-  const int tb = a.tap_begin[grp], ntap = a.tap_begin[grp + 1] - tb;
-  if (ntap == 0) return;
+  const int mW = a.mdiv_w[grp], mHW = a.mdiv_hw[grp], EHW = EH * EW;
+  const int tb = a.tap_begin[grp];
 
-  f32x4 acc[TG][4];
+  f32x4 acc[NTAP][4];
 #pragma unroll
-  for (int t = 0; t < TG; ++t)
+  for (int t = 0; t < NTAP; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int tapoff[TG];
+  int tapoff[NTAP];                                      // byte offset of each tap's window in the X brick (wave-uniform)
 #pragma unroll
-  for (int t = 0; t < TG; ++t) {
-    tapoff[t] = 0;
-    if (t < ntap) {
-      const int tp = a.taps[tb + t];
-      const int sd = (tp & 15) - 8, sh = ((tp >> 4) & 15) - 8, sw = ((tp >> 8) & 15) - 8;
-      tapoff[t] = ((sd - a.mind[grp]) * EH + (sh - a.minh[grp])) * EW + (sw - a.minw[grp]);
-    }
+  for (int t = 0; t < NTAP; ++t) {
+    const int tp = a.taps[tb + t];
+    const int sd = (tp & 15) - 8, sh = ((tp >> 4) & 15) - 8, sw = ((tp >> 8) & 15) - 8;
+    tapoff[t] = (((sd - a.mind[grp]) * EH + (sh - a.minh[grp])) * EW + (sw - a.minw[grp])) * RSX;
   }
+
+  // ---- per-thread staging plans (brick-relative, computed once) ----
+  int yrel[NITY], ydst[NITY];                            // voxel offset relative to the brick origin ; LDS byte offset (-1: none)
+#pragma unroll
+  for (int it = 0; it < NITY; ++it) {
+    const int idx = tid + it * 256;
+    const int v = idx / CPR, c = idx % CPR;
+    yrel[it] = (((v / (BW * BH)) * a.OS) * a.Hy + ((v / BW) % BH) * a.OS) * a.Wy + (v % BW) * a.OS;
+    ydst[it] = idx < MV * CPR ? v * RSY + c * 16 : -1;
+  }
+  int xrel[NITX], xdst[NITX];
+#pragma unroll
+  for (int it = 0; it < NITX; ++it) {
+    const int idx = tid + it * 256;
+    const int e = idx / CPR, c = idx % CPR;
+    const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
+    xrel[it] = e < nvox ? (ez * a.Hx + ey) * a.Wx + (rem - ey * EW) : 0;
+    xdst[it] = e < nvox ? e * RSX + c * 16 : -1;
+  }
+  const int ychan = (tid % CPR) * EPC;                   // 256 % CPR == 0: a thread keeps its channel chunk across iterations
+  const bool ycok = cy0 + ychan < a.Cy, xcok = cx0 + ychan < a.Cx;
+  const int ycoff = ycok ? cy0 + ychan : 0, xcoff = xcok ? cx0 + ychan : 0;
 
   const T* __restrict__ xg = (const T*)a.x;
   const T* __restrict__ yg = (const T*)a.dy;
   const int nbrick = a.B * a.nbd * a.nbh * a.nbw;
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
 
   for (int brick = blockIdx.x; brick < nbrick; brick += gridDim.x) {
     int bid = brick;
@@ -89,75 +111,99 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     const int bh_ = bid % a.nbh; bid /= a.nbh;
     const int bd_ = bid % a.nbd; const int b = bid / a.nbd;
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
-
-    // ---- stage dY brick (zero where out of range / inactive); skip the brick if it is all zero ----
-    __syncthreads();
-    int any = 0;
-    for (int idx = tid; idx < MV * CPR; idx += 256) {
-      const int v = idx / CPR, c = idx % CPR;
-      const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
-      u32x4 val = u32x4{0u, 0u, 0u, 0u};
-      const int cy = cy0 + c * EPC;
-      if (od < a.Dy && oh < a.Hy && ow < a.Wy && a.y_mask.active(b, od, oh, ow)) {
-        any = 1;
-        if (cy < a.Cy) val = *(const u32x4*)(yg + (((size_t)(b * a.Dy + od) * a.Hy + oh) * a.Wy + ow) * a.Cy + cy);
-      }
-      *(u32x4*)(ldsY + v * RSY + c * 16) = val;
-    }
-    if (!__syncthreads_or(any)) continue;
-    // ---- stage haloed X brick ----
     const int i0d = q0d * a.IS + a.mind[grp], i0h = q0h * a.IS + a.minh[grp], i0w = q0w * a.IS + a.minw[grp];
-    for (int idx = tid; idx < nvox * CPR; idx += 256) {
-      const int e = idx / CPR, c = idx % CPR;
-      const int id = i0d + e / (EW * EH), ih = i0h + (e / EW) % EH, iw = i0w + e % EW;
-      u32x4 val = u32x4{0u, 0u, 0u, 0u};
-      const int cx = cx0 + c * EPC;
-      if (cx < a.Cx && id >= 0 && id < a.Dx && ih >= 0 && ih < a.Hx && iw >= 0 && iw < a.Wx && a.x_mask.active(b, id, ih, iw))
-        val = *(const u32x4*)(xg + (((size_t)(b * a.Dx + id) * a.Hx + ih) * a.Wx + iw) * a.Cx + cx);
-      *(u32x4*)(ldsX + e * RSX + c * 16) = val;
+
+    // ---- addresses + validity of this brick's rows (clamped; zero-selected after the load) ----
+    int yv[NITY], xv[NITX];
+    unsigned yok = 0, xok = 0;
+    const int ybase = ((b * a.Dy + q0d * a.OS + pd) * a.Hy + q0h * a.OS + ph) * a.Wy + q0w * a.OS + pw;
+    const int xbase = ((b * a.Dx + i0d) * a.Hx + i0h) * a.Wx + i0w;
+    // interior brick of a dense tensor (wave-uniform): everything in range, one add per row instead of the bounds logic
+    const bool interior = !a.x_mask.m && !a.y_mask.m && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + ED <= a.Dx && i0h + EH <= a.Hx &&
+                          i0w + EW <= a.Wx && (q0d + BD - 1) * a.OS + pd < a.Dy && (q0h + BH - 1) * a.OS + ph < a.Hy &&
+                          (q0w + BW - 1) * a.OS + pw < a.Wy;
+    if (interior) {
+#pragma unroll
+      for (int it = 0; it < NITY; ++it) yv[it] = ybase + yrel[it];
+#pragma unroll
+      for (int it = 0; it < NITX; ++it) xv[it] = xbase + xrel[it];
+      yok = xok = 0xffffffffu;
+    } else {
+#pragma unroll
+      for (int it = 0; it < NITY; ++it) {
+        const int v = (tid + it * 256) / CPR;
+        const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
+        const bool ok = ydst[it] >= 0 && od < a.Dy && oh < a.Hy && ow < a.Wy && a.y_mask.active(b, od, oh, ow);
+        yv[it] = ok ? ybase + yrel[it] : 0;
+        yok |= (ok ? 1u : 0u) << it;
+      }
+      if (a.y_mask.m && !__syncthreads_or(yok != 0)) continue;    // nothing active in this brick (block-sparse dY)
+#pragma unroll
+      for (int it = 0; it < NITX; ++it) {
+        const int e = (tid + it * 256) / CPR;
+        const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
+        const int id = i0d + ez, ih = i0h + ey, iw = i0w + rem - ey * EW;
+        const bool ok = xdst[it] >= 0 && id >= 0 && id < a.Dx && ih >= 0 && ih < a.Hx && iw >= 0 && iw < a.Wx && a.x_mask.active(b, id, ih, iw);
+        xv[it] = ok ? xbase + xrel[it] : 0;
+        xok |= (ok ? 1u : 0u) << it;
+      }
     }
+    u32x4 ys[NITY], xs[NITX];
+#pragma unroll
+    for (int it = 0; it < NITY; ++it) ys[it] = (a.dbg & 4) ? zero4 : *(const u32x4*)(yg + (size_t)yv[it] * a.Cy + ycoff);
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) xs[it] = (a.dbg & 4) ? zero4 : *(const u32x4*)(xg + (size_t)xv[it] * a.Cx + xcoff);
+    __syncthreads();                                     // previous brick's fragment reads are done
+#pragma unroll
+    for (int it = 0; it < NITY; ++it)
+      if (ydst[it] >= 0) *(u32x4*)(ldsY + ydst[it]) = (ycok && ((yok >> it) & 1u)) ? ys[it] : zero4;
+#pragma unroll
+    for (int it = 0; it < NITX; ++it)
+      if (xdst[it] >= 0) *(u32x4*)(ldsX + xdst[it]) = (xcok && ((xok >> it) & 1u)) ? xs[it] : zero4;
     __syncthreads();
 
     // ---- contract over the brick's voxels ----
-    for (int ks = 0; ks < MV / KSTEP; ++ks) {
+#pragma unroll 1
+    for (int ks = 0; ks < ((a.dbg & 2) ? 0 : MV / KSTEP); ++ks) {
       if constexpr (sizeof(T) == 2) {
         const int q = (lane >> 2) & 3, p = lane & 3;
         const int v1 = ks * 32 + g * 8 + q, v2 = v1 + 4;
-        const int xv1 = ((v1 / (BW * BH)) * a.IS * EH + ((v1 / BW) % BH) * a.IS) * EW + (v1 % BW) * a.IS;
-        const int xv2 = ((v2 / (BW * BH)) * a.IS * EH + ((v2 / BW) % BH) * a.IS) * EW + (v2 % BW) * a.IS;
-        s16x8 af[4];
+        const int xa1 = (((v1 / (BW * BH)) * a.IS * EH + ((v1 / BW) % BH) * a.IS) * EW + (v1 % BW) * a.IS) * RSX + (16 * wave + 4 * p) * 2;
+        const int xa2 = (((v2 / (BW * BH)) * a.IS * EH + ((v2 / BW) % BH) * a.IS) * EW + (v2 % BW) * a.IS) * RSX + (16 * wave + 4 * p) * 2;
+        s16x4 alo[4], ahi[4], blo[NTAP], bhi[NTAP];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const s16x4 lo = tr_read(ldsY + v1 * RSY + (16 * i + 4 * p) * 2);
-          const s16x4 hi = tr_read(ldsY + v2 * RSY + (16 * i + 4 * p) * 2);
-          af[i] = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          alo[i] = tr_read(ldsY + v1 * RSY + (16 * i + 4 * p) * 2);
+          ahi[i] = tr_read(ldsY + v2 * RSY + (16 * i + 4 * p) * 2);
         }
 #pragma unroll
-        for (int t = 0; t < TG; ++t) {
-          if (t < ntap) {
-            const s16x4 lo = tr_read(ldsX + (xv1 + tapoff[t]) * RSX + (16 * wave + 4 * p) * 2);
-            const s16x4 hi = tr_read(ldsX + (xv2 + tapoff[t]) * RSX + (16 * wave + 4 * p) * 2);
-            const s16x8 bf = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+        for (int t = 0; t < NTAP; ++t) {
+          blo[t] = tr_read(ldsX + xa1 + tapoff[t]);
+          bhi[t] = tr_read(ldsX + xa2 + tapoff[t]);
+        }
+        typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+        bfx8 af[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, af[i]), __builtin_bit_cast(bfx8, bf), acc[t][i], 0, 0, 0);
-          }
+        for (int i = 0; i < 4; ++i)
+          af[i] = __builtin_bit_cast(bfx8, s16x8{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]});
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          const bfx8 bf = __builtin_bit_cast(bfx8, s16x8{blo[t][0], blo[t][1], blo[t][2], blo[t][3], bhi[t][0], bhi[t][1], bhi[t][2], bhi[t][3]});
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
         }
       } else {
         const int v = ks * 4 + g;
-        const int xv = ((v / (BW * BH)) * a.IS * EH + ((v / BW) % BH) * a.IS) * EW + (v % BW) * a.IS;
-        float af[4];
+        const int xa = (((v / (BW * BH)) * a.IS * EH + ((v / BW) % BH) * a.IS) * EW + (v % BW) * a.IS) * RSX + (16 * wave + r16) * 4;
+        float af[4], bf[NTAP];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const float*)(ldsY + v * RSY + (16 * i + r16) * 4);
 #pragma unroll
-        for (int t = 0; t < TG; ++t) {
-          if (t < ntap) {
-            const float bf = *(const float*)(ldsX + (xv + tapoff[t]) * RSX + (16 * wave + r16) * 4);
+        for (int t = 0; t < NTAP; ++t) bf[t] = *(const float*)(ldsX + xa + tapoff[t]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf, acc[t][i], 0, 0, 0);
-          }
-        }
+        for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[t], acc[t][i], 0, 0, 0);
       }
     }
   }
@@ -165,8 +211,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   // ---- flush: D row = cy 4g+r, col = cx r16 ----
   const int cx = cx0 + 16 * wave + r16;
 #pragma unroll
-  for (int t = 0; t < TG; ++t) {
-    if (t < ntap && cx < a.Cx) {
+  for (int t = 0; t < NTAP; ++t) {
+    if (cx < a.Cx && !(a.dbg & 1)) {
       const int widx = a.taps[tb + t] >> 12;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -179,11 +225,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
-template <typename T, int BD, int BH, int BW>
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX>
 int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
-  auto kern = conv_wgrad_kernel<T, BD, BH, BW>;
+  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX>;
   const size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + 16) + maxvox * (KT * sizeof(T) + 16);
   if (lds > 160 * 1024) return -3;
+  if (maxvox * (CT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
   static size_t attr_lds = 48 * 1024;
   if (lds > attr_lds) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_lds = lds;
@@ -208,6 +255,7 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   a.x_mask = MaskView{x_mask, fd, fh, fw, x_bshift};
   a.y_mask = MaskView{y_mask, fd, fh, fw, y_bshift};
   const int k = ksize;
+  { const char* e_ = getenv("AM_WG_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
   int bd, bh, bw;
   const bool bf = dtype == AM_DT_BF16;
   if (mode == AM_CONV_FWD) {
@@ -218,7 +266,12 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     if (k != 4 || stride != 2) return -2;
     a.OS = 2; a.IS = 1; a.ngroup = 8;
   } else return -2;
-  if (a.IS == 2) { bd = bf ? 4 : 2; bh = 4; bw = 4; } else { bd = bf ? 4 : 2; bh = 8; bw = 8; }
+  const int Qd = (Dy + a.OS - 1) / a.OS, Qh = (Hy + a.OS - 1) / a.OS, Qw = (Wy + a.OS - 1) / a.OS;
+  // q-brick per staging round.  bf16 (k-steps of 32 voxels): 2x4x16 / 2x8x8 = 128 voxels, ~44 KB of LDS so two
+  // workgroups share a CU and overlap each other's staging; source stride 2: 4x4x4.  f32 (k-steps of 4): 2x8x8 / 2x4x4.
+  if (a.IS == 2) { bd = bf ? 4 : 2; bh = 4; bw = 4; }
+  else if (bf && Qw >= 16) { bd = 2; bh = 4; bw = 16; }
+  else { bd = 2; bh = 8; bw = 8; }
   const int pad = (mode == AM_CONVT_FWD) ? 1 : k / 2;
   int n = 0; size_t maxvox = 0;
   for (int gI = 0; gI < a.ngroup; ++gI) {
@@ -236,24 +289,34 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
       for (int d = 0; d < 3; ++d) { if (first || s[d] < mn[d]) mn[d] = s[d]; if (first || s[d] > mx[d]) mx[d] = s[d]; }
       first = false;
     }
-    if (n - a.tap_begin[gI] > TG) return -2;
     a.mind[gI] = mn[0]; a.minh[gI] = mn[1]; a.minw[gI] = mn[2];
     a.ed[gI] = (bd - 1) * a.IS + (mx[0] - mn[0]) + 1;
     a.eh[gI] = (bh - 1) * a.IS + (mx[1] - mn[1]) + 1;
     a.ew[gI] = (bw - 1) * a.IS + (mx[2] - mn[2]) + 1;
+    a.mdiv_w[gI] = (1 << 20) / a.ew[gI] + 1;
+    a.mdiv_hw[gI] = (1 << 20) / (a.ew[gI] * a.eh[gI]) + 1;
     const size_t v = (size_t)a.ed[gI] * a.eh[gI] * a.ew[gI];
     if (v > maxvox) maxvox = v;
   }
   for (int gI = a.ngroup; gI <= 8; ++gI) a.tap_begin[gI] = n;
-  const int Qd = (Dy + a.OS - 1) / a.OS, Qh = (Hy + a.OS - 1) / a.OS, Qw = (Wy + a.OS - 1) / a.OS;
+  const int ntap = n / a.ngroup;                           // 9 (conv k3), 8 (ConvT), 1 (conv k1): uniform per group
   a.nbd = (Qd + bd - 1) / bd; a.nbh = (Qh + bh - 1) / bh; a.nbw = (Qw + bw - 1) / bw;
   const int nbrick = B * a.nbd * a.nbh * a.nbw;
-  // enough workgroups to fill 256 CUs, few enough that the atomic flush stays small
+  // enough workgroups to fill 256 CUs x 2, few enough that the atomic flush stays small
   const int tiles = ((Cy + CT - 1) / CT) * ((Cx + KT - 1) / KT) * a.ngroup;
   int split = (1024 + tiles - 1) / tiles;
   if (split > nbrick) split = nbrick;
   if (split < 1) split = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (bf) return a.IS == 2 ? launch<bf16_t, 4, 4, 4>(a, maxvox, split, st) : launch<bf16_t, 4, 8, 8>(a, maxvox, split, st);
-  return a.IS == 2 ? launch<float, 2, 4, 4>(a, maxvox, split, st) : launch<float, 2, 8, 8>(a, maxvox, split, st);
+#define WG_CASE(TT_, BD_, BH_, BW_, NT_, NX_) return launch<TT_, BD_, BH_, BW_, NT_, NX_>(a, maxvox, split, st)
+  if (bf) {
+    if (a.IS == 2) { if (ntap == 9) WG_CASE(bf16_t, 4, 4, 4, 9, 18); if (ntap == 1) WG_CASE(bf16_t, 4, 4, 4, 1, 11); return -2; }
+    if (bw == 16) { if (ntap == 9) WG_CASE(bf16_t, 2, 4, 16, 9, 7); if (ntap == 8) WG_CASE(bf16_t, 2, 4, 16, 8, 8); if (ntap == 1) WG_CASE(bf16_t, 2, 4, 16, 1, 4); return -2; }
+    if (ntap == 9) WG_CASE(bf16_t, 2, 8, 8, 9, 7); if (ntap == 8) WG_CASE(bf16_t, 2, 8, 8, 8, 8); if (ntap == 1) WG_CASE(bf16_t, 2, 8, 8, 1, 4);
+    return -2;
+  }
+  if (a.IS == 2) { if (ntap == 9) WG_CASE(float, 2, 4, 4, 9, 16); if (ntap == 1) WG_CASE(float, 2, 4, 4, 1, 10); return -2; }
+  if (ntap == 9) WG_CASE(float, 2, 8, 8, 9, 13); if (ntap == 8) WG_CASE(float, 2, 8, 8, 8, 16); if (ntap == 1) WG_CASE(float, 2, 8, 8, 1, 8);
+  return -2;
+#undef WG_CASE
 }
