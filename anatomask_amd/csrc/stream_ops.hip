@@ -8,15 +8,26 @@
 
 namespace {
 
-constexpr int VPW = 2048;   // voxels per workgroup for the row-walking kernels
+constexpr int NREP = 8;      // replicated reduction accumulators (spreads same-address atomic contention)
 
 struct Geo {                 // a channels-last tensor [B][D][H][W][C] and its (optional) patch mask
   int B, D, H, W, C;
+  int vpw;                   // voxels per workgroup (host picks it so that every launch has ~1-2k workgroups)
+  unsigned mW, mH, mD;       // floor(2^32/d)+1: exact floor(v/d) by __umulhi for v*d < 2^32
   MaskView mask;
   __device__ __forceinline__ bool active(long v) const {
     if (!mask.m) return true;
-    const int w = v % W; long t = v / W; const int h = t % H; t /= H; const int d = t % D; const int b = t / D;
-    return mask.active(b, d, h, w);
+    const unsigned u = (unsigned)v;
+    const unsigned t1 = __umulhi(u, mW); const int w = u - t1 * W;
+    const unsigned t2 = __umulhi(t1, mH); const int h = t1 - t2 * H;
+    const unsigned b = __umulhi(t2, mD); const int d = t2 - b * D;
+    return mask.active((int)b, d, h, w);
+  }
+  __device__ __forceinline__ void decode(long v, int& b, int& d, int& h, int& w) const {
+    const unsigned u = (unsigned)v;
+    const unsigned t1 = __umulhi(u, mW); w = u - t1 * W;
+    const unsigned t2 = __umulhi(t1, mH); h = t1 - t2 * H;
+    const unsigned bb = __umulhi(t2, mD); d = t2 - bb * D; b = (int)bb;
   }
   __device__ __forceinline__ long nvox() const { return (long)B * D * H * W; }
 };
@@ -39,7 +50,7 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x
   float s1[EPC], s2[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) s1[i] = s2[i] = 0.f;
-  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
   if (wk.live)
     for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
       if (!g.active(v)) continue;
@@ -63,7 +74,8 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x
 #pragma unroll
     for (int i = 0; i < EPC; ++i) {
       const int c = threadIdx.x * EPC + i;
-      atomicAdd(&sums[c * 2], a1[i]); atomicAdd(&sums[c * 2 + 1], a2[i]);
+      double* sr = sums + (size_t)(blockIdx.x % NREP) * g.C * 2;
+      atomicAdd(&sr[c * 2], a1[i]); atomicAdd(&sr[c * 2 + 1], a2[i]);
     }
   }
 }
@@ -80,14 +92,16 @@ __global__ void mask_count_kernel(const uint8_t* mask, int n, int voxels_per_pat
 }
 
 // mean / rstd / folded scale+shift; optional BatchNorm running-stat update (momentum, unbiased var)
-__global__ void norm_finalize_kernel(const double* sums, const double* count_ptr, double count_host, int C,
+__global__ void norm_finalize_kernel(const double* sums, int nrep, const double* count_ptr, double count_host, int C,
                                      const float* gamma, const float* beta, float eps, float* mean, float* rstd,
                                      float* scale, float* shift, float* run_mean, float* run_var, float momentum) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const double n = count_ptr ? count_ptr[0] : count_host;
-  const double m = sums[2 * c] / n;
-  double var = sums[2 * c + 1] / n - m * m;
+  double q1 = 0.0, q2 = 0.0;
+  for (int r = 0; r < nrep; ++r) { q1 += sums[((size_t)r * C + c) * 2]; q2 += sums[((size_t)r * C + c) * 2 + 1]; }
+  const double m = q1 / n;
+  double var = q2 / n - m * m;
   if (var < 0) var = 0;
   const float rs = (float)(1.0 / sqrt(var + (double)eps));
   mean[c] = (float)m; rstd[c] = rs;
@@ -134,7 +148,7 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
   float sc[EPC], sh[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) { sc[i] = scale[wk.cl * EPC + i]; sh[i] = shift[wk.cl * EPC + i]; }
-  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
   for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
     const size_t off = (size_t)v * g.C + wk.cl * EPC;
     float o[EPC];
@@ -182,7 +196,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restric
   if (wk.live) {
 #pragma unroll
     for (int i = 0; i < EPC; ++i) { mu[i] = mean[wk.cl * EPC + i]; rs[i] = rstd[wk.cl * EPC + i]; }
-    const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+    const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
     for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
       const size_t off = (size_t)v * g.C + wk.cl * EPC;
       const bool a = g.active(v);
@@ -223,8 +237,9 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restric
 #pragma unroll
     for (int i = 0; i < EPC; ++i) {
       const int c = threadIdx.x * EPC + i;
-      atomicAdd(&bsum[c * 3], a1[i]); atomicAdd(&bsum[c * 3 + 1], a2[i]);
-      if (fill) atomicAdd(&bsum[c * 3 + 2], a3[i]);
+      double* br = bsum + (size_t)(blockIdx.x % NREP) * g.C * 3;
+      atomicAdd(&br[c * 3], a1[i]); atomicAdd(&br[c * 3 + 1], a2[i]);
+      if (fill) atomicAdd(&br[c * 3 + 2], a3[i]);
     }
   }
 }
@@ -236,13 +251,15 @@ __global__ void norm_bwd_finalize_kernel(const double* bsum, const double* count
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const double n = count_ptr ? count_ptr[0] : count_host;
+  double b1 = 0.0, b2 = 0.0, b3 = 0.0;
+  for (int r = 0; r < NREP; ++r) { const double* q = bsum + ((size_t)r * C + c) * 3; b1 += q[0]; b2 += q[1]; b3 += q[2]; }
   const float gr = gamma[c] * rstd[c];
   k0[c] = gr;                                  // dx = k0*dpre - k1 - k2*xhat
-  k1[c] = gr * (float)(bsum[3 * c] / n);
-  k2[c] = gr * (float)(bsum[3 * c + 1] / n);
-  if (dgamma) dgamma[c] += (float)bsum[3 * c + 1];
-  if (dbeta) dbeta[c] += (float)bsum[3 * c];
-  if (dtoken) dtoken[c] += (float)bsum[3 * c + 2];
+  k1[c] = gr * (float)(b1 / n);
+  k2[c] = gr * (float)(b2 / n);
+  if (dgamma) dgamma[c] += (float)b2;
+  if (dbeta) dbeta[c] += (float)b1;
+  if (dtoken) dtoken[c] += (float)b3;
 }
 
 // ------------------------------------------------------------------ backward: apply
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
     const int c = wk.cl * EPC + i;
     mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c];
   }
-  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
   for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
     if (!g.active(v)) continue;
     const size_t off = (size_t)v * g.C + wk.cl * EPC;
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, 
   float s1[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) s1[i] = 0.f;
-  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
   if (wk.live)
     for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
       if (!g.active(v)) continue;
@@ -343,9 +360,10 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
   __syncthreads();
   Walk<T> wk(g.C);
   if (!wk.live) return;
-  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+  const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
   for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
-    const int ww = v % g.W; long t = v / g.W; const int hh = t % g.H; t /= g.H; const int dd = t % g.D; const int b = t / g.D;
+    int b, dd, hh, ww;
+    g.decode(v, b, dd, hh, ww);
     if (!g.mask.active(b, dd, hh, ww)) continue;
     float o[EPC];
 #pragma unroll
@@ -374,7 +392,7 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
   __syncthreads();
   Walk<T> wk(g.C);
   if (wk.live) {
-    const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, g.nvox());
+    const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
     for (int tg = 0; tg < nt; tg += 9) {                     // 9 taps at a time keeps the accumulators in registers
       float a[9][EPC], sb[EPC];
 #pragma unroll
@@ -384,7 +402,8 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
 #pragma unroll
       for (int i = 0; i < EPC; ++i) sb[i] = 0.f;
       for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
-        const int ww = v % g.W; long t = v / g.W; const int hh = t % g.H; t /= g.H; const int dd = t % g.D; const int b = t / g.D;
+        int b, dd, hh, ww;
+        g.decode(v, b, dd, hh, ww);
         if (!g.mask.active(b, dd, hh, ww)) continue;
         float d[EPC];
         chunk_to_f<T>(*(const u32x4*)(dy + (size_t)v * g.C + wk.cl * EPC), d);
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(const T* __restrict__ x, 
 
 // dx[v][c] = drec[v]*w[c];  dw[c] += sum_v drec[v]*x[v][c];  db += sum_v drec[v]
 template <typename T>
-__global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, const float* __restrict__ drec, long nvox, int C,
+__global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, const float* __restrict__ drec, long nvox, int C, int vpw,
                                                        const float* __restrict__ w, T* __restrict__ dx, float* __restrict__ dw,
                                                        float* __restrict__ db) {
   constexpr int EPC = TT<T>::EPC;
@@ -453,7 +472,7 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, 
   float sw[EPC], wv[EPC], sb = 0.f;
 #pragma unroll
   for (int i = 0; i < EPC; ++i) { sw[i] = 0.f; wv[i] = wk.live ? w[wk.cl * EPC + i] : 0.f; }
-  const long v0 = (long)blockIdx.x * VPW, v1 = min(v0 + VPW, nvox);
+  const long v0 = (long)blockIdx.x * vpw, v1 = min(v0 + (long)vpw, nvox);
   if (wk.live)
     for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
       const float d = drec[v];
@@ -528,9 +547,30 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __res
   }
 }
 
-inline int nblk(long nvox) { return (int)((nvox + VPW - 1) / VPW); }
-inline Geo mkgeo(int B, int D, int H, int W, int C, const uint8_t* mask, int bs, int fd, int fh, int fw) {
-  Geo g; g.B = B; g.D = D; g.H = H; g.W = W; g.C = C; g.mask = MaskView{mask, fd, fh, fw, bs}; return g;
+// voxels per workgroup: whole passes (256/(C/EPC) voxels each), ~2048 workgroups per launch (<= 1024 for reductions)
+inline int pick_vpw(long nvox, int C, int dtype, bool reduction) {
+  const int epc = dtype == AM_DT_BF16 ? 8 : 4;
+  int vpp = 256 / (C / epc); if (vpp < 1) vpp = 1;
+  const long target = reduction ? 1024 : 2048;
+  long v = (nvox + target - 1) / target;
+  v = (v + vpp - 1) / vpp * vpp;
+  if (v < vpp) v = vpp;
+  if (v > 65536) v = 65536;
+  return (int)v;
+}
+inline int nblk(long nvox, int vpw) { return (int)((nvox + vpw - 1) / vpw); }
+inline Geo mkgeo(int dtype, bool reduction, int B, int D, int H, int W, int C, const uint8_t* mask, int bs, int fd, int fh, int fw) {
+  Geo g; g.B = B; g.D = D; g.H = H; g.W = W; g.C = C; g.mask = MaskView{mask, fd, fh, fw, bs};
+  g.vpw = pick_vpw((long)B * D * H * W, C, dtype, reduction);
+  g.mW = (unsigned)(0x100000000ull / (unsigned)W) + 1; g.mH = (unsigned)(0x100000000ull / (unsigned)H) + 1;
+  g.mD = (unsigned)(0x100000000ull / (unsigned)D) + 1;
+  return g;
+}
+// the reciprocal-multiply decode is exact while v*d < 2^32
+inline bool geo_ok(int B, int D, int H, int W) {
+  const unsigned long long n = (unsigned long long)B * D * H * W;
+  int m = W > H ? W : H; if (D > m) m = D;
+  return n * (unsigned long long)m < 0xffffffffull;
 }
 
 }  // namespace
@@ -543,10 +583,11 @@ extern "C" {
 int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                   int fw, double* sums, void* stream) {
   CHK_C(C);
-  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
+  if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
-  const int nb = nblk((long)B * D * H * W);
+  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * NREP, st);
+  const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype, AM_LAUNCH(chan_stats_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, sums),
              AM_LAUNCH(chan_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, sums));
   AM_CHECK_LAUNCH();
@@ -559,10 +600,10 @@ int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out,
   return 0;
 }
 
-int am_norm_finalize(const double* sums, const double* count_ptr, double count_host, int C, const float* gamma,
+int am_norm_finalize(const double* sums, int nrep, const double* count_ptr, double count_host, int C, const float* gamma,
                      const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift, float* run_mean,
                      float* run_var, float momentum, void* stream) {
-  AM_LAUNCH(norm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, count_ptr, count_host,
+  AM_LAUNCH(norm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, nrep, count_ptr, count_host,
                      C, gamma, beta, eps, mean, rstd, scale, shift, run_mean, run_var, momentum);
   AM_CHECK_LAUNCH();
   return 0;
@@ -580,9 +621,10 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
                   int fw, const float* scale, const float* shift, int act, const void* res, const float* stem_x,
                   const float* stem_w, const float* stem_b, const float* fill, void* y, void* stream) {
   CHK_C(C);
-  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
+  if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W);
+  const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,
                                 (const float*)res, stem_x, stem_w, stem_b, fill, (float*)y),
@@ -596,10 +638,11 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
                        int fill, double* bsum, void* stream) {
   CHK_C(C);
-  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
+  if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C, st);
-  const int nb = nblk((long)B * D * H * W);
+  hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C * NREP, st);
+  const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
                                 (const float*)x, g, mean, rstd, act, fill, bsum),
@@ -622,9 +665,10 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, void* stream) {
   CHK_C(C);
-  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
+  if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W);
+  const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
                                 (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres),
@@ -637,9 +681,10 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
 int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                 int fw, float* out_accum, void* stream) {
   CHK_C(C);
-  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
+  if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W);
+  const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype, AM_LAUNCH(chan_sum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, out_accum),
              AM_LAUNCH(chan_sum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, out_accum));
   AM_CHECK_LAUNCH();
@@ -660,9 +705,10 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
                      int fd, int fh, int fw, const float* w, const float* bias, void* y, void* stream) {
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
-  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
+  if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W);
+  const int nb = nblk((long)B * D * H * W, g.vpw);
   const size_t sm = sizeof(float) * C * ksize * ksize * ksize;
   DISPATCH_T(dtype, AM_LAUNCH(stem_conv_fwd_kernel<float>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (float*)y),
              AM_LAUNCH(stem_conv_fwd_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (bf16_t*)y));
@@ -674,9 +720,10 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum, void* stream) {
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
-  Geo g = mkgeo(B, D, H, W, C, mask, bshift, fd, fh, fw);
+  Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
+  if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W);
+  const int nb = nblk((long)B * D * H * W, g.vpw);
   const size_t sm = sizeof(float) * C * (ksize * ksize * ksize + 1);
   DISPATCH_T(dtype,
              AM_LAUNCH(stem_conv_wgrad_kernel<float>, dim3(nb), dim3(256), sm, st, x, (const float*)dy, g, ksize, dw_accum, db_accum),
@@ -699,9 +746,10 @@ int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, c
                 float* db_accum, void* stream) {
   CHK_C(C);
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk(nvox);
-  DISPATCH_T(dtype, AM_LAUNCH(proj_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, drec, nvox, C, w, (float*)dx, dw_accum, db_accum),
-             AM_LAUNCH(proj_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, w, (bf16_t*)dx, dw_accum, db_accum));
+  const int vpw = pick_vpw(nvox, C, dtype, true);
+  const int nb = nblk(nvox, vpw);
+  DISPATCH_T(dtype, AM_LAUNCH(proj_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, drec, nvox, C, vpw, w, (float*)dx, dw_accum, db_accum),
+             AM_LAUNCH(proj_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, vpw, w, (bf16_t*)dx, dw_accum, db_accum));
   AM_CHECK_LAUNCH();
   return 0;
 }

@@ -79,6 +79,7 @@ def _sparse_norm(x, mask, bs, counts, gamma, beta, eps, part=None) -> NormStats:
     st.count_ptr = counts[bs]
     if part is not None:
         part.reduce(sums=st.sums)
+        st.nrep = 1
     else:
         ops.chan_stats(x, mask, bs, st)
     ops.norm_finalize(st, gamma, beta, eps)
@@ -91,6 +92,7 @@ def _batch_norm(x, W, prefix, train: bool, part=None) -> NormStats:
         st.count_host = float(x.numel() // x.shape[-1])
         if part is not None:
             part.reduce(sums=st.sums)
+            st.nrep = 1
         else:
             ops.chan_stats(x, None, 0, st)
         ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"],

@@ -158,11 +158,15 @@ def stem_conv_wgrad(x_b1: torch.Tensor, dy: torch.Tensor, ksize: int, mask: Opti
 
 
 # ------------------------------------------------------------------ norms
+NREP = 8   # AM_NREP
+
+
 class NormStats:
     """Per-channel statistics + folded coefficients of one norm instance (all fp32, length C)."""
 
     def __init__(self, C: int, device):
-        self.sums = torch.empty(C, 2, device=device, dtype=torch.float64)
+        self.sums = torch.empty(NREP, C, 2, device=device, dtype=torch.float64)
+        self.nrep = NREP
         self.buf = torch.empty(4, C, device=device, dtype=torch.float32)
         self.mean, self.rstd, self.scale, self.shift = self.buf[0], self.buf[1], self.buf[2], self.buf[3]
         self.count_ptr: Optional[torch.Tensor] = None
@@ -173,6 +177,7 @@ def chan_stats(x: torch.Tensor, mask: Optional[MaskInfo], bshift: int, st: NormS
     B, D, H, W, Cc = x.shape
     mp, fd, fh, fw = _mk(mask)
     hip.lib().chan_stats(_dt(x), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw, st.sums.data_ptr(), _stream())
+    st.nrep = NREP
 
 
 def mask_count(mask: MaskInfo, voxels_per_patch: int, out: torch.Tensor):
@@ -182,7 +187,7 @@ def mask_count(mask: MaskInfo, voxels_per_patch: int, out: torch.Tensor):
 def norm_finalize(st: NormStats, gamma: torch.Tensor, beta: torch.Tensor, eps: float,
                   run_mean: Optional[torch.Tensor] = None, run_var: Optional[torch.Tensor] = None, momentum: float = 0.1):
     Cc = gamma.numel()
-    hip.lib().norm_finalize(st.sums.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), beta.data_ptr(),
+    hip.lib().norm_finalize(st.sums.data_ptr(), st.nrep, _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), beta.data_ptr(),
                             eps, st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
                             _p(run_mean), _p(run_var), momentum, _stream())
 
@@ -207,7 +212,7 @@ def norm_apply(x: torch.Tensor, st: NormStats, act: int, mask: Optional[MaskInfo
 
 class NormBwdScratch:
     def __init__(self, C: int, device):
-        self.bsum = torch.empty(C, 3, device=device, dtype=torch.float64)
+        self.bsum = torch.empty(NREP, C, 3, device=device, dtype=torch.float64)
         self.k = torch.empty(3, C, device=device, dtype=torch.float32)
 
 

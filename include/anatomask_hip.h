@@ -32,6 +32,8 @@ extern "C" {
 #define AM_CONVT_FWD 2    /* y[o]  = sum_t x[(o + 1 - t)/2] W_t             (ConvTranspose3d k4 s2 p1)       */
 #define AM_CONVT_DGRAD 3  /* dx[i] = sum_t dy[2i - 1 + t] W_t^T                                              */
 
+#define AM_NREP 8        /* replicated reduction accumulators (spread atomic contention), summed by the finalize kernels */
+
 #define AM_ACT_NONE 0
 #define AM_ACT_LRELU 1    /* LeakyReLU(0.01)  P/STUNet_head.py:84,89 */
 #define AM_ACT_RELU6 2    /* ReLU6            P/decoder3D.py:21      */
@@ -77,9 +79,9 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
 /* Pooled sparse InstanceNorm (P/encoder3D.py:138-165: statistics over ALL active voxels of the local
  * batch) and BatchNorm3d (P/decoder3D.py:21-22) share these: stats -> finalize -> apply. */
 int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
-                  int fw, double* sums /* [C][2], zeroed inside */, void* stream);
+                  int fw, double* sums /* [AM_NREP][C][2] replicated accumulators, zeroed inside */, void* stream);
 int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out, void* stream);
-int am_norm_finalize(const double* sums, const double* count_ptr, double count_host, int C, const float* gamma,
+int am_norm_finalize(const double* sums, int nrep /* AM_NREP after am_chan_stats, 1 after am_partials_reduce */, const double* count_ptr, double count_host, int C, const float* gamma,
                      const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                      float* run_mean /* NULL or BN running stats, updated */, float* run_var, float momentum, void* stream);
 int am_norm_fold_running(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
@@ -92,7 +94,7 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
 /* backward: bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout}, dpre = dout*act'(out) */
 int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
-                       int fill, double* bsum /* [C][3], zeroed inside */, void* stream);
+                       int fill, double* bsum /* [AM_NREP][C][3], zeroed inside */, void* stream);
 int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
                          const float* rstd, float* k0, float* k1, float* k2, float* dgamma_accum, float* dbeta_accum,
                          float* dtoken_accum, void* stream);
