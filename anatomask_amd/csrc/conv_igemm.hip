@@ -395,11 +395,17 @@ extern "C" int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int*
   return 0;
 }
 
-extern "C" int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int* rows) {
+extern "C" int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout, int* rows) {
   const int os = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
   const int qd = (Do + os - 1) / os, qh = (Ho + os - 1) / os, qw = (Wo + os - 1) / os;
   int bd, bh, bw;
-  brick_shape(mode, stride, qw, &bd, &bh, &bw);
+  const int shape0 = brick_shape(mode, stride, qw, &bd, &bh, &bw);
+  {
+    const int tile = Cout <= 32 ? 32 : 64;
+    const long q = (long)qd * qh * qw;
+    const long nwg = (long)B * ((q + bd * bh * bw - 1) / (bd * bh * bw)) * ((Cout + tile - 1) / tile) * (os == 2 ? 8 : 1);
+    if (nwg < 256 && shape0 != 2) { bh = 4; bw = 4; }
+  }
   *rows = B * ((qd + bd - 1) / bd) * ((qh + bh - 1) / bh) * ((qw + bw - 1) / bw) * (os == 2 ? 8 : 1);
   (void)ksize;
   return 0;
@@ -413,8 +419,15 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   Plan P;
   ConvArgs& a = P.a;
   const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
-  const int shape = brick_shape(mode, stride, (Wo + os_ - 1) / os_, &P.bd, &P.bh, &P.bw);
+  int shape = brick_shape(mode, stride, (Wo + os_ - 1) / os_, &P.bd, &P.bh, &P.bw);
   P.nt_tile = Cout <= 32 ? 32 : 64;
+  {  // deep levels (8^3..16^3 grids, 256-512 channels): the default tiling gives a few dozen workgroups that each walk
+     // 16 channel slabs serially while 90 % of the chip idles -> 64-voxel bricks x 32 channels = 8x more workgroups
+    const long q = (long)((Do + os_ - 1) / os_) * ((Ho + os_ - 1) / os_) * ((Wo + os_ - 1) / os_);
+    const long nwg = (long)B * ((q + P.bd * P.bh * P.bw - 1) / (P.bd * P.bh * P.bw)) * ((Cout + P.nt_tile - 1) / P.nt_tile) * (os_ == 2 ? 8 : 1);
+    if (nwg < 256 && shape != 2) { shape = 2; P.bh = 4; P.bw = 4; P.nt_tile = 32; }
+    else if (nwg < 256) P.nt_tile = 32;
+  }
   int rc = build_plan(P, mode, ksize, stride);
   if (rc) return rc;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restric
 // per-channel coefficients of the apply pass + parameter gradients (accumulated into fp32 grads)
 __global__ void norm_bwd_finalize_kernel(const double* bsum, const double* count_ptr, double count_host, int C,
                                          const float* gamma, const float* rstd, float* k0, float* k1, float* k2,
-                                         float* dgamma, float* dbeta, float* dtoken) {
+                                         float* dgamma, float* dbeta, float* dtoken, float* dbeta2) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   const double n = count_ptr ? count_ptr[0] : count_host;
@@ -259,6 +259,7 @@ __global__ void norm_bwd_finalize_kernel(const double* bsum, const double* count
   k2[c] = gr * (float)(b2 / n);
   if (dgamma) dgamma[c] += (float)b2;
   if (dbeta) dbeta[c] += (float)b1;
+  if (dbeta2) dbeta2[c] += (float)b1;             // bias of a conv added AFTER the norm (1x1 shortcut): same sum
   if (dtoken) dtoken[c] += (float)b3;
 }
 
@@ -269,34 +270,58 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ k0,
                                                              const float* __restrict__ k1, const float* __restrict__ k2, int act,
-                                                             T* __restrict__ dx, T* __restrict__ dres) {
+                                                             T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum) {
   constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 8];
   Walk<T> wk(g.C);
-  if (!wk.live) return;
-  float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC];
+  float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC], sx[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) {
     const int c = wk.cl * EPC + i;
-    mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c];
+    sx[i] = 0.f;
+    if (wk.live) { mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c]; }
   }
   const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
-  for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
-    if (!g.active(v)) continue;
-    const size_t off = (size_t)v * g.C + wk.cl * EPC;
-    float d[EPC], f[EPC];
-    chunk_to_f<T>(*(const u32x4*)(dout + off), d);
-    chunk_to_f<T>(*(const u32x4*)(x + off), f);
-    if (act != AM_ACT_NONE) {
-      float o[EPC];
-      chunk_to_f<T>(*(const u32x4*)(out + off), o);
+  if (wk.live)
+    for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+      if (!g.active(v)) continue;
+      const size_t off = (size_t)v * g.C + wk.cl * EPC;
+      float d[EPC], f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(dout + off), d);
+      chunk_to_f<T>(*(const u32x4*)(x + off), f);
+      if (act != AM_ACT_NONE) {
+        float o[EPC];
+        chunk_to_f<T>(*(const u32x4*)(out + off), o);
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+        for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+      }
+      if (dres) *(u32x4*)(dres + off) = f_to_chunk<T>(d);
+      float r[EPC];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) r[i] = c0[i] * d[i] - c1[i] - c2[i] * (f[i] - mu[i]) * rs[i];
+      const u32x4 pk = f_to_chunk<T>(r);
+      *(u32x4*)(dx + off) = pk;
+      if (dxsum) {                                 // bias gradient of the conv that feeds this norm = sum of the STORED dx
+        float q[EPC];
+        chunk_to_f<T>(pk, q);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) sx[i] += q[i];
+      }
     }
-    if (dres) *(u32x4*)(dres + off) = f_to_chunk<T>(d);
-    float r[EPC];
+  if (dxsum) {                                     // (uniform) fold voxel lanes, one float atomic per channel per workgroup
 #pragma unroll
-    for (int i = 0; i < EPC; ++i) r[i] = c0[i] * d[i] - c1[i] - c2[i] * (f[i] - mu[i]) * rs[i];
-    *(u32x4*)(dx + off) = f_to_chunk<T>(r);
+    for (int i = 0; i < EPC; ++i) red[threadIdx.x * 8 + i] = sx[i];
+    __syncthreads();
+    if (threadIdx.x < wk.cpv) {
+      float a1[EPC];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) a1[i] = 0.f;
+      for (int vl = 0; vl < wk.vpp; ++vl)
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[threadIdx.x * EPC + i], a1[i]);
+    }
   }
 }
 
@@ -504,14 +529,33 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, 
 
 // ------------------------------------------------------------------ weight (un)packing
 // dst[t][r][k] = src[r*sr + k*sk + t] for r < R, k < K, zero in the padding (dst is [taps][Rp][Kp])
-// (fp32 master -> compute dtype, MFMA row-fragment layout, whole tiles so the conv inner loop needs no bounds)
+// (fp32 master -> compute dtype, MFMA row-fragment layout, whole tiles so the conv inner loop needs no bounds).
+// One workgroup per (row r, 64 consecutive k): when taps are innermost in the source (sk == taps, the forward
+// pack) the 64*taps source floats are one contiguous run -> coalesced read, LDS transpose, coalesced 128-byte row writes.
 template <typename T>
-__global__ void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int K, int taps, long sr, long sk,
-                                   int Rp, int Kp) {
-  const long n = (long)taps * Rp * Kp;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int k = i % Kp; long t = i / Kp; const int r = t % Rp; const int tp = t / Rp;
-    TT<T>::st(dst + i, (r < R && k < K) ? src[r * sr + k * sk + tp] : 0.f);
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int K, int taps,
+                                                          long sr, long sk, int Rp, int Kp) {
+  extern __shared__ float tile[];                          // [64][taps]
+  const int r = blockIdx.x, k0 = blockIdx.y * 64;
+  const int n = 64 * taps;
+  if (r < R) {
+    if (sk == taps) {
+      const float* base = src + r * sr + (long)k0 * taps;
+      const int lim = (K - k0 < 64 ? (K - k0 > 0 ? K - k0 : 0) : 64) * taps;
+      for (int i = threadIdx.x; i < n; i += 256) tile[i] = i < lim ? base[i] : 0.f;
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) {         // taps are innermost in every torch conv weight: runs of `taps` floats
+        const int kk = i / taps, tp = i - kk * taps;
+        tile[i] = (k0 + kk < K) ? src[r * sr + (long)(k0 + kk) * sk + tp] : 0.f;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) tile[i] = 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int kk = i % 64, tp = i / 64;
+    if (k0 + kk < Kp) TT<T>::st(dst + ((size_t)tp * Rp + r) * Kp + k0 + kk, tile[kk * taps + tp]);
   }
 }
 // dst[r*sr + k*sk + t] (+)= src[t][r][k]
@@ -654,16 +698,17 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
 
 int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
                          const float* rstd, float* k0, float* k1, float* k2, float* dgamma, float* dbeta, float* dtoken,
-                         void* stream) {
+                         float* dbeta2, void* stream) {
   AM_LAUNCH(norm_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, bsum, count_ptr,
-                     count_host, C, gamma, rstd, k0, k1, k2, dgamma, dbeta, dtoken);
+                     count_host, C, gamma, rstd, k0, k1, k2, dgamma, dbeta, dtoken, dbeta2);
   AM_CHECK_LAUNCH();
   return 0;
 }
 
 int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
-                      const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, void* stream) {
+                      const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, float* dxsum_accum,
+                      void* stream) {
   CHK_C(C);
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
@@ -671,9 +716,9 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres),
+                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxsum_accum),
              AM_LAUNCH(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres));
+                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxsum_accum));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -764,10 +809,10 @@ int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int tap
                    void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (Rp < R || Kp < K) return -1;
-  const long n = (long)taps * Rp * Kp;
-  int nb = (int)((n + 255) / 256); if (nb > 8192) nb = 8192;
-  DISPATCH_T(dtype, AM_LAUNCH(pack_weight_kernel<float>, dim3(nb), dim3(256), 0, st, src, (float*)dst, R, K, taps, stride_r, stride_k, Rp, Kp),
-             AM_LAUNCH(pack_weight_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k, Rp, Kp));
+  dim3 grid(Rp, (Kp + 63) / 64);
+  const size_t sm = sizeof(float) * 64 * taps;
+  DISPATCH_T(dtype, AM_LAUNCH(pack_weight_kernel<float>, grid, dim3(256), sm, st, src, (float*)dst, R, K, taps, stride_r, stride_k, Rp, Kp),
+             AM_LAUNCH(pack_weight_kernel<bf16_t>, grid, dim3(256), sm, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k, Rp, Kp));
   AM_CHECK_LAUNCH();
   return 0;
 }

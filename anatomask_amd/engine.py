@@ -285,20 +285,20 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
             p = t["p"]
             y2, a1, y1, out, x = t["y2"], t["a1"], t["y1"], t["out"], t["x"]
             dpre = torch.empty_like(y2)                      # gradient of the shortcut branch
+            # conv2.bias gradient = sum of dy2 (folded into the apply pass); conv3.bias gradient = sum of dpre = norm2's dbeta
             dy2 = ops.norm_backward(gout, out, y2, t["st2"], W[f"{p}.norm2.weight"], ACT_LRELU, mask, bs,
-                                    G[f"{p}.norm2.weight"], G[f"{p}.norm2.bias"], dres=dpre)
+                                    G[f"{p}.norm2.weight"], G[f"{p}.norm2.bias"], dres=dpre,
+                                    dbeta2=G.get(f"{p}.conv3.bias"), dxsum=G[f"{p}.conv2.bias"])
             sp = tuple(y2.shape[1:4])
             da1 = ops.conv3d(CONV_DGRAD, dy2, pk.get(W, f"{p}.conv2.weight", False, True), None, sp, 3, 1,
                              in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
             _wgrad_into(G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
-            ops.chan_sum(dy2, mask, bs, G[f"{p}.conv2.bias"])
             dy1 = ops.norm_backward(da1, a1, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
-                                    G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"])
-            ops.chan_sum(dy1, mask, bs, G[f"{p}.conv1.bias"])
+                                    G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"])
             stride = t["stride"]
             if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only
                 ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None)
-                ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), G[f"{p}.conv3.bias"])
+                ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), None)
                 break
             bsx = bs + (1 if stride == 2 else 0)
             spx = tuple(x.shape[1:4])
@@ -309,7 +309,6 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
                 gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, stride,
                                 in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=base, accumulate=base is not None)
                 _wgrad_into(G, f"{p}.conv3.weight", CONV_FWD, x, dpre, 1, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
-                ops.chan_sum(dpre, mask, bs, G[f"{p}.conv3.bias"])
                 ops.conv3d(CONV_DGRAD, dpre, pk.get(W, f"{p}.conv3.weight", False, True), None, spx, 1, stride,
                            in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=gx, accumulate=True)
                 gstage[s - 1] = gx

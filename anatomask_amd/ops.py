@@ -61,7 +61,7 @@ class ConvPartials:
     def __init__(self, mode, ksize, stride, B, out_spatial, cout, device):
         import ctypes
         n = ctypes.c_int(0)
-        hip.lib().conv3d_partials_rows(mode, ksize, stride, B, *out_spatial, ctypes.addressof(n))
+        hip.lib().conv3d_partials_rows(mode, ksize, stride, B, *out_spatial, cout, ctypes.addressof(n))
         self.rows, self.C = n.value, cout
         self.t = torch.empty(self.rows, cout, 2, device=device, dtype=torch.float32)
 
@@ -219,7 +219,8 @@ class NormBwdScratch:
 def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tensor, st: NormStats, gamma: torch.Tensor, act: int,
                   mask: Optional[MaskInfo], bshift: int, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
                   dtoken: Optional[torch.Tensor] = None, fill: bool = False, dx: Optional[torch.Tensor] = None,
-                  dres: Optional[torch.Tensor] = None, scratch: Optional[NormBwdScratch] = None) -> torch.Tensor:
+                  dres: Optional[torch.Tensor] = None, scratch: Optional[NormBwdScratch] = None,
+                  dbeta2: Optional[torch.Tensor] = None, dxsum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Backward of y = act(norm(x) [+res]) (or the densify fill).  Returns dx; accumulates dgamma/dbeta/dtoken."""
     B, D, H, W, Cc = x.shape
     sc = scratch or NormBwdScratch(Cc, x.device)
@@ -229,12 +230,12 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
     L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                       st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), sc.bsum.data_ptr(), s)
     L.norm_bwd_finalize(sc.bsum.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
-                        sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), s)
+                        sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
     if dx is None:
         dx = torch.empty_like(x)
     L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                      st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
-                     dx.data_ptr(), _p(dres), s)
+                     dx.data_ptr(), _p(dres), _p(dxsum), s)
     return dx
 
 

@@ -50,7 +50,7 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               int accumulate, float* partials /* NULL or [am_conv3d_partials_rows][Cout][2]: per-workgroup sum / sum-of-squares
               of the written outputs, feeds the following norm (or a bias gradient) without another pass */, void* stream);
 int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded);
-int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int* rows);
+int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout, int* rows);
 /* partials [rows][C][2] -> sums[C][2] (double, overwritten; may be NULL) and/or sum_accum[C] += sum (may be NULL) */
 int am_partials_reduce(const float* partials, int rows, int C, double* sums, float* sum_accum, void* stream);
 
@@ -97,10 +97,11 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
                        int fill, double* bsum /* [AM_NREP][C][3], zeroed inside */, void* stream);
 int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
                          const float* rstd, float* k0, float* k1, float* k2, float* dgamma_accum, float* dbeta_accum,
-                         float* dtoken_accum, void* stream);
+                         float* dtoken_accum, float* dbeta2_accum /* bias of a conv added after the norm: same sum */, void* stream);
 int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
-                      const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, void* stream);
+                      const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres,
+                      float* dxsum_accum /* NULL or += per-channel sum of dx: bias gradient of the conv feeding the norm */, void* stream);
 int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                 int fw, float* out_accum, void* stream);   /* conv bias gradients */
 int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream);   /* x + to_dec[i], P/decoder3D.py:59 */
