@@ -43,8 +43,12 @@ class AnatoMaskTrainer:
         if self.distributed:                      # DDP start-up broadcast (P/pretrain_AnatoMask_DDP.py:239-240)
             dist.broadcast(model._flat, 0, group=process_group)
             self.teacher.ema._flat.copy_(model._flat)
-        o = model._offs
-        names = model._pnames
+        self._build_ranges()
+
+    def _build_ranges(self):
+        """Flat-buffer ranges of the parameter groups in the order backward finishes them (gradient buckets)."""
+        model = self.model
+        o, names, n = model._offs, model._pnames, model._live_end
         first_dec = next(k for k in names if k.startswith("dense_decoder."))
         first_dens = next(k for k in names if k.startswith("densify_norms.") and k not in model._dead)
         self._ranges: Dict[str, tuple] = {"decoder": (o[first_dec], o[first_dens]), "densify": (o[first_dens], n)}
