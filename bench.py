@@ -82,7 +82,7 @@ def cpu_baseline(state_dict_cpu, spec_kw):
     """The CPU oracle (port of the reference step, pinned against it by tests/golden) on the host cores:
     ONE full AnatoMask step of the same workload at B=1 (teacher fwd + sampler + student fwd/bwd + clip + AdamW + EMA)."""
     from oracle import anatomask_oracle as O
-    n = os.cpu_count() or 1
+    n = min(32, os.cpu_count() or 1)      # measured on the MI355X host: 8/16/32/64 threads -> 5.4/4.8/4.1/5.8 s per forward; 256 oversubscribes 10x
     torch.set_num_threads(n)
     cfg = O.Config(spec_kw["dims"], spec_kw["depth"], spec_kw["width"], (128, 128, 128), 0.6)
     st = O.StepState(cfg, state_dict_cpu)
