@@ -37,12 +37,14 @@ struct ConvArgs {
   int mind[8], minh[8], minw[8];
   int ed[8], eh[8], ew[8];    // LDS source-brick extents per class
   int mdiv_w[8], mdiv_hw[8];  // 2^20-scaled reciprocals of ew and ew*eh (exact floor division for e < 1024)
+  int w_bytes;                // size of the packed weight buffer
   int w_lds_off, tap_lds_off; // byte offsets of the weight-group buffers / tap table inside dynamic LDS
   MaskView in_mask, out_mask;
   int accumulate;
 };
 
 constexpr int ROWB = 64;      // channel-slab bytes staged per voxel / per weight row (unpadded, XOR-swizzled)
+constexpr int LROWB = 80;     // LDS row stride of the source brick (16 B pad; B-fragment address = lane const + scalar tap offset)
 constexpr int TG = 3;         // taps per weight group staged in LDS
 
 // LDS image of a [rows][64 B] tile: 16-byte chunk c of row r lives at r*64 + ((c ^ 2*bit2(r)) * 16).
@@ -96,48 +98,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int tb = a.tap_begin[cls], nt = a.tap_begin[cls + 1] - tb;
   const int ng = (nt + TG - 1) / TG;
 
-  // tap table -> LDS: voxel offset of the tap's window inside the brick | weight slice index << 20
+  // tap table -> LDS: byte offset of the tap's window inside the (80-byte-row) brick | weight slice index << 20
   if (tid < nt) {
     const int tp = a.taps[tb + tid];
     const int sd = (tp & 15) - 8, sh = ((tp >> 4) & 15) - 8, sw = ((tp >> 8) & 15) - 8;
-    ldsTap[tid] = (((sd - a.mind[cls]) * EH + (sh - a.minh[cls])) * EW + (sw - a.minw[cls])) | ((tp >> 12) << 20);
+    ldsTap[tid] = ((((sd - a.mind[cls]) * EH + (sh - a.minh[cls])) * EW + (sw - a.minw[cls])) * LROWB) | ((tp >> 12) << 20);
   }
 
-  // ---- per-thread staging plan for the source brick (branch-free: clamped address + zero select) ----
-  int svox[NIT];
-  unsigned sval = 0;
+  // Buffer descriptors (wave-uniform): loads take a per-lane 32-bit byte offset + an SGPR offset, so the slab / tap
+  // advance costs no vector instruction, and any offset >= num_records reads back as zero -- the hardware does the
+  // zero-fill of halo voxels that are out of range or belong to inactive patches (sentinel offset 0x80000000).
+  const size_t sample_elems = (size_t)a.Di * a.Hi * a.Wi * a.Cin;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.x + (size_t)b * sample_elems), 0,
+                                                                      (int)(sample_elems * sizeof(T)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+
+  // ---- per-thread staging plan for the source brick: byte offset of this thread's 16-byte chunk in each of its rows ----
+  unsigned soff[NIT];
   const int mW = a.mdiv_w[cls], mHW = a.mdiv_hw[cls], EHW = EH * EW;
+  const int cchunk = (tid & 3) * EPC;                    // this thread's channel offset inside the slab
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
-    svox[it] = 0;
+    soff[it] = OOB;
     const int e = (tid + it * 256) >> 2;
     if (e < nvox) {
       const int ez = (e * mHW) >> 20, rem = e - ez * EHW;       // runtime extents: reciprocal multiply instead of
       const int ey = (rem * mW) >> 20, ex = rem - ey * EW;       // ~35-instruction integer divisions
       const int id = i0d + ez, ih = i0h + ey, iw = i0w + ex;
-      if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw)) {
-        svox[it] = ((b * a.Di + id) * a.Hi + ih) * a.Wi + iw;
-        sval |= 1u << it;
-      }
+      if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw))
+        soff[it] = (unsigned)((((id * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T));
     }
   }
+  const int sdst = (tid >> 2) * LROWB + (tid & 3) * 16;  // LDS byte offset of iteration 0; iteration it adds it*64*LROWB (immediate)
   // ---- per-thread staging plan for the weight groups: chunk idx -> (tap in group [wave-uniform], cout row, chunk) ----
-  int wsrc[WIT], wdst[WIT];
+  unsigned wsrc[WIT];
+  int wdst[WIT];
 #pragma unroll
   for (int it = 0; it < WIT; ++it) {
     const int idx = tid + it * 256;
     const int row = (idx >> 2) % NT, tig = idx / (NT * 4);
-    wsrc[it] = (co0 + row) * a.Cinp + (idx & 3) * EPC;
+    wsrc[it] = (unsigned)(((co0 + row) * a.Cinp + (idx & 3) * EPC) * (int)sizeof(T));
     wdst[it] = idx < WCH ? tig * NT * ROWB + swz(row, idx & 3) : -1;
   }
 
   // ---- per-lane fragment bases ----
-  int vbv[VS];                                           // LDS voxel row of this lane's voxel, tap shift excluded
+  int bb[VS];                                            // LDS byte offset of this lane's voxel-row chunk, tap shift excluded
 #pragma unroll
   for (int j = 0; j < VS; ++j) {
     const int v = wave * (MV / 4) + j * 16 + r16;
     const int lw = v % BW, lh = (v / BW) % BH, ld = v / (BW * BH);
-    vbv[j] = ((ld * a.IS) * EH + lh * a.IS) * EW + lw * a.IS;
+    bb[j] = (((ld * a.IS) * EH + lh * a.IS) * EW + lw * a.IS) * LROWB + g * 16;
   }
   int aoff[NS];                                          // swizzled LDS offset of this lane's weight row chunk (tap 0 of a group)
 #pragma unroll
@@ -148,18 +159,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < VS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const T* __restrict__ xg = (const T*)a.x;
-  const T* __restrict__ wg = (const T*)a.w;
-  const int cchunk = (tid & 3) * EPC;                    // this thread's channel offset inside the slab when staging
-  const size_t wtap = (size_t)a.Coutp * a.Cinp;
-  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+  const int wtapB = a.Coutp * a.Cinp * (int)sizeof(T);   // bytes per weight tap slice
 
-  // issue the global loads of weight group GI (slab kc) into WR; the tap of a chunk is wave-uniform
+  // issue the loads of weight group GI (slab kc) into WR; the tap of a chunk is wave-uniform -> scalar offset
 #define AM_WLOAD(WR, GI)                                                                                   \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
     const int tt_ = (GI) * TG + (tid + it * 256) / (NT * 4);                                                \
     const int wi_ = __builtin_amdgcn_readfirstlane(ldsTap[tt_ < nt ? tt_ : nt - 1]) >> 20;                  \
-    WR[it] = *(const u32x4*)(wg + (size_t)wi_ * wtap + kc + wsrc[it]);                                      \
+    /* taps past the end of the class (last group of 8- or 64-tap classes) load zeros: out-of-range offset */ \
+    WR[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tt_ < nt ? wsrc[it] : OOB, wi_ * wtapB + kc * (int)sizeof(T), 0)); \
   }
 #define AM_WSTORE(WR, BUF)                                                                                 \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it)                                                        \
@@ -168,17 +176,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int kc = 0; kc < (nt > 0 ? a.Cinp : 0); kc += KC) {   // classes without taps (k1 s2 dgrad parities) write zeros
     __syncthreads();                                     // all fragment reads of the previous slab are done (tap table visible)
     {
-      const bool cok = kc + cchunk < a.Cin;
-      const int coff = cok ? kc + cchunk : 0;
+      const bool cok = kc + cchunk < a.Cin;                // only false in a partial last slab (Cin % KC != 0)
       u32x4 stg[NIT], wr0[WIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) stg[it] = *(const u32x4*)(xg + (size_t)svox[it] * a.Cin + coff);
+      for (int it = 0; it < NIT; ++it)
+        stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, cok ? soff[it] : OOB, kc * (int)sizeof(T), 0));
       AM_WLOAD(wr0, 0);
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + it * 256;
-        if ((idx >> 2) < nvox) *(u32x4*)(lds + swz(idx >> 2, idx & 3)) = (cok && ((sval >> it) & 1u)) ? stg[it] : zero4;
-      }
+      for (int it = 0; it < NIT; ++it)
+        if (((tid + it * 256) >> 2) < nvox) *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
       AM_WSTORE(wr0, 0);
     }
     __syncthreads();
@@ -186,22 +192,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       const int buf = gi & 1;
       u32x4 wr[WIT];
       const bool more = gi + 1 < ng;
-      if (more) { AM_WLOAD(wr, gi + 1); }                // next group's weights fly while this group's MFMAs issue
+      AM_WLOAD(wr, more ? gi + 1 : gi);                  // next group's weights fly while this group's MFMAs issue (branch-free:
+                                                         // a conditional load makes hipcc drain vmcnt at the join)
       __builtin_amdgcn_sched_barrier(0);
+      // straight-line over the TG taps of the group (padding taps multiply zero weights): no per-tap branch, so the
+      // fragment reads of tap t+1 can be scheduled under the MFMAs of tap t
 #pragma unroll
       for (int tl = 0; tl < TG; ++tl) {
-        if (gi * TG + tl < nt) {
-          const int tov = __builtin_amdgcn_readfirstlane(ldsTap[gi * TG + tl]) & 0xFFFFF;
-          u32x4 af[NS];
+        const int tt = gi * TG + tl;
+        const int tob = __builtin_amdgcn_readfirstlane(ldsTap[tt < nt ? tt : nt - 1]) & 0xFFFFF;
+        u32x4 af[NS];
 #pragma unroll
-          for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
+        for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
 #pragma unroll
-          for (int j = 0; j < VS; ++j) {
-            const int v = vbv[j] + tov;
-            const u32x4 bf = *(const u32x4*)(lds + (v << 6) + ((g << 4) ^ ((v & 4) << 3)));
+        for (int j = 0; j < VS; ++j) {
+          const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
-          }
+          for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +334,7 @@ int build_plan(Plan& P, int mode, int k, int stride) {
   size_t mxv = 0;
   for (int c = 0; c < a.nclass; ++c) { size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
   P.nit = (int)((mxv * (ROWB / 16) + 255) / 256);
-  size_t brick = mxv * ROWB;
+  size_t brick = mxv * LROWB;
   if (brick < 4096) brick = 4096;                        // the stats epilogue reuses the head of the brick
   a.w_lds_off = (int)brick;
   a.tap_lds_off = a.w_lds_off + 2 * TG * P.nt_tile * ROWB;
@@ -433,6 +440,8 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   am_packed_dims(dtype, Cout, Cin, &a.Coutp, &a.Cinp);
+  a.w_bytes = ksize * ksize * ksize * a.Coutp * a.Cinp * (dtype == AM_DT_BF16 ? 2 : 4);
+  if ((size_t)Di * Hi * Wi * Cin * 4 >= 0x7fffffffull) return -5;   // per-sample tensor must stay below 2 GB (32-bit buffer offsets)
   const int Qd = (Do + a.OS - 1) / a.OS, Qh = (Ho + a.OS - 1) / a.OS, Qw = (Wo + a.OS - 1) / a.OS;
   a.nbd = (Qd + P.bd - 1) / P.bd; a.nbh = (Qh + P.bh - 1) / P.bh; a.nbw = (Qw + P.bw - 1) / P.bw;
   a.in_mask = MaskView{in_mask, fd, fh, fw, in_bshift};
