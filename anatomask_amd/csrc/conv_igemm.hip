@@ -30,10 +30,13 @@ namespace {
 struct ConvArgs {
   const void* x; const void* w; const float* bias; void* y; float* partials;
   int B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, Cinp, Coutp;
-  int OS, IS, nclass;
+  int OS, GS, nclass, nunit;  // output stride (parity classes), global source stride, #classes (grid.z), #units
   int nbd, nbh, nbw;          // bricks per dim of the q grid
-  int tap_begin[9];
-  int taps[64];               // (sd+8) | (sh+8)<<4 | (sw+8)<<8 | widx<<12
+  int tap_begin[9];           // per unit.  A unit = one dense source sub-brick + the taps that read it:
+                              //   OS == 2 : unit = output parity class (one per workgroup, blockIdx.z)
+                              //   GS == 2 : unit = source parity sub-lattice (all units looped inside the workgroup)
+  int upar[8];                // source parity of the unit (pd<<2 | ph<<1 | pw), 0 unless GS == 2
+  int taps[64];               // (ud+8) | (uh+8)<<4 | (uw+8)<<8 | widx<<12 | unit<<18 ; u* = shift in sub-lattice voxels
   int mind[8], minh[8], minw[8];
   int ed[8], eh[8], ew[8];    // LDS source-brick extents per class
   int mdiv_w[8], mdiv_hw[8];  // 2^20-scaled reciprocals of ew and ew*eh (exact floor division for e < 1024)
@@ -92,17 +95,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
   }
 
-  const int ED = a.ed[cls], EH = a.eh[cls], EW = a.ew[cls];
-  const int nvox = ED * EH * EW;
-  const int i0d = q0d * a.IS + a.mind[cls], i0h = q0h * a.IS + a.minh[cls], i0w = q0w * a.IS + a.minw[cls];
-  const int tb = a.tap_begin[cls], nt = a.tap_begin[cls + 1] - tb;
-  const int ng = (nt + TG - 1) / TG;
+  const int u0 = a.OS == 2 ? cls : 0, u1 = a.OS == 2 ? cls + 1 : a.nunit;
 
-  // tap table -> LDS: byte offset of the tap's window inside the (80-byte-row) brick | weight slice index << 20
-  if (tid < nt) {
-    const int tp = a.taps[tb + tid];
-    const int sd = (tp & 15) - 8, sh = ((tp >> 4) & 15) - 8, sw = ((tp >> 8) & 15) - 8;
-    ldsTap[tid] = ((((sd - a.mind[cls]) * EH + (sh - a.minh[cls])) * EW + (sw - a.minw[cls])) * LROWB) | ((tp >> 12) << 20);
+  // tap table -> LDS (all units of this workgroup): byte offset of the tap's window inside its unit's brick | widx << 20
+  for (int t = a.tap_begin[u0] + tid; t < a.tap_begin[u1]; t += 256) {
+    const int tp = a.taps[t];
+    const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8, un = (tp >> 18) & 7;
+    ldsTap[t] = ((((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LROWB) | (((tp >> 12) & 63) << 20);
   }
 
   // Buffer descriptors (wave-uniform): loads take a per-lane 32-bit byte offset + an SGPR offset, so the slab / tap
@@ -113,24 +112,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                                                                       (int)(sample_elems * sizeof(T)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
-
-  // ---- per-thread staging plan for the source brick: byte offset of this thread's 16-byte chunk in each of its rows ----
-  unsigned soff[NIT];
-  const int mW = a.mdiv_w[cls], mHW = a.mdiv_hw[cls], EHW = EH * EW;
   const int cchunk = (tid & 3) * EPC;                    // this thread's channel offset inside the slab
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    soff[it] = OOB;
-    const int e = (tid + it * 256) >> 2;
-    if (e < nvox) {
-      const int ez = (e * mHW) >> 20, rem = e - ez * EHW;       // runtime extents: reciprocal multiply instead of
-      const int ey = (rem * mW) >> 20, ex = rem - ey * EW;       // ~35-instruction integer divisions
-      const int id = i0d + ez, ih = i0h + ey, iw = i0w + ex;
-      if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw))
-        soff[it] = (unsigned)((((id * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T));
-    }
-  }
   const int sdst = (tid >> 2) * LROWB + (tid & 3) * 16;  // LDS byte offset of iteration 0; iteration it adds it*64*LROWB (immediate)
+  const int wtapB = a.Coutp * a.Cinp * (int)sizeof(T);   // bytes per weight tap slice
+
   // ---- per-thread staging plan for the weight groups: chunk idx -> (tap in group [wave-uniform], cout row, chunk) ----
   unsigned wsrc[WIT];
   int wdst[WIT];
@@ -141,15 +126,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     wsrc[it] = (unsigned)(((co0 + row) * a.Cinp + (idx & 3) * EPC) * (int)sizeof(T));
     wdst[it] = idx < WCH ? tig * NT * ROWB + swz(row, idx & 3) : -1;
   }
-
-  // ---- per-lane fragment bases ----
-  int bb[VS];                                            // LDS byte offset of this lane's voxel-row chunk, tap shift excluded
-#pragma unroll
-  for (int j = 0; j < VS; ++j) {
-    const int v = wave * (MV / 4) + j * 16 + r16;
-    const int lw = v % BW, lh = (v / BW) % BH, ld = v / (BW * BH);
-    bb[j] = (((ld * a.IS) * EH + lh * a.IS) * EW + lw * a.IS) * LROWB + g * 16;
-  }
   int aoff[NS];                                          // swizzled LDS offset of this lane's weight row chunk (tap 0 of a group)
 #pragma unroll
   for (int i = 0; i < NS; ++i) aoff[i] = swz(i * 16 + r16, g);
@@ -159,61 +135,91 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < VS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int wtapB = a.Coutp * a.Cinp * (int)sizeof(T);   // bytes per weight tap slice
-
-  // issue the loads of weight group GI (slab kc) into WR; the tap of a chunk is wave-uniform -> scalar offset
+  // issue the loads of weight group GI (slab kc) into WR; the tap of a chunk is wave-uniform -> scalar offset.
+  // taps past the end of the unit (partial last group) load zeros through the out-of-range rule.
 #define AM_WLOAD(WR, GI)                                                                                   \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
     const int tt_ = (GI) * TG + (tid + it * 256) / (NT * 4);                                                \
-    const int wi_ = __builtin_amdgcn_readfirstlane(ldsTap[tt_ < nt ? tt_ : nt - 1]) >> 20;                  \
-    /* taps past the end of the class (last group of 8- or 64-tap classes) load zeros: out-of-range offset */ \
+    const int wi_ = __builtin_amdgcn_readfirstlane(ldsTap[tb + (tt_ < nt ? tt_ : nt - 1)]) >> 20;           \
     WR[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tt_ < nt ? wsrc[it] : OOB, wi_ * wtapB + kc * (int)sizeof(T), 0)); \
   }
 #define AM_WSTORE(WR, BUF)                                                                                 \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it)                                                        \
     if (wdst[it] >= 0) *(u32x4*)(ldsW + (BUF) * WBUF + wdst[it]) = WR[it];
 
-  for (int kc = 0; kc < (nt > 0 ? a.Cinp : 0); kc += KC) {   // classes without taps (k1 s2 dgrad parities) write zeros
-    __syncthreads();                                     // all fragment reads of the previous slab are done (tap table visible)
-    {
-      const bool cok = kc + cchunk < a.Cin;                // only false in a partial last slab (Cin % KC != 0)
-      u32x4 stg[NIT], wr0[WIT];
+  for (int un = u0; un < u1; ++un) {
+    const int tb = a.tap_begin[un], nt = a.tap_begin[un + 1] - tb;
+    if (nt == 0) continue;                               // (k1 s2 dgrad parities without taps write zeros)
+    const int ng = (nt + TG - 1) / TG;
+    const int ED = a.ed[un], EH = a.eh[un], EW = a.ew[un];
+    const int nvox = ED * EH * EW;
+    const int upd = (a.upar[un] >> 2) & 1, uph = (a.upar[un] >> 1) & 1, upw = a.upar[un] & 1;
+    const int i0d = q0d + a.mind[un], i0h = q0h + a.minh[un], i0w = q0w + a.minw[un];   // brick origin in sub-lattice voxels
+
+    // ---- per-thread staging plan for this unit's source brick: byte offset of this thread's chunk in each of its rows ----
+    unsigned soff[NIT];
+    const int mW = a.mdiv_w[un], mHW = a.mdiv_hw[un], EHW = EH * EW;
 #pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, cok ? soff[it] : OOB, kc * (int)sizeof(T), 0));
-      AM_WLOAD(wr0, 0);
-#pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        if (((tid + it * 256) >> 2) < nvox) *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
-      AM_WSTORE(wr0, 0);
-    }
-    __syncthreads();
-    for (int gi = 0; gi < ng; ++gi) {
-      const int buf = gi & 1;
-      u32x4 wr[WIT];
-      const bool more = gi + 1 < ng;
-      AM_WLOAD(wr, more ? gi + 1 : gi);                  // next group's weights fly while this group's MFMAs issue (branch-free:
-                                                         // a conditional load makes hipcc drain vmcnt at the join)
-      __builtin_amdgcn_sched_barrier(0);
-      // straight-line over the TG taps of the group (padding taps multiply zero weights): no per-tap branch, so the
-      // fragment reads of tap t+1 can be scheduled under the MFMAs of tap t
-#pragma unroll
-      for (int tl = 0; tl < TG; ++tl) {
-        const int tt = gi * TG + tl;
-        const int tob = __builtin_amdgcn_readfirstlane(ldsTap[tt < nt ? tt : nt - 1]) & 0xFFFFF;
-        u32x4 af[NS];
-#pragma unroll
-        for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
-#pragma unroll
-        for (int j = 0; j < VS; ++j) {
-          const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
-#pragma unroll
-          for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
-        }
+    for (int it = 0; it < NIT; ++it) {
+      soff[it] = OOB;
+      const int e = (tid + it * 256) >> 2;
+      if (e < nvox) {
+        const int ez = (e * mHW) >> 20, rem = e - ez * EHW;       // runtime extents: reciprocal multiply instead of
+        const int ey = (rem * mW) >> 20, ex = rem - ey * EW;       // ~35-instruction integer divisions
+        const int id = (i0d + ez) * a.GS + upd, ih = (i0h + ey) * a.GS + uph, iw = (i0w + ex) * a.GS + upw;
+        if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw))
+          soff[it] = (unsigned)((((id * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T));
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (more) { AM_WSTORE(wr, buf ^ 1); }
+    }
+    int bb[VS];                                          // LDS byte offset of this lane's voxel-row chunk, tap shift excluded
+#pragma unroll
+    for (int j = 0; j < VS; ++j) {
+      const int v = wave * (MV / 4) + j * 16 + r16;
+      bb[j] = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * LROWB + g * 16;
+    }
+
+    for (int kc = 0; kc < a.Cinp; kc += KC) {
+      __syncthreads();                                   // all fragment reads of the previous slab are done (tap table visible)
+      {
+        const bool cok = kc + cchunk < a.Cin;              // only false in a partial last slab (Cin % KC != 0)
+        u32x4 stg[NIT], wr0[WIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, cok ? soff[it] : OOB, kc * (int)sizeof(T), 0));
+        AM_WLOAD(wr0, 0);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+          if (((tid + it * 256) >> 2) < nvox) *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
+        AM_WSTORE(wr0, 0);
+      }
       __syncthreads();
+      for (int gi = 0; gi < ng; ++gi) {
+        const int buf = gi & 1;
+        u32x4 wr[WIT];
+        const bool more = gi + 1 < ng;
+        AM_WLOAD(wr, more ? gi + 1 : gi);                // next group's weights fly while this group's MFMAs issue (branch-free:
+                                                         // a conditional load makes hipcc drain vmcnt at the join)
+        __builtin_amdgcn_sched_barrier(0);
+        // straight-line over the TG taps of the group (padding taps multiply zero weights): no per-tap branch, so the
+        // fragment reads of tap t+1 can be scheduled under the MFMAs of tap t
+#pragma unroll
+        for (int tl = 0; tl < TG; ++tl) {
+          const int tt = gi * TG + tl;
+          const int tob = __builtin_amdgcn_readfirstlane(ldsTap[tb + (tt < nt ? tt : nt - 1)]) & 0xFFFFF;
+          u32x4 af[NS];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
+#pragma unroll
+          for (int j = 0; j < VS; ++j) {
+            const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) { AM_WSTORE(wr, buf ^ 1); }
+        __syncthreads();
+      }
     }
   }
 #undef AM_WLOAD
@@ -295,44 +301,50 @@ struct Plan { ConvArgs a; int bd, bh, bw; size_t lds; int nit, nt_tile; };
 int build_plan(Plan& P, int mode, int k, int stride) {
   ConvArgs& a = P.a;
   const int pad = (mode == AM_CONVT_FWD || mode == AM_CONVT_DGRAD) ? 1 : k / 2;
-  a.OS = 1; a.IS = 1; a.nclass = 1;
-  if (mode == AM_CONV_FWD) a.IS = stride;
+  a.OS = 1; a.GS = 1; a.nclass = 1;
+  if (mode == AM_CONV_FWD) a.GS = stride;
   else if (mode == AM_CONV_DGRAD) a.OS = stride;
   else if (mode == AM_CONVT_FWD) { a.OS = 2; if (k != 4 || stride != 2) return -2; }
-  else if (mode == AM_CONVT_DGRAD) { a.IS = 2; if (k != 4 || stride != 2) return -2; }
+  else if (mode == AM_CONVT_DGRAD) { a.GS = 2; if (k != 4 || stride != 2) return -2; }
   else return -2;
   if (a.OS == 2) a.nclass = 8;
+  a.nunit = (a.OS == 2 || a.GS == 2) ? 8 : 1;
   if (k * k * k > 64) return -2;
   int n = 0;
-  for (int c = 0; c < a.nclass; ++c) {
+  for (int c = 0; c < a.nunit; ++c) {
     a.tap_begin[c] = n;
+    a.upar[c] = a.GS == 2 ? c : 0;
     const int p[3] = {(c >> 2) & 1, (c >> 1) & 1, c & 1};
     int mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
     bool first = true;
     for (int td = 0; td < k; ++td) for (int th = 0; th < k; ++th) for (int tw = 0; tw < k; ++tw) {
       const int t[3] = {td, th, tw};
-      int s[3]; bool ok = true;
+      int u[3]; bool ok = true;
       for (int d = 0; d < 3; ++d) {
-        if (mode == AM_CONV_FWD || mode == AM_CONVT_DGRAD) s[d] = t[d] - pad;
-        else if (a.OS == 1) s[d] = pad - t[d];
-        else { const int num = p[d] + pad - t[d]; if (num & 1) { ok = false; break; } s[d] = num / 2; }
+        if (a.GS == 2) {                       // source voxel 2q + (t - pad) = 2(q + u) + r: belongs to unit c iff r == p[d]
+          const int sft = t[d] - pad, r = ((sft % 2) + 2) % 2;
+          if (r != p[d]) { ok = false; break; }
+          u[d] = (sft - r) / 2;
+        } else if (mode == AM_CONV_FWD) u[d] = t[d] - pad;
+        else if (a.OS == 1) u[d] = pad - t[d];
+        else { const int num = p[d] + pad - t[d]; if (num & 1) { ok = false; break; } u[d] = num / 2; }
       }
       if (!ok) continue;
       if (n >= 64) return -2;
-      a.taps[n++] = (s[0] + 8) | ((s[1] + 8) << 4) | ((s[2] + 8) << 8) | ((td * k * k + th * k + tw) << 12);
-      for (int d = 0; d < 3; ++d) { if (first || s[d] < mn[d]) mn[d] = s[d]; if (first || s[d] > mx[d]) mx[d] = s[d]; }
+      a.taps[n++] = (u[0] + 8) | ((u[1] + 8) << 4) | ((u[2] + 8) << 8) | ((td * k * k + th * k + tw) << 12) | (c << 18);
+      for (int d = 0; d < 3; ++d) { if (first || u[d] < mn[d]) mn[d] = u[d]; if (first || u[d] > mx[d]) mx[d] = u[d]; }
       first = false;
     }
     a.mind[c] = mn[0]; a.minh[c] = mn[1]; a.minw[c] = mn[2];
-    a.ed[c] = (P.bd - 1) * a.IS + (mx[0] - mn[0]) + 1;
-    a.eh[c] = (P.bh - 1) * a.IS + (mx[1] - mn[1]) + 1;
-    a.ew[c] = (P.bw - 1) * a.IS + (mx[2] - mn[2]) + 1;
+    a.ed[c] = P.bd + (mx[0] - mn[0]);
+    a.eh[c] = P.bh + (mx[1] - mn[1]);
+    a.ew[c] = P.bw + (mx[2] - mn[2]);
     a.mdiv_w[c] = (1 << 20) / a.ew[c] + 1;
     a.mdiv_hw[c] = (1 << 20) / (a.ew[c] * a.eh[c]) + 1;
   }
-  for (int c = a.nclass; c <= 8; ++c) a.tap_begin[c] = n;
+  for (int c = a.nunit; c <= 8; ++c) a.tap_begin[c] = n;
   size_t mxv = 0;
-  for (int c = 0; c < a.nclass; ++c) { size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
+  for (int c = 0; c < a.nunit; ++c) { size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
   P.nit = (int)((mxv * (ROWB / 16) + 255) / 256);
   size_t brick = mxv * LROWB;
   if (brick < 4096) brick = 4096;                        // the stats epilogue reuses the head of the brick
@@ -360,10 +372,8 @@ int launch(Plan& P, hipStream_t st) {
 template <typename T, int NS>
 int dispatch_nit(Plan& P, int shape, hipStream_t st) {
   const int n = P.nit;
-  if (shape == 2) {                              // 4x4x4 brick (IS == 2: the haloed source brick would not fit otherwise)
-    if (n <= 6) return launch<T, 4, 4, 4, NS, 6>(P, st);
-    if (n <= 12) return launch<T, 4, 4, 4, NS, 12>(P, st);
-    if (n <= 16) return launch<T, 4, 4, 4, NS, 16>(P, st);
+  if (shape == 2) {                              // 4x4x4 brick: tiny grids only (more workgroups)
+    if (n <= 4) return launch<T, 4, 4, 4, NS, 4>(P, st);
     return -3;
   }
   if (shape == 1) {                              // 4x4x16: every 16-lane fragment is 16 consecutive voxels (conflict-free reads)
@@ -385,11 +395,10 @@ int dispatch(Plan& P, int shape, hipStream_t st) {
 
 }  // namespace
 
-// brick of q-space voxels per workgroup: 0 = 4x8x8 (narrow grids), 1 = 4x4x16, 2 = 4x4x4 (source stride 2)
+// brick of q-space voxels per workgroup: 0 = 4x8x8 (narrow grids), 1 = 4x4x16, 2 = 4x4x4 (tiny grids, chosen by the caller)
 static int brick_shape(int mode, int stride, int qw, int* bd, int* bh, int* bw) {
-  const bool small = (mode == AM_CONV_FWD && stride == 2) || mode == AM_CONVT_DGRAD;
+  (void)mode; (void)stride;
   *bd = 4;
-  if (small) { *bh = 4; *bw = 4; return 2; }
   if (qw >= 16) { *bh = 4; *bw = 16; return 1; }
   *bh = 8; *bw = 8; return 0;
 }

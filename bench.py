@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("AM_BENCH_BATCH", "2")), help="volumes per GPU per step")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("AM_BENCH_BATCH", "4")), help="volumes per GPU per step")
     ap.add_argument("--size", default="B")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
