@@ -373,52 +373,89 @@ __global__ void add_kernel(const T* a, const T* b, T* y, size_t nchunk) {
 
 // ------------------------------------------------------------------ stem: Cin = 1 convolution (k = 1 or 3)
 // y[v][c] = b[c] + sum_t w[c][t] * xm[v + t - pad],  xm = x on active patches, 0 elsewhere / outside.
-// 27 broadcast input reads per voxel (L1-resident stencil), one 16-byte chunk of channels per lane.
+// One workgroup per 4x8x16 brick of an active patch: the haloed input brick is staged once into LDS with the patch mask
+// and the volume bounds already applied (so the 27-tap loop is pure LDS reads + FMAs, the wavefront re-reads its
+// neighbours' values from LDS instead of re-fetching them), one 16-byte chunk of output channels per lane.
+constexpr int SBD = 4, SBH = 8, SBW = 16;                   // divides the 16^3 patch: a brick never straddles patches
+
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, Geo g, int k,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
                                                             T* __restrict__ y) {
   constexpr int EPC = TT<T>::EPC;
-  extern __shared__ float wl[];                              // [C][k^3]
+  extern __shared__ float sm[];                              // [C][k^3] weights, then the haloed x brick
   const int nt = k * k * k, pad = k / 2;
+  const int ED = SBD + 2 * pad, EH = SBH + 2 * pad, EW = SBW + 2 * pad;
+  float* wl = sm;
+  float* xb = sm + g.C * nt;
+  int bid = blockIdx.x;
+  const int nbw = g.W / SBW, nbh = g.H / SBH, nbd = g.D / SBD;
+  const int bw_ = bid % nbw; bid /= nbw;
+  const int bh_ = bid % nbh; bid /= nbh;
+  const int bd_ = bid % nbd; const int b = bid / nbd;
+  const int d0 = bd_ * SBD, h0 = bh_ * SBH, w0 = bw_ * SBW;
+  if (!g.mask.active(b, d0, h0, w0)) return;                  // whole brick inactive (wave-uniform)
   for (int i = threadIdx.x; i < g.C * nt; i += 256) wl[i] = w[i];
+  for (int e = threadIdx.x; e < ED * EH * EW; e += 256) {
+    const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
+    const int id = d0 + ez - pad, ih = h0 + ey - pad, iw = w0 + ex - pad;
+    float v = 0.f;
+    if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
+      v = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
+    xb[e] = v;
+  }
   __syncthreads();
   Walk<T> wk(g.C);
   if (!wk.live) return;
-  const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
-  for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
-    int b, dd, hh, ww;
-    g.decode(v, b, dd, hh, ww);
-    if (!g.mask.active(b, dd, hh, ww)) continue;
+  float bs[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) bs[i] = bias ? bias[wk.cl * EPC + i] : 0.f;
+  for (int v = wk.vl; v < SBD * SBH * SBW; v += wk.vpp) {
+    const int lw = v % SBW, lh = (v / SBW) % SBH, ld = v / (SBW * SBH);
     float o[EPC];
 #pragma unroll
-    for (int i = 0; i < EPC; ++i) o[i] = bias ? bias[wk.cl * EPC + i] : 0.f;
+    for (int i = 0; i < EPC; ++i) o[i] = bs[i];
     int ti = 0;
     for (int td = 0; td < k; ++td) for (int th = 0; th < k; ++th) for (int tw = 0; tw < k; ++tw, ++ti) {
-      const int id = dd + td - pad, ih = hh + th - pad, iw = ww + tw - pad;
-      float xv = 0.f;
-      if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
-        xv = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
+      const float xv = xb[((ld + td) * EH + lh + th) * EW + lw + tw];
 #pragma unroll
       for (int i = 0; i < EPC; ++i) o[i] += wl[(wk.cl * EPC + i) * nt + ti] * xv;
     }
-    *(u32x4*)(y + (size_t)v * g.C + wk.cl * EPC) = f_to_chunk<T>(o);
+    const size_t vox = ((size_t)(b * g.D + d0 + ld) * g.H + h0 + lh) * g.W + w0 + lw;
+    *(u32x4*)(y + vox * g.C + wk.cl * EPC) = f_to_chunk<T>(o);
   }
 }
 
-// dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]
+// dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]     (same brick staging; 9 taps at a time in registers)
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy, Geo g, int k,
                                                               float* __restrict__ dw, float* __restrict__ db) {
   constexpr int EPC = TT<T>::EPC;
-  extern __shared__ float acc_l[];                           // [C][k^3 + 1]
+  extern __shared__ float sm[];                              // [C][k^3 + 1] accumulators, then the haloed x brick
   const int nt = k * k * k, pad = k / 2;
+  const int ED = SBD + 2 * pad, EH = SBH + 2 * pad, EW = SBW + 2 * pad;
+  float* acc_l = sm;
+  float* xb = sm + g.C * (nt + 1);
+  int bid = blockIdx.x;
+  const int nbw = g.W / SBW, nbh = g.H / SBH, nbd = g.D / SBD;
+  const int bw_ = bid % nbw; bid /= nbw;
+  const int bh_ = bid % nbh; bid /= nbh;
+  const int bd_ = bid % nbd; const int b = bid / nbd;
+  const int d0 = bd_ * SBD, h0 = bh_ * SBH, w0 = bw_ * SBW;
+  if (!g.mask.active(b, d0, h0, w0)) return;
   for (int i = threadIdx.x; i < g.C * (nt + 1); i += 256) acc_l[i] = 0.f;
+  for (int e = threadIdx.x; e < ED * EH * EW; e += 256) {
+    const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
+    const int id = d0 + ez - pad, ih = h0 + ey - pad, iw = w0 + ex - pad;
+    float v = 0.f;
+    if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
+      v = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
+    xb[e] = v;
+  }
   __syncthreads();
   Walk<T> wk(g.C);
   if (wk.live) {
-    const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
-    for (int tg = 0; tg < nt; tg += 9) {                     // 9 taps at a time keeps the accumulators in registers
+    for (int tg = 0; tg < nt; tg += 9) {
       float a[9][EPC], sb[EPC];
 #pragma unroll
       for (int q = 0; q < 9; ++q)
@@ -426,12 +463,11 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
         for (int i = 0; i < EPC; ++i) a[q][i] = 0.f;
 #pragma unroll
       for (int i = 0; i < EPC; ++i) sb[i] = 0.f;
-      for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
-        int b, dd, hh, ww;
-        g.decode(v, b, dd, hh, ww);
-        if (!g.mask.active(b, dd, hh, ww)) continue;
+      for (int v = wk.vl; v < SBD * SBH * SBW; v += wk.vpp) {
+        const int lw = v % SBW, lh = (v / SBW) % SBH, ld = v / (SBW * SBH);
+        const size_t vox = ((size_t)(b * g.D + d0 + ld) * g.H + h0 + lh) * g.W + w0 + lw;
         float d[EPC];
-        chunk_to_f<T>(*(const u32x4*)(dy + (size_t)v * g.C + wk.cl * EPC), d);
+        chunk_to_f<T>(*(const u32x4*)(dy + vox * g.C + wk.cl * EPC), d);
         if (tg == 0) {
 #pragma unroll
           for (int i = 0; i < EPC; ++i) sb[i] += d[i];
@@ -441,10 +477,7 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
           const int ti = tg + q;
           if (ti < nt) {
             const int td = ti / (k * k), th = (ti / k) % k, tw = ti % k;
-            const int id = dd + td - pad, ih = hh + th - pad, iw = ww + tw - pad;
-            float xv = 0.f;
-            if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
-              xv = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
+            const float xv = xb[((ld + td) * EH + lh + th) * EW + lw + tw];
 #pragma unroll
             for (int i = 0; i < EPC; ++i) a[q][i] += d[i] * xv;
           }
@@ -753,8 +786,10 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W, g.vpw);
-  const size_t sm = sizeof(float) * C * ksize * ksize * ksize;
+  if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;      // stage-0 tensor: 16^3 patches
+  const int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
+  const int pad_ = ksize / 2;
+  const size_t sm = sizeof(float) * ((size_t)C * ksize * ksize * ksize + (size_t)(SBD + 2 * pad_) * (SBH + 2 * pad_) * (SBW + 2 * pad_));
   DISPATCH_T(dtype, AM_LAUNCH(stem_conv_fwd_kernel<float>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (float*)y),
              AM_LAUNCH(stem_conv_fwd_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (bf16_t*)y));
   AM_CHECK_LAUNCH();
@@ -768,8 +803,10 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W, g.vpw);
-  const size_t sm = sizeof(float) * C * (ksize * ksize * ksize + 1);
+  if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;
+  const int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
+  const int pad_ = ksize / 2;
+  const size_t sm = sizeof(float) * ((size_t)C * (ksize * ksize * ksize + 1) + (size_t)(SBD + 2 * pad_) * (SBH + 2 * pad_) * (SBW + 2 * pad_));
   DISPATCH_T(dtype,
              AM_LAUNCH(stem_conv_wgrad_kernel<float>, dim3(nb), dim3(256), sm, st, x, (const float*)dy, g, ksize, dw_accum, db_accum),
              AM_LAUNCH(stem_conv_wgrad_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, (const bf16_t*)dy, g, ksize, dw_accum, db_accum));

@@ -150,9 +150,9 @@ def test_conv_odd_extent(ops, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("k", [1, 3])
 def test_stem_conv(ops, dtype, k):
-    B, C, f = 2, 16, (2, 2, 3)
-    sp = tuple(v * 4 for v in f)
-    mask = mk_mask(B, f, 5)
+    B, C, f = 2, 16, (1, 2, 2)
+    sp = tuple(v * 16 for v in f)                   # stage-0 tensor: 16^3 patches (block shift 4)
+    mask = mk_mask(B, f, 2)
     mi = ops.MaskInfo.from_bool(mask, DEV)
     x = rnd(B, 1, *sp, seed=1)
     w = rnd(C, 1, k, k, k, seed=2, scale=0.3).requires_grad_(True)
@@ -160,10 +160,10 @@ def test_stem_conv(ops, dtype, k):
     dy = q(rnd(B, C, *sp, seed=4), dtype) * O.upsample_mask(mask, sp).float()
     yr = O.sparse_conv3d(x * O.upsample_mask(mask, sp).float(), w, b, 1, mask)
     yr.backward(dy)
-    y = ops.stem_conv_fwd(x[:, 0].contiguous().to(DEV), w.detach().to(DEV), b.detach().to(DEV), mi, 2, dtype)
+    y = ops.stem_conv_fwd(x[:, 0].contiguous().to(DEV), w.detach().to(DEV), b.detach().to(DEV), mi, 4, dtype)
     close(from_cl(y), yr.detach(), TOL[dtype], "stem fwd", O.upsample_mask(mask, sp).float())
     dw = torch.zeros(C, k ** 3, device=DEV); db = torch.zeros(C, device=DEV)
-    ops.stem_conv_wgrad(x[:, 0].contiguous().to(DEV), to_cl(dy, dtype), k, mi, 2, dw, db)
+    ops.stem_conv_wgrad(x[:, 0].contiguous().to(DEV), to_cl(dy, dtype), k, mi, 4, dw, db)
     close(dw.cpu().view_as(w), w.grad, 5e-4, "stem wgrad")
     close(db.cpu(), b.grad, 5e-4, "stem bgrad")
 
