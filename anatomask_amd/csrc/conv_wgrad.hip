@@ -46,8 +46,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int MV = BD * BH * BW;
   constexpr int KSTEP = sizeof(T) == 2 ? 32 : 4;
-  constexpr int RSY = CT * sizeof(T) + 16;               // LDS row strides (bytes)
-  constexpr int RSX = KT * sizeof(T) + 16;
+  // LDS row strides (bytes).  bf16: 160 B = 40 dwords: the 8 consecutive voxel rows a half-wave's ds_read_b64_tr_b16
+  // touches land on dword offsets {0,40,16,56,32,8,48,24} (mod 64): 8 disjoint 8-dword runs = all 64 banks, conflict-free.
+  constexpr int RPAD = sizeof(T) == 2 ? 32 : 16;
+  constexpr int RSY = CT * sizeof(T) + RPAD;
+  constexpr int RSX = KT * sizeof(T) + RPAD;
   constexpr int CPR = CT / EPC;                          // 16-byte chunks per row
   constexpr int NITY = (MV * CPR + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const T* __restrict__ xg = (const T*)a.x;
   const T* __restrict__ yg = (const T*)a.dy;
   const int nbrick = a.B * a.nbd * a.nbh * a.nbw;
-  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+  const size_t ysample = (size_t)a.Dy * a.Hy * a.Wy * a.Cy, xsample = (size_t)a.Dx * a.Hx * a.Wx * a.Cx;
 
   for (int brick = blockIdx.x; brick < nbrick; brick += gridDim.x) {
     int bid = brick;
@@ -116,8 +119,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     // ---- addresses + validity of this brick's rows (clamped; zero-selected after the load) ----
     int yv[NITY], xv[NITX];
     unsigned yok = 0, xok = 0;
-    const int ybase = ((b * a.Dy + q0d * a.OS + pd) * a.Hy + q0h * a.OS + ph) * a.Wy + q0w * a.OS + pw;
-    const int xbase = ((b * a.Dx + i0d) * a.Hx + i0h) * a.Wx + i0w;
+    const int ybase = ((q0d * a.OS + pd) * a.Hy + q0h * a.OS + ph) * a.Wy + q0w * a.OS + pw;   // relative to sample b
+    const int xbase = (i0d * a.Hx + i0h) * a.Wx + i0w;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + (size_t)b * ysample), 0, (int)(ysample * sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)b * xsample), 0, (int)(xsample * sizeof(T)), 0x00020000);
     // interior brick of a dense tensor (wave-uniform): everything in range, one add per row instead of the bounds logic
     const bool interior = !a.x_mask.m && !a.y_mask.m && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + ED <= a.Dx && i0h + EH <= a.Hx &&
                           i0w + EW <= a.Wx && (q0d + BD - 1) * a.OS + pd < a.Dy && (q0h + BH - 1) * a.OS + ph < a.Hy &&
@@ -149,17 +154,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       }
     }
     u32x4 ys[NITY], xs[NITX];
+    // buffer loads: per-lane 32-bit byte offset, hardware zero-fill for rows marked out of range (offset >= num_records)
 #pragma unroll
-    for (int it = 0; it < NITY; ++it) ys[it] = (a.dbg & 4) ? zero4 : *(const u32x4*)(yg + (size_t)yv[it] * a.Cy + ycoff);
+    for (int it = 0; it < NITY; ++it)
+      ys[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          ry, (ycok && ((yok >> it) & 1u)) ? (unsigned)((yv[it] * a.Cy + ycoff) * (int)sizeof(T)) : 0x80000000u, 0, 0));
 #pragma unroll
-    for (int it = 0; it < NITX; ++it) xs[it] = (a.dbg & 4) ? zero4 : *(const u32x4*)(xg + (size_t)xv[it] * a.Cx + xcoff);
+    for (int it = 0; it < NITX; ++it)
+      xs[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rx, (xcok && ((xok >> it) & 1u)) ? (unsigned)((xv[it] * a.Cx + xcoff) * (int)sizeof(T)) : 0x80000000u, 0, 0));
     __syncthreads();                                     // previous brick's fragment reads are done
 #pragma unroll
     for (int it = 0; it < NITY; ++it)
-      if (ydst[it] >= 0) *(u32x4*)(ldsY + ydst[it]) = (ycok && ((yok >> it) & 1u)) ? ys[it] : zero4;
+      if (ydst[it] >= 0) *(u32x4*)(ldsY + ydst[it]) = ys[it];
 #pragma unroll
     for (int it = 0; it < NITX; ++it)
-      if (xdst[it] >= 0) *(u32x4*)(ldsX + xdst[it]) = (xcok && ((xok >> it) & 1u)) ? xs[it] : zero4;
+      if (xdst[it] >= 0) *(u32x4*)(ldsX + xdst[it]) = xs[it];
     __syncthreads();
 
     // ---- contract over the brick's voxels ----
@@ -167,7 +177,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     for (int ks = 0; ks < ((a.dbg & 2) ? 0 : MV / KSTEP); ++ks) {
       if constexpr (sizeof(T) == 2) {
         const int q = (lane >> 2) & 3, p = lane & 3;
-        const int v1 = ks * 32 + g * 8 + q, v2 = v1 + 4;
+        // contraction index k = 8g + j of the MFMA  <->  voxel ks*32 + (j < 4 ? 4g + j : 16 + 4g + j - 4): any bijection
+        // works as long as A and B agree; this one makes each half-wave read 8 consecutive voxel rows
+        const int v1 = ks * 32 + g * 4 + q, v2 = v1 + 16;
         const int xa1 = (((v1 / (BW * BH)) * a.IS * EH + ((v1 / BW) % BH) * a.IS) * EW + (v1 % BW) * a.IS) * RSX + (16 * wave + 4 * p) * 2;
         const int xa2 = (((v2 / (BW * BH)) * a.IS * EH + ((v2 / BW) % BH) * a.IS) * EW + (v2 % BW) * a.IS) * RSX + (16 * wave + 4 * p) * 2;
         s16x4 alo[4], ahi[4], blo[NTAP], bhi[NTAP];
@@ -228,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 template <typename T, int BD, int BH, int BW, int NTAP, int NITX>
 int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
   auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX>;
-  const size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + 16) + maxvox * (KT * sizeof(T) + 16);
+  constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
+  const size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
   if (lds > 160 * 1024) return -3;
   if (maxvox * (CT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
   static size_t attr_lds = 48 * 1024;
@@ -249,6 +262,7 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
                                const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift,
                                int fd, int fh, int fw, void* stream) {
   if (Cx % 8 || Cy % 8) return -1;
+  if ((size_t)Dx * Hx * Wx * Cx * 4 >= 0x7fffffffull || (size_t)Dy * Hy * Wy * Cy * 4 >= 0x7fffffffull) return -5;
   WgArgs a;
   a.x = x; a.dy = dy; a.dw = dw_packed;
   a.B = B; a.Dx = Dx; a.Hx = Hx; a.Wx = Wx; a.Cx = Cx; a.Dy = Dy; a.Hy = Hy; a.Wy = Wy; a.Cy = Cy;
