@@ -23,7 +23,9 @@ namespace {
 struct WgArgs {
   const void* x; const void* dy; float* dw;
   int B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy;
-  int OS, IS, ngroup;
+  int OS, GS, ngroup;         // dY stride (ConvT parity classes), global X stride (2: strided conv, X read per parity sub-lattice)
+  int zmap[8];                // blockIdx.z -> unit (one launch handles the units that share a tap count)
+  int upar[8];                // X parity of the unit when GS == 2
   int nbd, nbh, nbw;
   int tap_begin[9];
   int taps[64];
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
-  const int grp = blockIdx.z;
+  const int grp = a.zmap[blockIdx.z];
   const int ncxt = (a.Cx + KT - 1) / KT;
   const int cy0 = (blockIdx.y / ncxt) * CT, cx0 = (blockIdx.y % ncxt) * KT;
   const int pd = (a.pofs[grp] >> 2) & 1, ph = (a.pofs[grp] >> 1) & 1, pw = a.pofs[grp] & 1;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int nvox = ED * EH * EW;
   const int mW = a.mdiv_w[grp], mHW = a.mdiv_hw[grp], EHW = EH * EW;
   const int tb = a.tap_begin[grp];
+  const int upd = (a.upar[grp] >> 2) & 1, uph = (a.upar[grp] >> 1) & 1, upw = a.upar[grp] & 1;
 
   f32x4 acc[NTAP][4];
 #pragma unroll
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     const int idx = tid + it * 256;
     const int e = idx / CPR, c = idx % CPR;
     const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
-    xrel[it] = e < nvox ? (ez * a.Hx + ey) * a.Wx + (rem - ey * EW) : 0;
+    xrel[it] = e < nvox ? ((ez * a.Hx + ey) * a.Wx + (rem - ey * EW)) * a.GS : 0;
     xdst[it] = e < nvox ? e * RSX + c * 16 : -1;
   }
   const int ychan = (tid % CPR) * EPC;                   // 256 % CPR == 0: a thread keeps its channel chunk across iterations
@@ -114,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     const int bh_ = bid % a.nbh; bid /= a.nbh;
     const int bd_ = bid % a.nbd; const int b = bid / a.nbd;
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
-    const int i0d = q0d * a.IS + a.mind[grp], i0h = q0h * a.IS + a.minh[grp], i0w = q0w * a.IS + a.minw[grp];
+    // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
+    const int i0d = (q0d + a.mind[grp]) * a.GS + upd, i0h = (q0h + a.minh[grp]) * a.GS + uph, i0w = (q0w + a.minw[grp]) * a.GS + upw;
 
     // ---- addresses + validity of this brick's rows (clamped; zero-selected after the load) ----
     int yv[NITY], xv[NITX];
@@ -124,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + (size_t)b * ysample), 0, (int)(ysample * sizeof(T)), 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)b * xsample), 0, (int)(xsample * sizeof(T)), 0x00020000);
     // interior brick of a dense tensor (wave-uniform): everything in range, one add per row instead of the bounds logic
-    const bool interior = !a.x_mask.m && !a.y_mask.m && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + ED <= a.Dx && i0h + EH <= a.Hx &&
-                          i0w + EW <= a.Wx && (q0d + BD - 1) * a.OS + pd < a.Dy && (q0h + BH - 1) * a.OS + ph < a.Hy &&
+    const bool interior = !a.x_mask.m && !a.y_mask.m && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + (ED - 1) * a.GS < a.Dx &&
+                          i0h + (EH - 1) * a.GS < a.Hx && i0w + (EW - 1) * a.GS < a.Wx && (q0d + BD - 1) * a.OS + pd < a.Dy && (q0h + BH - 1) * a.OS + ph < a.Hy &&
                           (q0w + BW - 1) * a.OS + pw < a.Wy;
     if (interior) {
 #pragma unroll
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       for (int it = 0; it < NITX; ++it) {
         const int e = (tid + it * 256) / CPR;
         const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
-        const int id = i0d + ez, ih = i0h + ey, iw = i0w + rem - ey * EW;
+        const int id = i0d + ez * a.GS, ih = i0h + ey * a.GS, iw = i0w + (rem - ey * EW) * a.GS;
         const bool ok = xdst[it] >= 0 && id >= 0 && id < a.Dx && ih >= 0 && ih < a.Hx && iw >= 0 && iw < a.Wx && a.x_mask.active(b, id, ih, iw);
         xv[it] = ok ? xbase + xrel[it] : 0;
         xok |= (ok ? 1u : 0u) << it;
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
         // contraction index k = 8g + j of the MFMA  <->  voxel ks*32 + (j < 4 ? 4g + j : 16 + 4g + j - 4): any bijection
         // works as long as A and B agree; this one makes each half-wave read 8 consecutive voxel rows
         const int v1 = ks * 32 + g * 4 + q, v2 = v1 + 16;
-        const int xa1 = (((v1 / (BW * BH)) * a.IS * EH + ((v1 / BW) % BH) * a.IS) * EW + (v1 % BW) * a.IS) * RSX + (16 * wave + 4 * p) * 2;
-        const int xa2 = (((v2 / (BW * BH)) * a.IS * EH + ((v2 / BW) % BH) * a.IS) * EW + (v2 % BW) * a.IS) * RSX + (16 * wave + 4 * p) * 2;
+        const int xa1 = (((v1 / (BW * BH)) * EH + (v1 / BW) % BH) * EW + v1 % BW) * RSX + (16 * wave + 4 * p) * 2;
+        const int xa2 = (((v2 / (BW * BH)) * EH + (v2 / BW) % BH) * EW + v2 % BW) * RSX + (16 * wave + 4 * p) * 2;
         s16x4 alo[4], ahi[4], blo[NTAP], bhi[NTAP];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
         }
       } else {
         const int v = ks * 4 + g;
-        const int xa = (((v / (BW * BH)) * a.IS * EH + ((v / BW) % BH) * a.IS) * EW + (v % BW) * a.IS) * RSX + (16 * wave + r16) * 4;
+        const int xa = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * RSX + (16 * wave + r16) * 4;
         float af[4], bf[NTAP];
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const float*)(ldsY + v * RSY + (16 * i + r16) * 4);
@@ -270,67 +274,87 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   a.y_mask = MaskView{y_mask, fd, fh, fw, y_bshift};
   const int k = ksize;
   { const char* e_ = getenv("AM_WG_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
-  int bd, bh, bw;
   const bool bf = dtype == AM_DT_BF16;
+  // units: taps that share the dY operand AND one dense X sub-brick
+  //   conv stride 1: one unit per d-tap (9 taps, no d-halo);  ConvT: the 8 output parities (8 taps each);
+  //   conv stride 2: the 8 parity sub-lattices of X (1,2,2,2,4,4,4,8 taps): X[2q + s] = X_sub[r][q + u], s = 2u + r
+  int nunit;
+  a.OS = 1; a.GS = 1;
   if (mode == AM_CONV_FWD) {
-    a.OS = 1; a.IS = stride;
     if (k != 1 && k != 3) return -2;
-    a.ngroup = k;                                          // one group per d-tap
+    if (stride == 2) { a.GS = 2; nunit = 8; } else nunit = k;
   } else if (mode == AM_CONVT_FWD) {
     if (k != 4 || stride != 2) return -2;
-    a.OS = 2; a.IS = 1; a.ngroup = 8;
+    a.OS = 2; nunit = 8;
   } else return -2;
   const int Qd = (Dy + a.OS - 1) / a.OS, Qh = (Hy + a.OS - 1) / a.OS, Qw = (Wy + a.OS - 1) / a.OS;
-  // q-brick per staging round.  bf16 (k-steps of 32 voxels): 2x4x16 / 2x8x8 = 128 voxels, ~44 KB of LDS so two
-  // workgroups share a CU and overlap each other's staging; source stride 2: 4x4x4.  f32 (k-steps of 4): 2x8x8 / 2x4x4.
-  if (a.IS == 2) { bd = bf ? 4 : 2; bh = 4; bw = 4; }
-  else if (bf && Qw >= 16) { bd = 2; bh = 4; bw = 16; }
-  else { bd = 2; bh = 8; bw = 8; }
+  // q-brick per staging round: bf16 (k-steps of 32 voxels) 2x4x16 / 2x8x8 = 128 voxels, ~55 KB of LDS so two workgroups
+  // share a CU and overlap each other's staging;  f32 (k-steps of 4): 2x8x8.
+  int bd = 2, bh = 8, bw = 8;
+  if (bf && Qw >= 16) { bh = 4; bw = 16; }
   const int pad = (mode == AM_CONVT_FWD) ? 1 : k / 2;
   int n = 0; size_t maxvox = 0;
-  for (int gI = 0; gI < a.ngroup; ++gI) {
+  int ucount[8];
+  for (int gI = 0; gI < nunit; ++gI) {
     a.tap_begin[gI] = n;
     const int p[3] = {(gI >> 2) & 1, (gI >> 1) & 1, gI & 1};
     a.pofs[gI] = (mode == AM_CONVT_FWD) ? gI : 0;
+    a.upar[gI] = a.GS == 2 ? gI : 0;
     int mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0}; bool first = true;
     for (int td = 0; td < k; ++td) for (int th = 0; th < k; ++th) for (int tw = 0; tw < k; ++tw) {
       const int t[3] = {td, th, tw};
-      int s[3]; bool ok = true;
-      if (mode == AM_CONV_FWD) { if (td != gI) continue; for (int d = 0; d < 3; ++d) s[d] = t[d] - pad; }
-      else for (int d = 0; d < 3; ++d) { const int num = p[d] + pad - t[d]; if (num & 1) { ok = false; break; } s[d] = num / 2; }
+      int u[3]; bool ok = true;
+      for (int d = 0; d < 3 && ok; ++d) {
+        if (mode == AM_CONVT_FWD) { const int num = p[d] + pad - t[d]; if (num & 1) ok = false; else u[d] = num / 2; }
+        else if (a.GS == 2) { const int sft = t[d] - pad, r = ((sft % 2) + 2) % 2; if (r != p[d]) ok = false; else u[d] = (sft - r) / 2; }
+        else u[d] = t[d] - pad;
+      }
+      if (ok && mode == AM_CONV_FWD && a.GS == 1 && td != gI) ok = false;
       if (!ok) continue;
-      a.taps[n++] = (s[0] + 8) | ((s[1] + 8) << 4) | ((s[2] + 8) << 8) | ((td * k * k + th * k + tw) << 12);
-      for (int d = 0; d < 3; ++d) { if (first || s[d] < mn[d]) mn[d] = s[d]; if (first || s[d] > mx[d]) mx[d] = s[d]; }
+      a.taps[n++] = (u[0] + 8) | ((u[1] + 8) << 4) | ((u[2] + 8) << 8) | ((td * k * k + th * k + tw) << 12);
+      for (int d = 0; d < 3; ++d) { if (first || u[d] < mn[d]) mn[d] = u[d]; if (first || u[d] > mx[d]) mx[d] = u[d]; }
       first = false;
     }
+    ucount[gI] = n - a.tap_begin[gI];
     a.mind[gI] = mn[0]; a.minh[gI] = mn[1]; a.minw[gI] = mn[2];
-    a.ed[gI] = (bd - 1) * a.IS + (mx[0] - mn[0]) + 1;
-    a.eh[gI] = (bh - 1) * a.IS + (mx[1] - mn[1]) + 1;
-    a.ew[gI] = (bw - 1) * a.IS + (mx[2] - mn[2]) + 1;
+    a.ed[gI] = bd + (mx[0] - mn[0]);
+    a.eh[gI] = bh + (mx[1] - mn[1]);
+    a.ew[gI] = bw + (mx[2] - mn[2]);
     a.mdiv_w[gI] = (1 << 20) / a.ew[gI] + 1;
     a.mdiv_hw[gI] = (1 << 20) / (a.ew[gI] * a.eh[gI]) + 1;
     const size_t v = (size_t)a.ed[gI] * a.eh[gI] * a.ew[gI];
     if (v > maxvox) maxvox = v;
   }
-  for (int gI = a.ngroup; gI <= 8; ++gI) a.tap_begin[gI] = n;
-  const int ntap = n / a.ngroup;                           // 9 (conv k3), 8 (ConvT), 1 (conv k1): uniform per group
+  for (int gI = nunit; gI <= 8; ++gI) a.tap_begin[gI] = n;
   a.nbd = (Qd + bd - 1) / bd; a.nbh = (Qh + bh - 1) / bh; a.nbw = (Qw + bw - 1) / bw;
   const int nbrick = B * a.nbd * a.nbh * a.nbw;
-  // enough workgroups to fill 256 CUs x 2, few enough that the atomic flush stays small
-  const int tiles = ((Cy + CT - 1) / CT) * ((Cx + KT - 1) / KT) * a.ngroup;
-  int split = (1024 + tiles - 1) / tiles;
-  if (split > nbrick) split = nbrick;
-  if (split < 1) split = 1;
   hipStream_t st = (hipStream_t)stream;
-#define WG_CASE(TT_, BD_, BH_, BW_, NT_, NX_) return launch<TT_, BD_, BH_, BW_, NT_, NX_>(a, maxvox, split, st)
-  if (bf) {
-    if (a.IS == 2) { if (ntap == 9) WG_CASE(bf16_t, 4, 4, 4, 9, 18); if (ntap == 1) WG_CASE(bf16_t, 4, 4, 4, 1, 11); return -2; }
-    if (bw == 16) { if (ntap == 9) WG_CASE(bf16_t, 2, 4, 16, 9, 7); if (ntap == 8) WG_CASE(bf16_t, 2, 4, 16, 8, 8); if (ntap == 1) WG_CASE(bf16_t, 2, 4, 16, 1, 4); return -2; }
-    if (ntap == 9) WG_CASE(bf16_t, 2, 8, 8, 9, 7); if (ntap == 8) WG_CASE(bf16_t, 2, 8, 8, 8, 8); if (ntap == 1) WG_CASE(bf16_t, 2, 8, 8, 1, 4);
-    return -2;
-  }
-  if (a.IS == 2) { if (ntap == 9) WG_CASE(float, 2, 4, 4, 9, 16); if (ntap == 1) WG_CASE(float, 2, 4, 4, 1, 10); return -2; }
-  if (ntap == 9) WG_CASE(float, 2, 8, 8, 9, 13); if (ntap == 8) WG_CASE(float, 2, 8, 8, 8, 16); if (ntap == 1) WG_CASE(float, 2, 8, 8, 1, 8);
-  return -2;
+  // one launch per tap count: the kernel's tap loop is compile-time
+  static const int counts[5] = {9, 8, 4, 2, 1};
+  for (int ci = 0; ci < 5; ++ci) {
+    const int ntap = counts[ci];
+    a.ngroup = 0;
+    for (int gI = 0; gI < nunit; ++gI) if (ucount[gI] == ntap) a.zmap[a.ngroup++] = gI;
+    if (!a.ngroup) continue;
+    // enough workgroups to fill 256 CUs x 2, few enough that the atomic flush stays small
+    const int tiles = ((Cy + CT - 1) / CT) * ((Cx + KT - 1) / KT) * a.ngroup;
+    int split = (1024 + tiles - 1) / tiles;
+    if (split > nbrick) split = nbrick;
+    if (split < 1) split = 1;
+    int rc = -2;
+#define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, split, st)
+    if (bf && bw == 16) {
+      if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
+      else if (ntap == 2) WG_CASE(bf16_t, 4, 16, 2, 8); else WG_CASE(bf16_t, 4, 16, 1, 8);
+    } else if (bf) {
+      if (ntap == 9) WG_CASE(bf16_t, 8, 8, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 8, 8, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 8, 8, 4, 8);
+      else if (ntap == 2) WG_CASE(bf16_t, 8, 8, 2, 8); else WG_CASE(bf16_t, 8, 8, 1, 8);
+    } else {
+      if (ntap == 9) WG_CASE(float, 8, 8, 9, 13); else if (ntap == 8) WG_CASE(float, 8, 8, 8, 16); else if (ntap == 4) WG_CASE(float, 8, 8, 4, 16);
+      else if (ntap == 2) WG_CASE(float, 8, 8, 2, 16); else WG_CASE(float, 8, 8, 1, 16);
+    }
 #undef WG_CASE
+    if (rc) return rc;
+  }
+  return 0;
 }
