@@ -48,7 +48,7 @@ struct ConvArgs {
 
 constexpr int ROWB = 64;      // channel-slab bytes staged per voxel / per weight row (unpadded, XOR-swizzled)
 constexpr int LROWB = 80;     // LDS row stride of the source brick (16 B pad; B-fragment address = lane const + scalar tap offset)
-constexpr int TG = 3;         // taps per weight group staged in LDS
+constexpr int TG_OF(int ns) { return ns == 2 ? 6 : 3; }   // taps per weight group staged in LDS: ~48 MFMAs per wave between barriers
 
 // LDS image of a [rows][64 B] tile: 16-byte chunk c of row r lives at r*64 + ((c ^ 2*bit2(r)) * 16).
 // With this swizzle a ds_read_b128 of 16 consecutive rows (any alignment) x 4 chunks is bank-conflict free
@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int MV = BD * BH * BW;
   constexpr int VS = MV / 64;                           // 16-voxel subtiles per wave
   constexpr int NT = 16 * NS;                           // output channels per workgroup
+  constexpr int TG = TG_OF(NS);
   constexpr int WBUF = TG * NT * ROWB;                  // bytes of one weight-group buffer
   constexpr int WCH = TG * NT * 4;                      // 16-byte chunks per weight group
   constexpr int WIT = (WCH + 255) / 256;
@@ -349,7 +350,7 @@ int build_plan(Plan& P, int mode, int k, int stride) {
   size_t brick = mxv * LROWB;
   if (brick < 4096) brick = 4096;                        // the stats epilogue reuses the head of the brick
   a.w_lds_off = (int)brick;
-  a.tap_lds_off = a.w_lds_off + 2 * TG * P.nt_tile * ROWB;
+  a.tap_lds_off = a.w_lds_off + 2 * TG_OF(P.nt_tile / 16) * P.nt_tile * ROWB;
   P.lds = a.tap_lds_off + 64 * sizeof(int);
   return 0;
 }

@@ -426,7 +426,9 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
   }
 }
 
-// dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]     (same brick staging; 9 taps at a time in registers)
+// dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]     (same brick staging; 9 taps at a time in registers).
+// Persistent: a workgroup walks a strided set of bricks and keeps its [C][k^3+1] partial sums in LDS, so the global
+// atomics happen once per workgroup, not once per brick.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy, Geo g, int k,
                                                               float* __restrict__ dw, float* __restrict__ db) {
@@ -436,33 +438,36 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
   const int ED = SBD + 2 * pad, EH = SBH + 2 * pad, EW = SBW + 2 * pad;
   float* acc_l = sm;
   float* xb = sm + g.C * (nt + 1);
-  int bid = blockIdx.x;
   const int nbw = g.W / SBW, nbh = g.H / SBH, nbd = g.D / SBD;
-  const int bw_ = bid % nbw; bid /= nbw;
-  const int bh_ = bid % nbh; bid /= nbh;
-  const int bd_ = bid % nbd; const int b = bid / nbd;
-  const int d0 = bd_ * SBD, h0 = bh_ * SBH, w0 = bw_ * SBW;
-  if (!g.mask.active(b, d0, h0, w0)) return;
+  const int nbrick = g.B * nbd * nbh * nbw;
   for (int i = threadIdx.x; i < g.C * (nt + 1); i += 256) acc_l[i] = 0.f;
-  for (int e = threadIdx.x; e < ED * EH * EW; e += 256) {
-    const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
-    const int id = d0 + ez - pad, ih = h0 + ey - pad, iw = w0 + ex - pad;
-    float v = 0.f;
-    if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
-      v = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
-    xb[e] = v;
-  }
-  __syncthreads();
   Walk<T> wk(g.C);
-  if (wk.live) {
-    for (int tg = 0; tg < nt; tg += 9) {
-      float a[9][EPC], sb[EPC];
+  for (int tg = 0; tg < nt; tg += 9) {                        // 9 taps x EPC channels of partial sums live in registers
+    float a[9][EPC], sb[EPC];                                 // across ALL bricks of this workgroup
 #pragma unroll
-      for (int q = 0; q < 9; ++q)
+    for (int q = 0; q < 9; ++q)
 #pragma unroll
-        for (int i = 0; i < EPC; ++i) a[q][i] = 0.f;
+      for (int i = 0; i < EPC; ++i) a[q][i] = 0.f;
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) sb[i] = 0.f;
+    for (int i = 0; i < EPC; ++i) sb[i] = 0.f;
+    for (int brick = blockIdx.x; brick < nbrick; brick += gridDim.x) {
+      int bid = brick;
+      const int bw_ = bid % nbw; bid /= nbw;
+      const int bh_ = bid % nbh; bid /= nbh;
+      const int bd_ = bid % nbd; const int b = bid / nbd;
+      const int d0 = bd_ * SBD, h0 = bh_ * SBH, w0 = bw_ * SBW;
+      if (!g.mask.active(b, d0, h0, w0)) continue;            // wave-uniform
+      __syncthreads();                                        // previous brick's reads of xb are done
+      for (int e = threadIdx.x; e < ED * EH * EW; e += 256) {
+        const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
+        const int id = d0 + ez - pad, ih = h0 + ey - pad, iw = w0 + ex - pad;
+        float v = 0.f;
+        if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
+          v = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
+        xb[e] = v;
+      }
+      __syncthreads();
+      if (!wk.live) continue;
       for (int v = wk.vl; v < SBD * SBH * SBW; v += wk.vpp) {
         const int lw = v % SBW, lh = (v / SBW) % SBH, ld = v / (SBW * SBH);
         const size_t vox = ((size_t)(b * g.D + d0 + ld) * g.H + h0 + lh) * g.W + w0 + lw;
@@ -483,6 +488,8 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
           }
         }
       }
+    }
+    if (wk.live) {
 #pragma unroll
       for (int q = 0; q < 9; ++q)
         if (tg + q < nt)
@@ -496,8 +503,10 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
   __syncthreads();
   for (int i = threadIdx.x; i < g.C * (nt + 1); i += 256) {
     const int c = i / (nt + 1), t = i % (nt + 1);
-    if (t < nt) atomicAdd(&dw[c * nt + t], acc_l[i]);
-    else if (db) atomicAdd(&db[c], acc_l[i]);
+    const float v = acc_l[i];
+    if (v == 0.f) continue;
+    if (t < nt) atomicAdd(&dw[c * nt + t], v);
+    else if (db) atomicAdd(&db[c], v);
   }
 }
 
@@ -804,7 +813,8 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;
-  const int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
+  int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
+  if (nb > 1024) nb = 1024;                                   // persistent workgroups: one atomic flush each
   const int pad_ = ksize / 2;
   const size_t sm = sizeof(float) * ((size_t)C * (ksize * ksize * ksize + 1) + (size_t)(SBD + 2 * pad_) * (SBH + 2 * pad_) * (SBW + 2 * pad_));
   DISPATCH_T(dtype,
