@@ -34,6 +34,7 @@ struct WgArgs {
   int mdiv_w[8], mdiv_hw[8];  // 2^20-scaled reciprocals of ew and ew*eh
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
+  int split;                  // brick-walk slots per (tile, group)
   int dbg;                    // AM_WG_DBG ablation bits (timing experiments only): 1 no flush, 2 no contraction, 4 no global loads
 };
 
@@ -61,7 +62,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
-  const int grp = a.zmap[blockIdx.z];
+  // workgroup id -> (brick-walk slot s, tap group): the groups that walk the SAME bricks get ids that differ by 8, i.e. the
+  // same XCD under round-robin dispatch (shared L2: x and dy are fetched from HBM once, not once per group) -- speed only
+  const int ng_ = a.ngroup;
+  const int blk_ = blockIdx.x / (8 * ng_), rem_ = blockIdx.x % (8 * ng_);
+  const int slot = blk_ * 8 + (rem_ & 7);
+  if (slot >= a.split) return;
+  const int grp = a.zmap[rem_ >> 3];
   const int ncxt = (a.Cx + KT - 1) / KT;
   const int cy0 = (blockIdx.y / ncxt) * CT, cx0 = (blockIdx.y % ncxt) * KT;
   const int pd = (a.pofs[grp] >> 2) & 1, ph = (a.pofs[grp] >> 1) & 1, pw = a.pofs[grp] & 1;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int nbrick = a.B * a.nbd * a.nbh * a.nbw;
   const size_t ysample = (size_t)a.Dy * a.Hy * a.Wy * a.Cy, xsample = (size_t)a.Dx * a.Hx * a.Wx * a.Cx;
 
-  for (int brick = blockIdx.x; brick < nbrick; brick += gridDim.x) {
+  for (int brick = slot; brick < nbrick; brick += a.split) {
     int bid = brick;
     const int bw_ = bid % a.nbw; bid /= a.nbw;
     const int bh_ = bid % a.nbh; bid /= a.nbh;
@@ -253,7 +260,8 @@ int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_lds = lds;
     (void)hipGetLastError();
   }
-  dim3 grid(split, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), a.ngroup);
+  a.split = split;
+  dim3 grid(((split + 7) / 8) * 8 * a.ngroup, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a);
   AM_CHECK_LAUNCH();
   return 0;
