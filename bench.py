@@ -52,9 +52,13 @@ def dominant_kernel_roofline(B, dev):
     t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (128, 128, 128), 3, 1, out=y))
     flops = 2.0 * B * 128 ** 3 * C * C * 27
     achieved = flops / t / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
+    # HBM bytes per launch from the PMC counters of the SAME launch shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc_traffic.md, measured at B=2 -> linear in B
+    traffic = (615e6 + 537e6) * B / 2
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4,11> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
-            "traffic": None, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops}
+            "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, scaled from B=2)",
+            "algorithmic_bytes": (2 * 128 ** 3 * C * 2 * B) + 27 * C * C * 2, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops}
 
 
 def encoder_forward_hbm(model, x, dev):

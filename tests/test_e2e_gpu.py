@@ -245,3 +245,93 @@ def test_reference_style_driver_loop(fwd):
     keys = list(model.state_dict().keys())
     assert all(k.startswith("module.") for k in keys) and len(keys) == 131
     assert "module.sparse_encoder.sp_cnn.conv_blocks_context.0.0.conv1.weight" in keys
+
+
+def test_depth2_blocks_identity_shortcut_vs_oracle():
+    """STUNet-L/H style stages (depth > 1): blocks after the first have no 1x1 conv, the residual is the block input
+    (P/STUNet_head.py:99-103).  Forward + gradients against the CPU oracle on the same box."""
+    from anatomask_amd import modules as M
+    cfg = O.Config([8, 16, 32, 64, 128, 128], [2, 2, 2, 2, 2, 2], 128, (32, 32, 48), 0.6)
+    W = O.closed_form_state(cfg, salt=0.3)
+    assert len(W) == 131 + 5 * 8                       # 8 more entries per extra block
+    x = np_volume(2, cfg.input_size, 91)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(9))
+    loss_o, rl_o, g_o, _ = O.student_loss_and_grads(cfg, W, x, mask)
+    m = M.build_spark(cfg.dims, cfg.depth, cfg.width, cfg.input_size, cfg.mask_ratio)
+    assert list(m.state_dict().keys()) == list(W.keys())
+    m.load_state_dict({k: v.clone() for k, v in W.items()})
+    m = m.to(DEV).train()
+    inp, rec = m(x.to(DEV), active_b1ff=mask.to(DEV))
+    loss, rl = m.forward_loss(inp, rec, mask.to(DEV))
+    assert abs(loss.item() - float(loss_o)) < 2e-4 * abs(float(loss_o)), (loss.item(), float(loss_o))
+    assert rel_err(rl.detach().cpu().numpy(), rl_o.numpy()) < 2e-4
+    loss.backward()
+    for k, p in m.named_parameters():
+        if g_o[k] is None:
+            assert p.grad is None, k
+            continue
+        if float(g_o[k].norm()) < 1e-6:
+            continue
+        a, b = p.grad.cpu().double().flatten(), g_o[k].double().flatten()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        big = a.numel() >= 256
+        assert cos > (0.99 if big else 0.95) and abs(float(a.norm() / b.norm()) - 1) < (GRAD_RTOL if big else 0.15), (k, cos, float(a.norm()), float(b.norm()))
+
+
+def test_trainer_distributed_path_single_rank_nccl():
+    """The RCCL exchange path with world_size 1 (all that one GPU allows): broadcast, per-group async all-reduce from the
+    backward hook, averaging; must give the same step as the non-distributed trainer."""
+    import os
+    import torch.distributed as dist
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    r, f = load("train_tiny.npz"), load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    W0 = O.closed_form_state(cfg)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        ep, tot = (int(v) for v in r["epoch"])
+        x = np_volume(int(f["B"]), cfg.input_size, r["x_seeds"][0]).to(DEV)
+        outs = []
+        for distributed in (False, True):
+            m = make_model(cfg, W0)
+            tr = AnatoMaskTrainer(m, lr=float(r["lr"]), ema_decay=float(r["ema_decay"]), total_epochs=tot + 1, distributed=distributed)
+            o = tr.step(x, epoch=ep, mask1=torch.from_numpy(r["mask1"][0]), keys=torch.from_numpy(r["keys"][0]))
+            outs.append((o["loss"].item(), o["grad_norm"].item()))
+        assert abs(outs[0][0] - outs[1][0]) < 1e-6 and abs(outs[0][1] - outs[1][1]) < 1e-3 * outs[0][1], outs
+        assert abs(outs[1][0] - r["losses"][0]) < 3e-4 * abs(r["losses"][0])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_checkpoint_roundtrip_and_finetune_handoff(tmp_path):
+    """Reference checkpoint format (P/pretrain_AntoMask.py:472-479), resume, and the key contract of
+    load_stunet_ssl_weights (nnunetv2/run/load_pretrained_weights.py:66-106)."""
+    from anatomask_amd import checkpoint
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    r, f = load("train_tiny.npz"), load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    W0 = O.closed_form_state(cfg)
+    x = np_volume(int(f["B"]), cfg.input_size, 5).to(DEV)
+
+    def fresh():
+        return AnatoMaskTrainer(make_model(cfg, W0), lr=1e-3, ema_decay=0.99, total_epochs=1000, distributed=False, seed=1)
+    a = fresh()
+    a.step(x, epoch=500)
+    p = str(tmp_path / "STUNet_B_head_latest.pt")
+    checkpoint.save_checkpoint(p, a, [1.0], 0)
+    ck = torch.load(p, weights_only=False)
+    assert set(["network_weights", "optimizer_state", "grad_scaler_state", "train_loss", "current_epoch"]) <= set(ck)
+    assert ck["grad_scaler_state"] is None and len(ck["network_weights"]) == 131
+    enc = checkpoint.encoder_weights_for_finetuning(ck["network_weights"])
+    assert len(enc) == 50 and "conv_blocks_context.0.0.conv1.weight" in enc and all(k.startswith("conv_blocks_context.") for k in enc)
+    b = fresh()
+    assert checkpoint.load_checkpoint(p, b) == 1
+    oa, ob = a.step(x, epoch=500), b.step(x, epoch=500)          # same RNG state, weights, moments, teacher -> same step
+    assert abs(oa["loss"].item() - ob["loss"].item()) < 1e-6
+    assert torch.equal(oa["mask"], ob["mask"])
+    bad = tot = 0                                                # resumed and original runs differ by atomic-order noise only;
+    for (k, u), (_, v) in zip(a.model.state_dict().items(), b.model.state_dict().items()):   # Adam (lr 1e-3) can flip noise-level elements
+        if u.is_floating_point():
+            bad += int(((u - v).abs() > 2e-4).sum()); tot += u.numel()
+    assert bad / tot < 5e-3, bad / tot
