@@ -61,6 +61,8 @@ class Tape:
         self.dec: List[dict] = []          # one per UNetBlock
         self.last: Optional[torch.Tensor] = None
         self.counts: Dict[int, torch.Tensor] = {}
+        self.recompute = False
+        self.enc_in: List[Optional[torch.Tensor]] = []   # recompute mode: the input map of every encoder stage
 
 
 def _counts(mask: MaskInfo, levels: Sequence[int]) -> Dict[int, torch.Tensor]:
@@ -86,7 +88,7 @@ def _sparse_norm(x, mask, bs, counts, gamma, beta, eps, part=None) -> NormStats:
     return st
 
 
-def _batch_norm(x, W, prefix, train: bool, part=None) -> NormStats:
+def _batch_norm(x, W, prefix, train: bool, part=None, update_running: bool = True) -> NormStats:
     st = NormStats(x.shape[-1], x.device)
     if train:
         st.count_host = float(x.numel() // x.shape[-1])
@@ -95,9 +97,12 @@ def _batch_norm(x, W, prefix, train: bool, part=None) -> NormStats:
             st.nrep = 1
         else:
             ops.chan_stats(x, None, 0, st)
-        ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"],
-                          W[f"{prefix}.running_var"], 0.1)
-        W[f"{prefix}.num_batches_tracked"].add_(1)
+        if update_running:
+            ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"],
+                              W[f"{prefix}.running_var"], 0.1)
+            W[f"{prefix}.num_batches_tracked"].add_(1)
+        else:                                     # recomputation pass: same batch statistics, running stats already updated
+            ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5)
     else:
         ops.norm_fold_running(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], W[f"{prefix}.running_mean"],
                               W[f"{prefix}.running_var"], 1e-5)
@@ -124,49 +129,75 @@ class PackCache:
 
 
 # ====================================================================================== forward
-def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
-            tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False):
-    """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps)."""
+def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
+    """One BasicResBlock (P/STUNet_head.py:96-103) -> (out, record for backward)."""
     dt = pk.dtype
-    B = inp.shape[0]
+    bs = 4 - s
+    p = f"{ENC}.{s}.{b}"
+    first = b == 0
+    stride = 2 if (first and s > 0) else 1
+    rec_ = {"p": p, "s": s, "first": first, "stride": stride, "x": x}
+    if s == 0 and first:
+        y1, pt1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt), None
+    else:
+        y1, pt1 = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv1.weight", False, False), W[f"{p}.conv1.bias"], sp, 3, stride,
+                             in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs,
+                             want_partials=True)
+    st1 = _sparse_norm(y1, mask, bs, counts, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], 1e-5, pt1)
+    a1 = ops.norm_apply(y1, st1, ACT_LRELU, mask, bs)
+    y2, pt2 = ops.conv3d(CONV_FWD, a1, pk.get(W, f"{p}.conv2.weight", False, False), W[f"{p}.conv2.bias"], sp, 3, 1,
+                         in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs, want_partials=True)
+    st2 = _sparse_norm(y2, mask, bs, counts, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], 1e-5, pt2)
+    if s == 0 and first:      # 1x1 Cin=1 shortcut folded into the apply pass
+        out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, stem=(inp, W[f"{p}.conv3.weight"].view(-1), W[f"{p}.conv3.bias"]))
+    elif first:
+        sc = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv3.weight", False, False), W[f"{p}.conv3.bias"], sp, 1, stride,
+                        in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs)
+        out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, res=sc)
+    else:
+        out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, res=x)
+    rec_.update(y1=y1, st1=st1, a1=a1, y2=y2, st2=st2, out=out)
+    return out, rec_
+
+
+def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True):
+    """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record)."""
+    q = f"{DEC}.{i}"
+    so = tuple(2 * v for v in x.shape[1:4])
+    u = ops.conv3d(CONVT_FWD, x, pk.get(W, f"{q}.up_sample.weight", True, False), W[f"{q}.up_sample.bias"], so, 4, 2)
+    c1, pt1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1, want_partials=train), None
+    if train:
+        c1, pt1 = c1
+    st1 = _batch_norm(c1, W, f"{q}.conv.1", train, pt1, update_running)
+    r = ops.norm_apply(c1, st1, ACT_RELU6)
+    c2, pt2 = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1, want_partials=train), None
+    if train:
+        c2, pt2 = c2
+    st2 = _batch_norm(c2, W, f"{q}.conv.4", train, pt2, update_running)
+    o = ops.norm_apply(c2, st2, ACT_NONE, res=nxt)            # x = x + to_dec[i+1] fused into the BN apply
+    return o, {"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2}
+
+
+def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
+            tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False, recompute: bool = False):
+    """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps).
+    recompute=True is the P/GC.py policy (torch.utils.checkpoint per encoder stage :324 and per decoder block :68): the tape
+    keeps only stage / block INPUTS; backward re-runs that stage's forward before differentiating it."""
     counts = _counts(mask, range(5))
     if tape is not None:
         tape.counts = counts
+        tape.recompute = recompute
     feats = []
     x = None
     # ------------------------------------------------------------------ sparse encoder
     for s in range(spec.n_stage):
-        bs = 4 - s
         sp = spec.stage_spatial(s)
+        if tape is not None and recompute:
+            tape.enc_in.append(x)
         for b in range(spec.depth[s]):
-            p = f"{ENC}.{s}.{b}"
-            first = b == 0
-            stride = 2 if (first and s > 0) else 1
-            rec_ = {"p": p, "s": s, "first": first, "stride": stride, "x": x}
-            if s == 0 and first:
-                y1, pt1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt), None
-            else:
-                y1, pt1 = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv1.weight", False, False), W[f"{p}.conv1.bias"], sp, 3, stride,
-                                     in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs,
-                                     want_partials=True)
-            st1 = _sparse_norm(y1, mask, bs, counts, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], 1e-5, pt1)
-            a1 = ops.norm_apply(y1, st1, ACT_LRELU, mask, bs)
-            y2, pt2 = ops.conv3d(CONV_FWD, a1, pk.get(W, f"{p}.conv2.weight", False, False), W[f"{p}.conv2.bias"], sp, 3, 1,
-                                 in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs, want_partials=True)
-            st2 = _sparse_norm(y2, mask, bs, counts, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], 1e-5, pt2)
-            if s == 0 and first:      # 1x1 Cin=1 shortcut folded into the apply pass
-                out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs,
-                                     stem=(inp, W[f"{p}.conv3.weight"].view(-1), W[f"{p}.conv3.bias"]))
-            elif first:
-                sc = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv3.weight", False, False), W[f"{p}.conv3.bias"], sp, 1, stride,
-                                in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs)
-                out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, res=sc)
-            else:
-                out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, res=x)
-            if tape is not None:
-                rec_.update(y1=y1, st1=st1, a1=a1, y2=y2, st2=st2, out=out)
+            x, rec_ = _enc_block(W, pk, inp, mask, counts, sp, s, b, x)
+            if tape is not None and not recompute:
                 tape.enc.append(rec_)
-            x = out
         feats.append(x)
     if encoder_only:
         return feats
@@ -189,22 +220,10 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
     # ------------------------------------------------------------------ dense decoder
     x = to_dec[0]
     for i in range(n_dec):
-        q = f"{DEC}.{i}"
-        so = tuple(2 * v for v in x.shape[1:4])
-        u = ops.conv3d(CONVT_FWD, x, pk.get(W, f"{q}.up_sample.weight", True, False), W[f"{q}.up_sample.bias"], so, 4, 2)
-        c1, pt1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1, want_partials=train), None
-        if train:
-            c1, pt1 = c1
-        st1 = _batch_norm(c1, W, f"{q}.conv.1", train, pt1)
-        r = ops.norm_apply(c1, st1, ACT_RELU6)
-        c2, pt2 = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1, want_partials=train), None
-        if train:
-            c2, pt2 = c2
-        st2 = _batch_norm(c2, W, f"{q}.conv.4", train, pt2)
-        nxt = to_dec[i + 1] if i + 1 < n_dec else None       # x = x + to_dec[i+1] fused into the BN apply
-        o = ops.norm_apply(c2, st2, ACT_NONE, res=nxt)
+        nxt = to_dec[i + 1] if i + 1 < n_dec else None
+        o, rec_ = _dec_block(W, pk, i, x, nxt, train)
         if tape is not None:
-            tape.dec.append({"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2})
+            tape.dec.append({"q": rec_["q"], "xin": x, "nxt": nxt} if recompute else rec_)
         x = o
     rec = ops.proj_fwd(x, W["dense_decoder.proj.weight"].view(-1), W["dense_decoder.proj.bias"])
     if tape is not None:
@@ -231,6 +250,9 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
     dproj: List[Optional[torch.Tensor]] = [None] * n_dec
     for i in reversed(range(n_dec)):
         t = tape.dec[i]
+        if tape.recompute:                        # P/GC.py:68: re-run the block forward from its saved input
+            _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False)
+            tape.dec[i] = None
         q = t["q"]
         if i + 1 < n_dec:
             dproj[i + 1] = g
@@ -279,6 +301,12 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
         by_stage.setdefault(t["s"], []).append(t)
     for s in reversed(range(spec.n_stage)):
         bs = 4 - s
+        if tape.recompute:                        # P/GC.py:324: re-run the stage forward from its saved input
+            xs, recs = tape.enc_in[s], []
+            for b in range(spec.depth[s]):
+                xs, r_ = _enc_block(W, pk, inp, mask, counts, spec.stage_spatial(s), s, b, xs)
+                recs.append(r_)
+            by_stage[s] = recs
         gout = gstage[s]
         assert gout is not None
         for t in reversed(by_stage[s]):
@@ -303,6 +331,8 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
             bsx = bs + (1 if stride == 2 else 0)
             spx = tuple(x.shape[1:4])
             _wgrad_into(G, f"{p}.conv1.weight", CONV_FWD, x, dy1, 3, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
+            if tape.recompute:
+                t["y1"] = t["a1"] = t["y2"] = t["out"] = None      # free as we go
             if t["first"]:
                 # block input = output map of stage s-1: add onto its densify gradient if it has one
                 base = gstage[s - 1]

@@ -179,7 +179,7 @@ class _SparKFn(torch.autograd.Function):
     def forward(ctx, model: "SparK", inp_b1, mask_info, *params):
         need_grad = any(ctx.needs_input_grad[3:])          # False under torch.no_grad() (teacher pass)
         tape = engine.Tape() if need_grad else None
-        rec = engine.forward(model.spec, model._W, model._pack, inp_b1, mask_info, model.training, tape)
+        rec = engine.forward(model.spec, model._W, model._pack, inp_b1, mask_info, model.training, tape, recompute=model.recompute)
         ctx.model, ctx.tape, ctx.inp, ctx.mask = model, tape, inp_b1, mask_info
         return rec
 
@@ -222,8 +222,9 @@ class SparK(nn.Module):
     patchify/unpatchify, get_config, state_dict(with_config), load_state_dict)."""
 
     def __init__(self, sparse_encoder: SparseEncoder, dense_decoder: LightDecoder, mask_ratio=0.6, densify_norm="in", sbn=False,
-                 compute_dtype: torch.dtype = torch.float32):
+                 compute_dtype: torch.dtype = torch.float32, recompute: bool = False):
         super().__init__()
+        self.recompute = recompute        # P/GC.py policy: recompute encoder stages / decoder blocks in backward
         input_size, downsample_ratio = sparse_encoder.input_size, sparse_encoder.downsample_ratio
         self.downsample_ratio = downsample_ratio
         self.fmap_h, self.fmap_w, self.fmap_d = (input_size[0] // downsample_ratio, input_size[1] // downsample_ratio,
@@ -520,12 +521,13 @@ def ema_decay_for_epoch(i: int, total_epochs: int) -> float:
     return 0.999 + i / q * (0.9999 - 0.999) if i < q else 0.9999
 
 
-def build_spark(dims, depth, width, input_size, mask_ratio=0.6, compute_dtype=torch.float32) -> SparK:
+def build_spark(dims, depth, width, input_size, mask_ratio=0.6, compute_dtype=torch.float32, recompute=False) -> SparK:
     """The model build of P/pretrain_AntoMask.py:184-217 in one call."""
     head = STUNet(1, 1, depth=list(depth), dims=list(dims))
     enc = SparseEncoder(head, input_size=tuple(input_size), sbn=False)
     dec = LightDecoder(enc.downsample_ratio, sbn=False, width=width, out_channel=1)
-    return SparK(sparse_encoder=enc, dense_decoder=dec, mask_ratio=mask_ratio, densify_norm="in", compute_dtype=compute_dtype)
+    return SparK(sparse_encoder=enc, dense_decoder=dec, mask_ratio=mask_ratio, densify_norm="in", compute_dtype=compute_dtype,
+                 recompute=recompute)
 
 
 STUNET_CONFIGS = {   # P/pretrain_AntoMask.py:188-196, P/pretrain_AnatoMask_DDP.py:223-229

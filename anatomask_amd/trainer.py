@@ -106,7 +106,7 @@ class AnatoMaskTrainer:
         mi = ops.MaskInfo(mk.view(B, *spec.fmap))
         # 4. student forward + loss (:429-430)
         tape = engine.Tape()
-        rec = engine.forward(spec, m._W, m._pack, x, mi, train=True, tape=tape)
+        rec = engine.forward(spec, m._W, m._pack, x, mi, train=True, tape=tape, recompute=m.recompute)
         l2m, pm, pr, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
         drec = ops.patch_loss_bwd(x, rec, mi, pm, pr, info, None)
         # 5. backward (:435) with overlapped gradient exchange

@@ -335,3 +335,30 @@ def test_checkpoint_roundtrip_and_finetune_handoff(tmp_path):
         if u.is_floating_point():
             bad += int(((u - v).abs() > 2e-4).sum()); tot += u.numel()
     assert bad / tot < 5e-3, bad / tot
+
+
+def test_recompute_mode_matches_plain_backward():
+    """P/GC.py policy (checkpoint per encoder stage / decoder block): same loss, same gradients, BN buffers updated once."""
+    from anatomask_amd import modules as M
+    cfg = O.Config([8, 16, 32, 64, 128, 128], [2, 1, 2, 1, 1, 1], 128, (32, 32, 48), 0.6)
+    W = O.closed_form_state(cfg, salt=0.7)
+    x = np_volume(2, cfg.input_size, 3).to(DEV)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(4)).to(DEV)
+    res = []
+    for rc in (False, True):
+        m = M.build_spark(cfg.dims, cfg.depth, cfg.width, cfg.input_size, cfg.mask_ratio, recompute=rc)
+        m.load_state_dict({k: v.clone() for k, v in W.items()})
+        m = m.to(DEV).train()
+        inp, rec = m(x, active_b1ff=mask)
+        loss, _ = m.forward_loss(inp, rec, mask)
+        loss.backward()
+        res.append((loss.item(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None},
+                    {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k}))
+    assert res[0][0] == res[1][0]
+    for k in res[0][1]:
+        a, b = res[0][1][k], res[1][1][k]
+        if a.abs().max().item() < 1e-6:
+            continue                                   # analytically-zero conv-bias gradients: float noise
+        assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item(), k      # fp32 atomics order only
+    for k in res[0][2]:
+        assert torch.equal(res[0][2][k], res[1][2][k]), k
