@@ -108,9 +108,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // Buffer descriptors (wave-uniform): loads take a per-lane 32-bit byte offset + an SGPR offset, so the slab / tap
   // advance costs no vector instruction, and any offset >= num_records reads back as zero -- the hardware does the
   // zero-fill of halo voxels that are out of range or belong to inactive patches (sentinel offset 0x80000000).
-  const size_t sample_elems = (size_t)a.Di * a.Hi * a.Wi * a.Cin;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)((const T*)a.x + (size_t)b * sample_elems), 0,
-                                                                      (int)(sample_elems * sizeof(T)), 0x00020000);
+  // The source descriptor is anchored at the first d-plane this workgroup can touch (not at the sample start), so the 32-bit
+  // offsets only span the brick's few planes: tensors of any size work (STUNet-H 192^3 x 192 ch is 2.7 GB per sample).
+  const size_t plane_elems = (size_t)a.Hi * a.Wi * a.Cin;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const int cchunk = (tid & 3) * EPC;                    // this thread's channel offset inside the slab
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int nvox = ED * EH * EW;
     const int upd = (a.upar[un] >> 2) & 1, uph = (a.upar[un] >> 1) & 1, upw = a.upar[un] & 1;
     const int i0d = q0d + a.mind[un], i0h = q0h + a.minh[un], i0w = q0w + a.minw[un];   // brick origin in sub-lattice voxels
+    int dbase = i0d * a.GS + upd; dbase = dbase < 0 ? 0 : (dbase > a.Di ? a.Di : dbase);
+    const size_t left = (size_t)(a.Di - dbase) * plane_elems * sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)a.x + ((size_t)b * a.Di + dbase) * plane_elems), 0, (int)(left < 0x7fffff00ull ? left : 0x7fffff00ull), 0x00020000);
 
     // ---- per-thread staging plan for this unit's source brick: byte offset of this thread's chunk in each of its rows ----
     unsigned soff[NIT];
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int ey = (rem * mW) >> 20, ex = rem - ey * EW;       // ~35-instruction integer divisions
         const int id = (i0d + ez) * a.GS + upd, ih = (i0h + ey) * a.GS + uph, iw = (i0w + ex) * a.GS + upw;
         if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw))
-          soff[it] = (unsigned)((((id * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T));
+          soff[it] = (unsigned)(((((id - dbase) * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T));
       }
     }
     int bb[VS];                                          // LDS byte offset of this lane's voxel-row chunk, tap shift excluded
@@ -451,7 +455,7 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   am_packed_dims(dtype, Cout, Cin, &a.Coutp, &a.Cinp);
   a.w_bytes = ksize * ksize * ksize * a.Coutp * a.Cinp * (dtype == AM_DT_BF16 ? 2 : 4);
-  if ((size_t)Di * Hi * Wi * Cin * 4 >= 0x7fffffffull) return -5;   // per-sample tensor must stay below 2 GB (32-bit buffer offsets)
+  if ((size_t)24 * Hi * Wi * Cin * 4 >= 0x7fffff00ull) return -5;   // the <= 24 source planes a brick spans must stay below 2 GB (32-bit offsets)
   const int Qd = (Do + a.OS - 1) / a.OS, Qh = (Ho + a.OS - 1) / a.OS, Qw = (Wo + a.OS - 1) / a.OS;
   a.nbd = (Qd + P.bd - 1) / P.bd; a.nbh = (Qh + P.bh - 1) / P.bh; a.nbw = (Qw + P.bw - 1) / P.bw;
   a.in_mask = MaskView{in_mask, fd, fh, fw, in_bshift};

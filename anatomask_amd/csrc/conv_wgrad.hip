@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const T* __restrict__ xg = (const T*)a.x;
   const T* __restrict__ yg = (const T*)a.dy;
   const int nbrick = a.B * a.nbd * a.nbh * a.nbw;
-  const size_t ysample = (size_t)a.Dy * a.Hy * a.Wy * a.Cy, xsample = (size_t)a.Dx * a.Hx * a.Wx * a.Cx;
+  const size_t yplane = (size_t)a.Hy * a.Wy * a.Cy, xplane = (size_t)a.Hx * a.Wx * a.Cx;
 
   for (int brick = slot; brick < nbrick; brick += a.split) {
     int bid = brick;
@@ -130,10 +130,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     // ---- addresses + validity of this brick's rows (clamped; zero-selected after the load) ----
     int yv[NITY], xv[NITX];
     unsigned yok = 0, xok = 0;
-    const int ybase = ((q0d * a.OS + pd) * a.Hy + q0h * a.OS + ph) * a.Wy + q0w * a.OS + pw;   // relative to sample b
-    const int xbase = (i0d * a.Hx + i0h) * a.Wx + i0w;
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + (size_t)b * ysample), 0, (int)(ysample * sizeof(T)), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + (size_t)b * xsample), 0, (int)(xsample * sizeof(T)), 0x00020000);
+    // descriptors anchored at the first d-plane of this brick (32-bit offsets span a few planes only: any tensor size works)
+    const int yd0 = q0d * a.OS + pd < a.Dy ? q0d * a.OS + pd : a.Dy, xd0 = i0d < 0 ? 0 : (i0d > a.Dx ? a.Dx : i0d);
+    const int ybase = ((q0d * a.OS + pd - yd0) * a.Hy + q0h * a.OS + ph) * a.Wy + q0w * a.OS + pw;   // relative to plane yd0 of sample b
+    const int xbase = ((i0d - xd0) * a.Hx + i0h) * a.Wx + i0w;
+    const size_t yleft = (size_t)(a.Dy - yd0) * yplane * sizeof(T), xleft = (size_t)(a.Dx - xd0) * xplane * sizeof(T);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + ((size_t)b * a.Dy + yd0) * yplane), 0,
+                                                                        (int)(yleft < 0x7fffff00ull ? yleft : 0x7fffff00ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + ((size_t)b * a.Dx + xd0) * xplane), 0,
+                                                                        (int)(xleft < 0x7fffff00ull ? xleft : 0x7fffff00ull), 0x00020000);
     // interior brick of a dense tensor (wave-uniform): everything in range, one add per row instead of the bounds logic
     const bool interior = !a.x_mask.m && !a.y_mask.m && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + (ED - 1) * a.GS < a.Dx &&
                           i0h + (EH - 1) * a.GS < a.Hx && i0w + (EW - 1) * a.GS < a.Wx && (q0d + BD - 1) * a.OS + pd < a.Dy && (q0h + BH - 1) * a.OS + ph < a.Hy &&
@@ -274,7 +279,7 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
                                const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift,
                                int fd, int fh, int fw, void* stream) {
   if (Cx % 8 || Cy % 8) return -1;
-  if ((size_t)Dx * Hx * Wx * Cx * 4 >= 0x7fffffffull || (size_t)Dy * Hy * Wy * Cy * 4 >= 0x7fffffffull) return -5;
+  if ((size_t)8 * Hx * Wx * Cx * 4 >= 0x7fffff00ull || (size_t)8 * Hy * Wy * Cy * 4 >= 0x7fffff00ull) return -5;   // planes a brick spans
   WgArgs a;
   a.x = x; a.dy = dy; a.dw = dw_packed;
   a.B = B; a.Dx = Dx; a.Hx = Hx; a.Wx = Wx; a.Cx = Cx; a.Dy = Dy; a.Hy = Hy; a.Wy = Wy; a.Cy = Cy;

@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("AM_BENCH_BATCH", "4")), help="volumes per GPU per step")
     ap.add_argument("--size", default="B")
+    ap.add_argument("--patch", type=int, default=128)
+    ap.add_argument("--mask-ratio", type=float, default=0.6)
+    ap.add_argument("--recompute", action="store_true")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -129,12 +132,13 @@ def main():
     kw = M.STUNET_CONFIGS[a.size]
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     torch.manual_seed(0)                                            # identical init on every rank (+ broadcast in the trainer)
-    model = M.build_spark(kw["dims"], kw["depth"], kw["width"], (128, 128, 128), 0.6, compute_dtype=dtype)
-    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
+    model = M.build_spark(kw["dims"], kw["depth"], kw["width"], (a.patch,) * 3, a.mask_ratio, compute_dtype=dtype, recompute=a.recompute)
+    sd_cpu = ({k: v.clone() for k, v in model.state_dict().items()}
+              if (rank == 0 and world == 1 and not a.no_cpu_baseline and a.size == "B" and a.patch == 128) else None)
     model = model.to(dev)
     tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=4321 + rank)
     tr.set_epoch(500)
-    x = torch.randn(a.batch, 1, 128, 128, 128, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
+    x = torch.randn(a.batch, 1, a.patch, a.patch, a.patch, device=dev, generator=torch.Generator(device=dev).manual_seed(1234 + rank))
 
     for _ in range(a.warmup):
         out = tr.step(x, epoch=500)
@@ -157,14 +161,14 @@ def main():
 
     res = None
     if rank == 0:
-        res = {"metric": "pretrain volumes/sec @128^3 patch mask=0.6", "value": round(a.batch * world * a.steps / dt, 4),
+        res = {"metric": f"pretrain volumes/sec @{a.patch}^3 patch mask={a.mask_ratio}", "value": round(a.batch * world * a.steps / dt, 4),
                "unit": "volumes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-               "config": {"workload": f"STUNet-{a.size} AnatoMask step, 128^3 patch, mask_ratio 0.6, {a.dtype} storage/MFMA + fp32 master",
+               "config": {"workload": f"STUNet-{a.size} AnatoMask step, {a.patch}^3 patch, mask_ratio {a.mask_ratio}, {a.dtype} storage/MFMA + fp32 master",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                           "step": "teacher fwd + sampler + student fwd + loss + bwd + clip + AdamW + EMA"},
                "final_loss": round(loss, 5)}
-        if not a.no_roofline:
+        if not a.no_roofline and a.size == "B" and a.patch == 128:
             res["roofline"] = dominant_kernel_roofline(a.batch, dev)
             res["encoder_fwd_hbm"] = encoder_forward_hbm(model, x, dev)
     if world > 1:
