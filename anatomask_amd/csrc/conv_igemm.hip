@@ -232,46 +232,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   // ---- epilogue: D row = cout 4g+r, col = voxel r16 ----
   T* __restrict__ yg = (T*)a.y;
-  float ps1[NS][4], ps2[NS][4];
-#pragma unroll
-  for (int i = 0; i < NS; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ps1[i][r] = ps2[i][r] = 0.f;
   f32x4 bia[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int co = co0 + i * 16 + g * 4;
     bia[i] = (a.bias && co < a.Cout) ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const bool sparse_out = a.out_mask.m != nullptr;
 #pragma unroll
   for (int j = 0; j < VS; ++j) {
     const int v = wave * (MV / 4) + j * 16 + r16;
     const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
-    if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) continue;
-    const bool act = a.out_mask.active(b, od, oh, ow);
+    const bool inr = od < a.Do && oh < a.Ho && ow < a.Wo;
+    const bool act = inr && (!sparse_out || a.out_mask.active(b, od, oh, ow));
     const size_t ovox = ((size_t)(b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+    T* dstv = yg + ovox * a.Cout + co0 + g * 4;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      const int co = co0 + i * 16 + g * 4;
-      if (co >= a.Cout) continue;                        // Cout % 4 == 0 (C % 8 == 0 contract)
       f32x4 o = acc[i][j] + bia[i];
-      if (!act) o = f32x4{0.f, 0.f, 0.f, 0.f};
-      T* dst = yg + ovox * a.Cout + co;
-      if (a.accumulate && act) {
+      if (sparse_out && !act) o = f32x4{0.f, 0.f, 0.f, 0.f};
+      T* dst = dstv + i * 16;
+      const bool wr = inr && co0 + i * 16 + g * 4 < a.Cout;     // Cout % 4 == 0 (C % 8 == 0 contract)
+      if (a.accumulate && act && wr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] += TT<T>::ld(dst + r);
       }
       if constexpr (sizeof(T) == 4) {
-        *(f32x4*)dst = o;
+        if (wr) *(f32x4*)dst = o;
+        acc[i][j] = act && wr ? o : f32x4{0.f, 0.f, 0.f, 0.f};   // what was stored (for the statistics pass below)
       } else {
         typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
         const bfx4 pk = __builtin_convertvector(o, bfx4);      // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
-        *(bfx4*)dst = pk;
-        if (part) o = __builtin_convertvector(pk, f32x4);      // statistics of what was actually stored
-      }
-      if (part) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ps1[i][r] += o[r]; ps2[i][r] += o[r] * o[r]; }
+        if (wr) *(bfx4*)dst = pk;
+        if (part) acc[i][j] = act && wr ? __builtin_convertvector(pk, f32x4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
@@ -282,7 +275,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < NS; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float s1 = ps1[i][r], s2 = ps2[i][r];
+        float s1 = 0.f, s2 = 0.f;                        // sums over this lane's VS voxels of the STORED values
+#pragma unroll
+        for (int j = 0; j < VS; ++j) { const float o = acc[i][j][r]; s1 += o; s2 += o * o; }
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
         if (r16 == 0) {
