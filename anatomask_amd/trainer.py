@@ -19,8 +19,9 @@ from .modules import ModelEma, SparK, ema_decay_for_epoch
 class AnatoMaskTrainer:
     def __init__(self, model: SparK, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  clip: float = 12.0, ema_decay: float = 0.999, total_epochs: int = 1000, guide: bool = True, seed: int = 4321,
-                 process_group=None, distributed: Optional[bool] = None):
+                 process_group=None, distributed: Optional[bool] = None, self_distill: bool = True):
         self.model = model
+        self.self_distill = self_distill      # False: plain SparK step (P/spark3D.py:98-146, P/pretrain.py): random mask, no teacher
         model._ensure_flat()
         model.train()
         self.teacher = ModelEma(model, decay=ema_decay)
@@ -94,16 +95,19 @@ class AnatoMaskTrainer:
         else:
             m1 = mask1.reshape(B, L).to(device=dev, dtype=torch.uint8).contiguous()
         mi1 = ops.MaskInfo(m1.view(B, *spec.fmap))
-        # 2. teacher pass + raw per-patch loss (:421-425)
-        rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False)
-        recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
-        del rec1
-        # 3. hard-mask sampler (:427)
-        ll = m.len_loss_for(L, m.len_keep, epoch, self.total_epochs - 1, self.guide)
-        if keys is None:
-            keys = torch.rand(B, L, device=dev, generator=self.gen)
-        mk = ops.mask_sampler(recon, keys.to(dev).float().contiguous(), m.len_keep, ll)
-        mi = ops.MaskInfo(mk.view(B, *spec.fmap))
+        if self.self_distill:
+            # 2. teacher pass + raw per-patch loss (:421-425)
+            rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False)
+            recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
+            del rec1
+            # 3. hard-mask sampler (:427)
+            ll = m.len_loss_for(L, m.len_keep, epoch, self.total_epochs - 1, self.guide)
+            if keys is None:
+                keys = torch.rand(B, L, device=dev, generator=self.gen)
+            mk = ops.mask_sampler(recon, keys.to(dev).float().contiguous(), m.len_keep, ll)
+            mi = ops.MaskInfo(mk.view(B, *spec.fmap))
+        else:                                                     # plain SparK: the random mask IS the student mask
+            recon, mk, mi = None, m1, mi1
         # 4. student forward + loss (:429-430)
         tape = engine.Tape()
         rec = engine.forward(spec, m._W, m._pack, x, mi, train=True, tape=tape, recompute=m.recompute)
@@ -119,8 +123,11 @@ class AnatoMaskTrainer:
         n = m._live_end
         decay = self.teacher.decay if ema_decay is None else ema_decay
         ops.sumsq(m._gflat[:n], self.sumsq)
-        ops.adamw_ema(m._flat, m._gflat, self.m, self.v, t._flat, n, self.lr if lr is None else lr, self.betas, self.eps, self.wd,
-                      self.step_count, self.sumsq, self.clip, decay, self.gnorm)
+        ops.adamw_ema(m._flat, m._gflat, self.m, self.v, t._flat if self.self_distill else None, n, self.lr if lr is None else lr,
+                      self.betas, self.eps, self.wd, self.step_count, self.sumsq, self.clip, decay, self.gnorm)
+        if not self.self_distill:
+            m.weights_changed()
+            return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": None, "rec_loss": l2m}
         if m._flat.numel() > n:                                   # dead densify[4] tensors: EMA only (no optimizer step)
             ops.ema(t._flat[n:], m._flat[n:], decay)
         ops.ema(t._bflat, m._bflat, decay)                        # BN running stats are EMA'd too (timm: every state_dict entry)

@@ -362,3 +362,21 @@ def test_recompute_mode_matches_plain_backward():
         assert (a - b).abs().max().item() <= 1e-4 * a.abs().max().item(), k      # fp32 atomics order only
     for k in res[0][2]:
         assert torch.equal(res[0][2][k], res[1][2][k]), k
+
+
+def test_plain_spark_step_vs_oracle():
+    """Plain SparK step (P/spark3D.py:98-146 / P/pretrain.py: random mask, loss on the student only, no teacher)."""
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    f = load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    W0 = O.closed_form_state(cfg)
+    x = np_volume(2, cfg.input_size, 41)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(8))
+    loss_o, _, grads, _ = O.student_loss_and_grads(cfg, {k: v.clone() for k, v in W0.items()}, x, mask)
+    live = {k: g for k, g in grads.items() if g is not None}
+    gn_o = float(O.clip_grad_norm(live, 12.0))
+    tr = AnatoMaskTrainer(make_model(cfg, W0), lr=1e-3, total_epochs=1000, distributed=False, self_distill=False)
+    o = tr.step(x.to(DEV), epoch=0, mask1=mask)
+    assert torch.equal(o["mask"].cpu().bool().view(mask.shape), mask)
+    assert abs(o["loss"].item() - float(loss_o)) < 2e-4 * abs(float(loss_o))
+    assert abs(o["grad_norm"].item() - gn_o) < 5e-2 * gn_o
