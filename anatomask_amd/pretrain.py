@@ -58,6 +58,7 @@ def main(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--data", default=None); ap.add_argument("--out", default="anatomask_run")
     ap.add_argument("--resume", default=None)
+    ap.add_argument("--plain-spark", action="store_true", help="plain SparK baseline (P/pretrain.py): random mask, no teacher")
     a = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -70,7 +71,8 @@ def main(argv=None):
     kw = STUNET_CONFIGS[a.model]
     model = build_spark(kw["dims"], kw["depth"], kw["width"], tuple(a.input_size), a.mask_ratio,
                         compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32).to(dev)
-    trainer = AnatoMaskTrainer(model, lr=a.lr, weight_decay=a.weight_decay, clip=a.clip, total_epochs=a.epochs, seed=4321 + rank)
+    trainer = AnatoMaskTrainer(model, lr=a.lr, weight_decay=a.weight_decay, clip=a.clip, total_epochs=a.epochs, seed=4321 + rank,
+                               self_distill=not a.plain_spark)
     lrs = linear_warmup_cosine_lrs(a.epochs, a.lr, a.warmup, 1e-6)                    # :359
     start = checkpoint.load_checkpoint(a.resume, trainer) if a.resume else 0
     files = sorted(glob.glob(os.path.join(a.data, "*.npy"))) if a.data else None
