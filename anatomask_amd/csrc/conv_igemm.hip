@@ -41,9 +41,10 @@ struct ConvArgs {
   int ed[8], eh[8], ew[8];    // LDS source-brick extents per class
   int mdiv_w[8], mdiv_hw[8];  // 2^20-scaled reciprocals of ew and ew*eh (exact floor division for e < 1024)
   int w_bytes;                // size of the packed weight buffer
-  int w_lds_off, tap_lds_off; // byte offsets of the weight-group buffers / tap table inside dynamic LDS
+  int w_lds_off;              // byte offset of the weight-group buffers inside dynamic LDS
   MaskView in_mask, out_mask;
   int accumulate;
+  int dbg;                    // AM_CV_DBG ablation bits (timing experiments only): 1 no stores, 2 no source loads, 4 no weight loads
 };
 
 constexpr int ROWB = 64;      // channel-slab bytes staged per voxel / per weight row (unpadded, XOR-swizzled)
@@ -54,6 +55,11 @@ constexpr int TG_OF(int ns) { return ns == 2 ? 6 : 3; }   // taps per weight gro
 // With this swizzle a ds_read_b128 of 16 consecutive rows (any alignment) x 4 chunks is bank-conflict free
 // (brute-forced over the four 16-lane groups of the instruction, MI355X_MICROARCH.md "LDS").
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 6) + ((chunk ^ ((row >> 1) & 2)) << 4); }
+
+// MFMA tile row -> output channel.  D row 4g+r of cout tile i lands in lane group g, register r; rows are assigned so that
+// a lane's registers of tiles (2h, 2h+1) are the 8 CONSECUTIVE channels h*32 + g*8 .. +8: the epilogue stores 16 bytes per
+// lane and the 4 lane groups of a voxel write one contiguous 64-byte run (instead of 8-byte pieces of four 32-byte runs).
+__device__ __forceinline__ int crow(int R) { return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3); }
 
 template <typename T, int BD, int BH, int BW, int NS, int NIT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
@@ -69,7 +75,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   static_assert(MV % 64 == 0, "brick must give each wave whole 16-voxel subtiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* ldsW = lds + a.w_lds_off;
-  int* ldsTap = (int*)(lds + a.tap_lds_off);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
@@ -98,12 +103,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   const int u0 = a.OS == 2 ? cls : 0, u1 = a.OS == 2 ? cls + 1 : a.nunit;
 
-  // tap table -> LDS (all units of this workgroup): byte offset of the tap's window inside its unit's brick | widx << 20
-  for (int t = a.tap_begin[u0] + tid; t < a.tap_begin[u1]; t += 256) {
-    const int tp = a.taps[t];
+  // tap table -> one VGPR (lane t = tap t of the plan, <= 64 taps): byte offset of the tap's window inside its unit's brick | widx << 20.
+  // Taps are fetched with v_readlane (no LDS round trip in front of every weight load / fragment read).
+  int tapv;
+  {
+    const int tp = a.taps[lane];
     const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8, un = (tp >> 18) & 7;
-    ldsTap[t] = ((((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LROWB) | (((tp >> 12) & 63) << 20);
+    tapv = ((((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LROWB) | (((tp >> 12) & 63) << 20);
   }
+#define AM_TAP(T_) __builtin_amdgcn_readlane(tapv, tb + ((T_) < nt ? (T_) : nt - 1))
 
   // Buffer descriptors (wave-uniform): loads take a per-lane 32-bit byte offset + an SGPR offset, so the slab / tap
   // advance costs no vector instruction, and any offset >= num_records reads back as zero -- the hardware does the
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   for (int it = 0; it < WIT; ++it) {
     const int idx = tid + it * 256;
     const int row = (idx >> 2) % NT, tig = idx / (NT * 4);
-    wsrc[it] = (unsigned)(((co0 + row) * a.Cinp + (idx & 3) * EPC) * (int)sizeof(T));
+    wsrc[it] = (unsigned)(((co0 + crow(row)) * a.Cinp + (idx & 3) * EPC) * (int)sizeof(T));
     wdst[it] = idx < WCH ? tig * NT * ROWB + swz(row, idx & 3) : -1;
   }
   int aoff[NS];                                          // swizzled LDS offset of this lane's weight row chunk (tap 0 of a group)
@@ -136,17 +144,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < VS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // issue the loads of weight group GI (slab kc) into WR; the tap of a chunk is wave-uniform -> scalar offset.
-  // taps past the end of the unit (partial last group) load zeros through the out-of-range rule.
-#define AM_WLOAD(WR, GI)                                                                                   \
+  // issue the loads of weight group GI of slab KCW into WR; the tap of a chunk is wave-uniform -> scalar offset.
+  // taps past the end of the unit (partial last group) and !OK requests load zeros through the out-of-range rule.
+#define AM_WLOAD(WR, GI, KCW, OK)                                                                          \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
-    const int tt_ = (GI) * TG + (tid + it * 256) / (NT * 4);                                                \
-    const int wi_ = __builtin_amdgcn_readfirstlane(ldsTap[tb + (tt_ < nt ? tt_ : nt - 1)]) >> 20;           \
-    WR[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, tt_ < nt ? wsrc[it] : OOB, wi_ * wtapB + kc * (int)sizeof(T), 0)); \
+    const int tt_ = __builtin_amdgcn_readfirstlane((GI) * TG + (tid + it * 256) / (NT * 4));                \
+    const int wi_ = AM_TAP(tt_) >> 20;                                                                      \
+    WR[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tt_ < nt && (OK) && !(a.dbg & 4)) ? wsrc[it] : OOB, wi_ * wtapB + (KCW) * (int)sizeof(T), 0)); \
   }
 #define AM_WSTORE(WR, BUF)                                                                                 \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it)                                                        \
     if (wdst[it] >= 0) *(u32x4*)(ldsW + (BUF) * WBUF + wdst[it]) = WR[it];
+  // issue the loads of the source brick's channel slab KCS into stg (only a partial last slab, Cin % KC != 0, has !cok lanes)
+#define AM_SLOAD(KCS, OK)                                                                                  \
+  {                                                                                                        \
+    const bool cok_ = (KCS) + cchunk < a.Cin && (OK) && !(a.dbg & 2);                                       \
+    _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
+      stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, cok_ ? soff[it] : OOB, (KCS) * (int)sizeof(T), 0)); \
+  }
 
   for (int un = u0; un < u1; ++un) {
     const int tb = a.tap_begin[un], nt = a.tap_begin[un + 1] - tb;
@@ -183,34 +198,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       bb[j] = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * LROWB + g * 16;
     }
 
+    // Software pipeline over the channel slabs: the source brick of slab k+1 and the first weight group of slab k+1 are
+    // loaded into registers while the MFMAs of slab k issue (HBM latency of every slab but the first is hidden), and are
+    // written to LDS behind the barrier that ends slab k.
+    u32x4 stg[NIT], wr[WIT];
+    AM_SLOAD(0, true);
+    AM_WLOAD(wr, 0, 0, true);
     for (int kc = 0; kc < a.Cinp; kc += KC) {
-      __syncthreads();                                   // all fragment reads of the previous slab are done (tap table visible)
-      {
-        const bool cok = kc + cchunk < a.Cin;              // only false in a partial last slab (Cin % KC != 0)
-        u32x4 stg[NIT], wr0[WIT];
+      __syncthreads();                                   // all fragment reads of the previous slab / unit are done
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, cok ? soff[it] : OOB, kc * (int)sizeof(T), 0));
-        AM_WLOAD(wr0, 0);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it)
-          if (((tid + it * 256) >> 2) < nvox) *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
-        AM_WSTORE(wr0, 0);
-      }
+      for (int it = 0; it < NIT; ++it)
+        if (((tid + it * 256) >> 2) < nvox) *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
+      AM_WSTORE(wr, 0);
       __syncthreads();
+      const bool more_slabs = kc + KC < a.Cinp;
+      AM_SLOAD(kc + KC, more_slabs);                     // branch-free: past the last slab the loads are out-of-range (zeros, no traffic)
       for (int gi = 0; gi < ng; ++gi) {
         const int buf = gi & 1;
-        u32x4 wr[WIT];
         const bool more = gi + 1 < ng;
-        AM_WLOAD(wr, more ? gi + 1 : gi);                // next group's weights fly while this group's MFMAs issue (branch-free:
-                                                         // a conditional load makes hipcc drain vmcnt at the join)
+        // next group's weights (or group 0 of the next slab) fly while this group's MFMAs issue (branch-free:
+        // a conditional load makes hipcc drain vmcnt at the join)
+        AM_WLOAD(wr, more ? gi + 1 : 0, more ? kc : kc + KC, more || more_slabs);
         __builtin_amdgcn_sched_barrier(0);
         // straight-line over the TG taps of the group (padding taps multiply zero weights): no per-tap branch, so the
         // fragment reads of tap t+1 can be scheduled under the MFMAs of tap t
 #pragma unroll
         for (int tl = 0; tl < TG; ++tl) {
           const int tt = gi * TG + tl;
-          const int tob = __builtin_amdgcn_readfirstlane(ldsTap[tb + (tt < nt ? tt : nt - 1)]) & 0xFFFFF;
+          const int tob = AM_TAP(tt) & 0xFFFFF;
           u32x4 af[NS];
 #pragma unroll
           for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
@@ -222,20 +237,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) { AM_WSTORE(wr, buf ^ 1); }
-        __syncthreads();
+        if (more) { AM_WSTORE(wr, buf ^ 1); __syncthreads(); }
       }
     }
   }
+#undef AM_SLOAD
+#undef AM_TAP
 #undef AM_WLOAD
 #undef AM_WSTORE
 
-  // ---- epilogue: D row = cout 4g+r, col = voxel r16 ----
+  // ---- epilogue: D row 4g+r of tile i = channel crow(16i+4g+r), col = voxel r16 ----
   T* __restrict__ yg = (T*)a.y;
+  constexpr int NH = NS / 2;                             // 8-channel runs per lane and voxel
   f32x4 bia[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
-    const int co = co0 + i * 16 + g * 4;
+    const int co = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
     bia[i] = (a.bias && co < a.Cout) ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool sparse_out = a.out_mask.m != nullptr;
@@ -246,25 +263,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const bool inr = od < a.Do && oh < a.Ho && ow < a.Wo;
     const bool act = inr && (!sparse_out || a.out_mask.active(b, od, oh, ow));
     const size_t ovox = ((size_t)(b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-    T* dstv = yg + ovox * a.Cout + co0 + g * 4;
+    T* dstv = yg + ovox * a.Cout + co0 + g * 8;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      f32x4 o = acc[i][j] + bia[i];
-      if (sparse_out && !act) o = f32x4{0.f, 0.f, 0.f, 0.f};
-      T* dst = dstv + i * 16;
-      const bool wr = inr && co0 + i * 16 + g * 4 < a.Cout;     // Cout % 4 == 0 (C % 8 == 0 contract)
+    for (int h = 0; h < NH; ++h) {
+      f32x4 o0 = acc[2 * h][j] + bia[2 * h], o1 = acc[2 * h + 1][j] + bia[2 * h + 1];
+      if (sparse_out && !act) { o0 = f32x4{0.f, 0.f, 0.f, 0.f}; o1 = o0; }
+      T* dst = dstv + h * 32;
+      const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout && !(a.dbg & 1);     // Cout % 8 == 0 (C % 8 == 0 contract)
       if (a.accumulate && act && wr) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] += TT<T>::ld(dst + r);
+        for (int r = 0; r < 4; ++r) { o0[r] += TT<T>::ld(dst + r); o1[r] += TT<T>::ld(dst + 4 + r); }
       }
       if constexpr (sizeof(T) == 4) {
-        if (wr) *(f32x4*)dst = o;
-        acc[i][j] = act && wr ? o : f32x4{0.f, 0.f, 0.f, 0.f};   // what was stored (for the statistics pass below)
+        if (wr) { *(f32x4*)dst = o0; *(f32x4*)(dst + 4) = o1; }
+        acc[2 * h][j] = act && wr ? o0 : f32x4{0.f, 0.f, 0.f, 0.f};   // what was stored (for the statistics pass below)
+        acc[2 * h + 1][j] = act && wr ? o1 : f32x4{0.f, 0.f, 0.f, 0.f};
       } else {
         typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
-        const bfx4 pk = __builtin_convertvector(o, bfx4);      // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
-        if (wr) *(bfx4*)dst = pk;
-        if (part) acc[i][j] = act && wr ? __builtin_convertvector(pk, f32x4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+        const bfx4 p0 = __builtin_convertvector(o0, bfx4), p1 = __builtin_convertvector(o1, bfx4);   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+        if (wr) *(bfx8*)dst = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (part) {
+          acc[2 * h][j] = act && wr ? __builtin_convertvector(p0, f32x4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[2 * h + 1][j] = act && wr ? __builtin_convertvector(p1, f32x4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   }
@@ -281,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
         if (r16 == 0) {
-          const int c = i * 16 + g * 4 + r;
+          const int c = (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r;
           red[(wave * 16 * NS + c) * 2] = s1; red[(wave * 16 * NS + c) * 2 + 1] = s2;
         }
       }
@@ -349,8 +371,7 @@ int build_plan(Plan& P, int mode, int k, int stride) {
   size_t brick = mxv * LROWB;
   if (brick < 4096) brick = 4096;                        // the stats epilogue reuses the head of the brick
   a.w_lds_off = (int)brick;
-  a.tap_lds_off = a.w_lds_off + 2 * TG_OF(P.nt_tile / 16) * P.nt_tile * ROWB;
-  P.lds = a.tap_lds_off + 64 * sizeof(int);
+  P.lds = a.w_lds_off + 2 * TG_OF(P.nt_tile / 16) * P.nt_tile * ROWB;
   return 0;
 }
 
@@ -456,6 +477,7 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   a.in_mask = MaskView{in_mask, fd, fh, fw, in_bshift};
   a.out_mask = MaskView{out_mask, fd, fh, fw, out_bshift};
   a.accumulate = accumulate;
+  { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
   hipStream_t st = (hipStream_t)stream;
   return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, shape, st) : dispatch<float>(P, shape, st);
 }
