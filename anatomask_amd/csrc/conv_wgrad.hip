@@ -38,15 +38,18 @@ struct WgArgs {
   int dbg;                    // AM_WG_DBG ablation bits (timing experiments only): 1 no flush, 2 no contraction, 4 no global loads
 };
 
-constexpr int CT = 64, KT = 64;
 
 __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
 }
 
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX>
+// MI = 16-row cy tiles per wave (CT = 16*MI dY channels per workgroup); NWX = waves along cx (KT = 16*NWX X channels); the
+// remaining 4/NWX waves split the k-steps (voxels) of a brick.  64x64 tiles for the wide layers; 32-channel operands
+// (STUNet-B level 0, decoder output level) get 32-wide tiles instead of multiplying zero padding.
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr int EPC = TT<T>::EPC;
+  constexpr int CT = 16 * MI, KT = 16 * NWX, KS = 4 / NWX;
   constexpr int MV = BD * BH * BW;
   constexpr int KSTEP = sizeof(T) == 2 ? 32 : 4;
   // LDS row strides (bytes).  bf16: 160 B = 40 dwords: the 8 consecutive voxel rows a half-wave's ds_read_b64_tr_b16
@@ -54,14 +57,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr int RPAD = sizeof(T) == 2 ? 32 : 16;
   constexpr int RSY = CT * sizeof(T) + RPAD;
   constexpr int RSX = KT * sizeof(T) + RPAD;
-  constexpr int CPR = CT / EPC;                          // 16-byte chunks per row
-  constexpr int NITY = (MV * CPR + 255) / 256;
+  constexpr int CPRY = CT / EPC, CPRX = KT / EPC;        // 16-byte chunks per row
+  constexpr int NITY = (MV * CPRY + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* ldsY = lds;
   unsigned char* ldsX = lds + MV * RSY;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
+  const int wx = wave % NWX, wk = wave / NWX;            // cx tile of this wave ; its share of the k-steps
   // workgroup id -> (brick-walk slot s, tap group): the groups that walk the SAME bricks get ids that differ by 8, i.e. the
   // same XCD under round-robin dispatch (shared L2: x and dy are fetched from HBM once, not once per group) -- speed only
   const int ng_ = a.ngroup;
@@ -78,11 +82,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int tb = a.tap_begin[grp];
   const int upd = (a.upar[grp] >> 2) & 1, uph = (a.upar[grp] >> 1) & 1, upw = a.upar[grp] & 1;
 
-  f32x4 acc[NTAP][4];
+  f32x4 acc[NTAP][MI];
 #pragma unroll
   for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   int tapoff[NTAP];                                      // byte offset of each tap's window in the X brick (wave-uniform)
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
@@ -96,22 +100,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int it = 0; it < NITY; ++it) {
     const int idx = tid + it * 256;
-    const int v = idx / CPR, c = idx % CPR;
+    const int v = idx / CPRY, c = idx % CPRY;
     yrel[it] = (((v / (BW * BH)) * a.OS) * a.Hy + ((v / BW) % BH) * a.OS) * a.Wy + (v % BW) * a.OS;
-    ydst[it] = idx < MV * CPR ? v * RSY + c * 16 : -1;
+    ydst[it] = idx < MV * CPRY ? v * RSY + c * 16 : -1;
   }
   int xrel[NITX], xdst[NITX];
 #pragma unroll
   for (int it = 0; it < NITX; ++it) {
     const int idx = tid + it * 256;
-    const int e = idx / CPR, c = idx % CPR;
+    const int e = idx / CPRX, c = idx % CPRX;
     const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
     xrel[it] = e < nvox ? ((ez * a.Hx + ey) * a.Wx + (rem - ey * EW)) * a.GS : 0;
     xdst[it] = e < nvox ? e * RSX + c * 16 : -1;
   }
-  const int ychan = (tid % CPR) * EPC;                   // 256 % CPR == 0: a thread keeps its channel chunk across iterations
-  const bool ycok = cy0 + ychan < a.Cy, xcok = cx0 + ychan < a.Cx;
-  const int ycoff = ycok ? cy0 + ychan : 0, xcoff = xcok ? cx0 + ychan : 0;
+  const int ychan = (tid % CPRY) * EPC, xchan = (tid % CPRX) * EPC;   // 256 % CPR == 0: a thread keeps its channel chunk across iterations
+  const bool ycok = cy0 + ychan < a.Cy, xcok = cx0 + xchan < a.Cx;
+  const int ycoff = ycok ? cy0 + ychan : 0, xcoff = xcok ? cx0 + xchan : 0;
 
   const T* __restrict__ xg = (const T*)a.x;
   const T* __restrict__ yg = (const T*)a.dy;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     } else {
 #pragma unroll
       for (int it = 0; it < NITY; ++it) {
-        const int v = (tid + it * 256) / CPR;
+        const int v = (tid + it * 256) / CPRY;
         const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
         const bool ok = ydst[it] >= 0 && od < a.Dy && oh < a.Hy && ow < a.Wy && a.y_mask.active(b, od, oh, ow);
         yv[it] = ok ? ybase + yrel[it] : 0;
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       if (a.y_mask.m && !__syncthreads_or(yok != 0)) continue;    // nothing active in this brick (block-sparse dY)
 #pragma unroll
       for (int it = 0; it < NITX; ++it) {
-        const int e = (tid + it * 256) / CPR;
+        const int e = (tid + it * 256) / CPRX;
         const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
         const int id = i0d + ez * a.GS, ih = i0h + ey * a.GS, iw = i0w + (rem - ey * EW) * a.GS;
         const bool ok = xdst[it] >= 0 && id >= 0 && id < a.Dx && ih >= 0 && ih < a.Hx && iw >= 0 && iw < a.Wx && a.x_mask.active(b, id, ih, iw);
@@ -190,17 +194,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 
     // ---- contract over the brick's voxels ----
 #pragma unroll 1
-    for (int ks = 0; ks < ((a.dbg & 2) ? 0 : MV / KSTEP); ++ks) {
+    for (int ks = wk; ks < ((a.dbg & 2) ? 0 : MV / KSTEP); ks += KS) {
       if constexpr (sizeof(T) == 2) {
         const int q = (lane >> 2) & 3, p = lane & 3;
         // contraction index k = 8g + j of the MFMA  <->  voxel ks*32 + (j < 4 ? 4g + j : 16 + 4g + j - 4): any bijection
         // works as long as A and B agree; this one makes each half-wave read 8 consecutive voxel rows
         const int v1 = ks * 32 + g * 4 + q, v2 = v1 + 16;
-        const int xa1 = (((v1 / (BW * BH)) * EH + (v1 / BW) % BH) * EW + v1 % BW) * RSX + (16 * wave + 4 * p) * 2;
-        const int xa2 = (((v2 / (BW * BH)) * EH + (v2 / BW) % BH) * EW + v2 % BW) * RSX + (16 * wave + 4 * p) * 2;
-        s16x4 alo[4], ahi[4], blo[NTAP], bhi[NTAP];
+        const int xa1 = (((v1 / (BW * BH)) * EH + (v1 / BW) % BH) * EW + v1 % BW) * RSX + (16 * wx + 4 * p) * 2;
+        const int xa2 = (((v2 / (BW * BH)) * EH + (v2 / BW) % BH) * EW + v2 % BW) * RSX + (16 * wx + 4 * p) * 2;
+        s16x4 alo[MI], ahi[MI], blo[NTAP], bhi[NTAP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
           alo[i] = tr_read(ldsY + v1 * RSY + (16 * i + 4 * p) * 2);
           ahi[i] = tr_read(ldsY + v2 * RSY + (16 * i + 4 * p) * 2);
         }
@@ -210,40 +214,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
           bhi[t] = tr_read(ldsX + xa2 + tapoff[t]);
         }
         typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
-        bfx8 af[4];
+        bfx8 af[MI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
           af[i] = __builtin_bit_cast(bfx8, s16x8{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]});
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
           const bfx8 bf = __builtin_bit_cast(bfx8, s16x8{blo[t][0], blo[t][1], blo[t][2], blo[t][3], bhi[t][0], bhi[t][1], bhi[t][2], bhi[t][3]});
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
+          for (int i = 0; i < MI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
         }
       } else {
         const int v = ks * 4 + g;
-        const int xa = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * RSX + (16 * wave + r16) * 4;
-        float af[4], bf[NTAP];
+        const int xa = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * RSX + (16 * wx + r16) * 4;
+        float af[MI], bf[NTAP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *(const float*)(ldsY + v * RSY + (16 * i + r16) * 4);
+        for (int i = 0; i < MI; ++i) af[i] = *(const float*)(ldsY + v * RSY + (16 * i + r16) * 4);
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) bf[t] = *(const float*)(ldsX + xa + tapoff[t]);
 #pragma unroll
         for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[t], acc[t][i], 0, 0, 0);
+          for (int i = 0; i < MI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[t], acc[t][i], 0, 0, 0);
       }
     }
   }
 
   // ---- flush: D row = cy 4g+r, col = cx r16 ----
-  const int cx = cx0 + 16 * wave + r16;
+  const int cx = cx0 + 16 * wx + r16;
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
     if (cx < a.Cx && !(a.dbg & 1)) {
       const int widx = a.taps[tb + t] >> 12;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int cy = cy0 + 16 * i + 4 * g + r;
@@ -253,13 +257,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX>
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4>
 int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
-  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX>;
+  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX>;
   constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
+  constexpr int CT = 16 * MI, KT = 16 * NWX;
   const size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
   if (lds > 160 * 1024) return -3;
-  if (maxvox * (CT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
+  if (maxvox * (KT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
   static size_t attr_lds = 48 * 1024;
   if (lds > attr_lds) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_lds = lds;
@@ -305,6 +310,13 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   // share a CU and overlap each other's staging;  f32 (k-steps of 4): 2x8x8.
   int bd = 2, bh = 8, bw = 8;
   if (bf && Qw >= 16) { bh = 4; bw = 16; }
+  // 32-channel operands: 32-wide tiles (MI = 2 cy tiles / NWX = 2 cx waves, the other waves split the voxels)
+  int mi = 4, nwx = 4;
+  if (bf && bw == 16 && mode == AM_CONV_FWD && (k == 3 || stride == 2)) {
+    if (Cy <= 32 && stride == 1) mi = 2;
+    if (Cx <= 32) nwx = 2;
+    if (mi == 2 && nwx == 2) bd = 4;                     // thin rows: a 256-voxel brick still fits two workgroups per CU
+  }
   const int pad = (mode == AM_CONVT_FWD) ? 1 : k / 2;
   int n = 0; size_t maxvox = 0;
   int ucount[8];
@@ -350,13 +362,21 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     for (int gI = 0; gI < nunit; ++gI) if (ucount[gI] == ntap) a.zmap[a.ngroup++] = gI;
     if (!a.ngroup) continue;
     // enough workgroups to fill 256 CUs x 2, few enough that the atomic flush stays small
-    const int tiles = ((Cy + CT - 1) / CT) * ((Cx + KT - 1) / KT) * a.ngroup;
+    const int tiles = ((Cy + 16 * mi - 1) / (16 * mi)) * ((Cx + 16 * nwx - 1) / (16 * nwx)) * a.ngroup;
     int split = (1024 + tiles - 1) / tiles;
     if (split > nbrick) split = nbrick;
     if (split < 1) split = 1;
     int rc = -2;
 #define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, split, st)
-    if (bf && bw == 16) {
+    if (bf && bw == 16 && (mi == 2 || nwx == 2)) {
+      if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2>(a, maxvox, split, st);
+      else if (ntap == 9 && mi == 2) rc = launch<bf16_t, 2, 4, 16, 9, 7, 2, 4>(a, maxvox, split, st);
+      else if (ntap == 9) rc = launch<bf16_t, 2, 4, 16, 9, 4, 4, 2>(a, maxvox, split, st);
+      else if (ntap == 8) rc = launch<bf16_t, 2, 4, 16, 8, 4, 4, 2>(a, maxvox, split, st);
+      else if (ntap == 4) rc = launch<bf16_t, 2, 4, 16, 4, 4, 4, 2>(a, maxvox, split, st);
+      else if (ntap == 2) rc = launch<bf16_t, 2, 4, 16, 2, 4, 4, 2>(a, maxvox, split, st);
+      else rc = launch<bf16_t, 2, 4, 16, 1, 4, 4, 2>(a, maxvox, split, st);
+    } else if (bf && bw == 16) {
       if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
       else if (ntap == 2) WG_CASE(bf16_t, 4, 16, 2, 8); else WG_CASE(bf16_t, 4, 16, 1, 8);
     } else if (bf) {

@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanatomask_hip.so")
+LIB_PATH = os.environ.get("AM_HIP_LIB") or os.path.join(_HERE, "libanatomask_hip.so")   # AM_HIP_LIB: A/B timing of alternative builds (tools/)
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "anatomask_hip.h")
 
 DT_F32, DT_BF16 = 0, 1

@@ -64,6 +64,31 @@ CONV_CASES = [  # Cin, Cout, k, stride
 ]
 
 
+@pytest.mark.parametrize("case", [(32, 32, 3, 1), (64, 32, 3, 1), (32, 64, 3, 1), (32, 64, 3, 2), (32, 64, 1, 2), (24, 16, 3, 1)])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_conv_wgrad_narrow_channels_wide_grid(ops, case, sparse):
+    """W >= 16 grids with <= 32-channel operands take the 32-wide wgrad tiles (MI/NWX variants of conv_wgrad_kernel)."""
+    cin, cout, k, s = case
+    dtype = torch.bfloat16
+    B, f, bs_out = 2, (2, 2, 8), 2
+    so = tuple(v << bs_out for v in f)           # (8, 8, 32)
+    si = tuple(v * s for v in so)
+    x = q(rnd(B, cin, *si, seed=11), dtype)
+    dy = q(rnd(B, cout, *so, seed=12), dtype)
+    mask = mk_mask(B, f, 13) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    bs_in = bs_out + (1 if s == 2 else 0)
+    if sparse:
+        x = x * O.upsample_mask(mask, si).float()
+        dy = dy * O.upsample_mask(mask, so).float()
+    w = torch.zeros(cout, cin, k, k, k, requires_grad=True)
+    F.conv3d(x, w, None, stride=s, padding=k // 2).backward(dy)
+    dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dtype), to_cl(dy, dtype), k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out)
+    dw = torch.zeros(cout, cin, k, k, k, device=DEV)
+    ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+    close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (narrow channels)")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("sparse", [False, True])

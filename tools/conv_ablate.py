@@ -13,7 +13,7 @@ shapes = [(64, 64, 128), (64, 32, 128), (128, 128, 64), (256, 256, 32), (512, 51
 
 
 def timed(fn, iters=10):
-    for _ in range(2):
+    for _ in range(5):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -30,9 +30,11 @@ for ci, co, S in shapes:
     y = torch.empty(B, S, S, S, co, device=dev, dtype=torch.bfloat16)
     fl = 2.0 * B * S ** 3 * ci * co * 27
     out = []
-    for dbg in (0, 1, 2, 4, 6, 7):
-        os.environ["AM_CV_DBG"] = str(dbg)
-        t = timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (S, S, S), 3, 1, out=y))
-        out.append(f"dbg{dbg}: {t:.3f} ms {fl / t / 1e9:.0f} TF")
+    DBG = [int(v) for v in os.environ.get("AM_ABLATE", "0").split(",")]
+    for rep in range(2):
+        for dbg in DBG:
+            os.environ["AM_CV_DBG"] = str(dbg)
+            t = timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (S, S, S), 3, 1, out=y), iters=20)
+            out.append(f"dbg{dbg}: {t:.3f} ms {fl / t / 1e9:.0f} TF")
     os.environ["AM_CV_DBG"] = "0"
     print(f"conv {ci}->{co} @{S}^3 B={B}: " + " | ".join(out), flush=True)
