@@ -29,6 +29,7 @@ namespace {
 
 struct ConvArgs {
   const void* x; const void* w; const float* bias; void* y; float* partials;
+  const float* ep_scale; const float* ep_shift; const void* ep_res; int ep_act;   // fused epilogue: act(conv * scale + shift + res)
   int B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, Cinp, Coutp;
   int OS, GS, nclass, nunit;  // output stride (parity classes), global source stride, #classes (grid.z), #units
   int nbd, nbh, nbw;          // bricks per dim of the q grid
@@ -256,6 +257,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int co = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
     bia[i] = (a.bias && co < a.Cout) ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const bool fused = a.ep_scale != nullptr || a.ep_res != nullptr || a.ep_act != AM_ACT_NONE;   // (uniform) eval-mode norm / residual / activation
+  const T* __restrict__ resg = (const T*)a.ep_res;
+  auto ep = [&](f32x4 o, int i, const T* res, bool ok) {
+    if (a.ep_scale && ok) {
+      const int co = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
+      o = o * *(const f32x4*)(a.ep_scale + co) + *(const f32x4*)(a.ep_shift + co);
+    }
+    if (res && ok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] += TT<T>::ld(res + r);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (a.ep_act == AM_ACT_RELU6) o[r] = fminf(fmaxf(o[r], 0.f), 6.f);
+      else if (a.ep_act == AM_ACT_LRELU) o[r] = o[r] > 0.f ? o[r] : 0.01f * o[r];
+    }
+    return o;
+  };
   const bool sparse_out = a.out_mask.m != nullptr;
 #pragma unroll
   for (int j = 0; j < VS; ++j) {
@@ -268,9 +287,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       f32x4 o0 = acc[2 * h][j] + bia[2 * h], o1 = acc[2 * h + 1][j] + bia[2 * h + 1];
-      if (sparse_out && !act) { o0 = f32x4{0.f, 0.f, 0.f, 0.f}; o1 = o0; }
       T* dst = dstv + h * 32;
       const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout && !(a.dbg & 1);     // Cout % 8 == 0 (C % 8 == 0 contract)
+      if (fused) {
+        const T* rs = resg ? resg + (dst - yg) : nullptr;
+        o0 = ep(o0, 2 * h, rs, act && wr); o1 = ep(o1, 2 * h + 1, rs ? rs + 4 : nullptr, act && wr);
+      }
+      if (sparse_out && !act) { o0 = f32x4{0.f, 0.f, 0.f, 0.f}; o1 = o0; }
       if (a.accumulate && act && wr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { o0[r] += TT<T>::ld(dst + r); o1[r] += TT<T>::ld(dst + 4 + r); }
@@ -452,7 +475,8 @@ extern "C" int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, i
 extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed,
                          const float* bias, void* y, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo,
                          int Cout, const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift,
-                         int fd, int fh, int fw, int accumulate, float* partials, void* stream) {
+                         int fd, int fh, int fw, int accumulate, float* partials, const float* ep_scale, const float* ep_shift,
+                         const void* ep_res, int ep_act, void* stream) {
   if (Cin % 8 || Cout % 8) return -1;
   Plan P;
   ConvArgs& a = P.a;
@@ -469,6 +493,8 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   int rc = build_plan(P, mode, ksize, stride);
   if (rc) return rc;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;
+  a.ep_scale = ep_scale; a.ep_shift = ep_scale ? ep_shift : nullptr; a.ep_res = ep_res; a.ep_act = ep_act;
+  if (ep_scale && !ep_shift) return -1;
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
   am_packed_dims(dtype, Cout, Cin, &a.Coutp, &a.Cinp);
   a.w_bytes = ksize * ksize * ksize * a.Coutp * a.Cinp * (dtype == AM_DT_BF16 ? 2 : 4);

@@ -160,11 +160,23 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
     return out, rec_
 
 
-def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True):
+def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False):
     """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record)."""
     q = f"{DEC}.{i}"
     so = tuple(2 * v for v in x.shape[1:4])
     u = ops.conv3d(CONVT_FWD, x, pk.get(W, f"{q}.up_sample.weight", True, False), W[f"{q}.up_sample.bias"], so, 4, 2)
+    if not train and fuse_eval:
+        # eval-mode BatchNorm (running statistics: the EMA teacher) is a per-channel affine map: it is folded, with the ReLU6
+        # and the skip add, into the store of the convolution that feeds it -- no separate pass over the 128^3 tensors
+        C1, C2 = W[f"{q}.conv.0.weight"].shape[0], W[f"{q}.conv.3.weight"].shape[0]
+        st1, st2 = NormStats(C1, x.device), NormStats(C2, x.device)
+        ops.norm_fold_running(st1, W[f"{q}.conv.1.weight"], W[f"{q}.conv.1.bias"], W[f"{q}.conv.1.running_mean"], W[f"{q}.conv.1.running_var"], 1e-5)
+        ops.norm_fold_running(st2, W[f"{q}.conv.4.weight"], W[f"{q}.conv.4.bias"], W[f"{q}.conv.4.running_mean"], W[f"{q}.conv.4.running_var"], 1e-5)
+        r = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1,
+                       ep_scale=st1.scale, ep_shift=st1.shift, ep_act=ACT_RELU6)
+        o = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1,
+                       ep_scale=st2.scale, ep_shift=st2.shift, ep_res=nxt)
+        return o, None
     c1, pt1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1, want_partials=train), None
     if train:
         c1, pt1 = c1
@@ -221,7 +233,7 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
     x = to_dec[0]
     for i in range(n_dec):
         nxt = to_dec[i + 1] if i + 1 < n_dec else None
-        o, rec_ = _dec_block(W, pk, i, x, nxt, train)
+        o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=tape is None)
         if tape is not None:
             tape.dec.append({"q": rec_["q"], "xin": x, "nxt": nxt} if recompute else rec_)
         x = o

@@ -103,7 +103,9 @@ def unpack_grad(dw_packed: torch.Tensor, grad_out: torch.Tensor, transposed_conv
 def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], out_spatial: Tuple[int, int, int],
            ksize: int, stride: int, in_mask: Optional[MaskInfo] = None, in_bshift: int = 0,
            out_mask: Optional[MaskInfo] = None, out_bshift: int = 0, out: Optional[torch.Tensor] = None,
-           accumulate: bool = False, want_partials: bool = False):
+           accumulate: bool = False, want_partials: bool = False, ep_scale: Optional[torch.Tensor] = None,
+           ep_shift: Optional[torch.Tensor] = None, ep_res: Optional[torch.Tensor] = None, ep_act: int = 0):
+    """ep_*: fused store epilogue y = act(conv * scale + shift + res) (eval-mode BatchNorm / skip add / activation)."""
     B, Di, Hi, Wi, Cin = x.shape
     Cout, Kl = w_packed.logical
     assert Kl == Cin and w_packed.dtype == x.dtype, (w_packed.logical, x.shape)
@@ -117,7 +119,8 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
                      B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
                      in_mask.t.data_ptr() if in_mask else None, in_bshift,
                      out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate),
-                     part.t.data_ptr() if part else None, _stream())
+                     part.t.data_ptr() if part else None, _p(ep_scale), _p(ep_shift),
+                     ep_res.data_ptr() if ep_res is not None else None, int(ep_act), _stream())
     return (out, part) if want_partials else out
 
 

@@ -48,7 +48,11 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout,
               const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift, int fd, int fh, int fw,
               int accumulate, float* partials /* NULL or [am_conv3d_partials_rows][Cout][2]: per-workgroup sum / sum-of-squares
-              of the written outputs, feeds the following norm (or a bias gradient) without another pass */, void* stream);
+              of the written outputs, feeds the following norm (or a bias gradient) without another pass */,
+              const float* ep_scale, const float* ep_shift /* NULL or [Cout]: y = conv * scale + shift -- an eval-mode BatchNorm
+              (running statistics, the EMA teacher's decoder: P/decoder3D.py:20-22 under model_ema.ema.eval()) folded into the store */,
+              const void* ep_res /* NULL or a tensor shaped like y that is added (x = x + to_dec[i], P/decoder3D.py:59) */,
+              int ep_act /* AM_ACT_*: applied last */, void* stream);
 int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded);
 int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout, int* rows);
 /* partials [rows][C][2] -> sums[C][2] (double, overwritten; may be NULL) and/or sum_accum[C] += sum (may be NULL) */

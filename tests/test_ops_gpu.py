@@ -436,3 +436,25 @@ def test_conv_epilogue_partials_feed_the_norm(ops, dtype, sparse):
     acc = torch.ones(cout, device=DEV)
     part.reduce(sum_accum=acc)
     assert (acc.cpu() - 1 - ref[:, 0].float()).abs().max().item() <= 1e-4 * ref[:, 0].abs().max().item() + 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cout", [32, 64])
+def test_conv_fused_epilogue(ops, dtype, cout):
+    """y = act(conv * scale + shift + res): the eval-mode BatchNorm / skip add / ReLU6 folded into the conv store (teacher decoder)."""
+    B, cin, S = 2, 40, (8, 8, 16)
+    x = q(rnd(B, cin, *S, seed=21), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=22, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    sc, sh = rnd(cout, seed=23).abs() + 0.5, rnd(cout, seed=24)
+    res = q(rnd(B, cout, *S, seed=25), dtype)
+    conv = F.conv3d(x, w, None, padding=1)
+    wp = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=False)
+    want1 = torch.clamp(conv * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1), 0, 6)
+    y1 = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, S, 3, 1, ep_scale=sc.to(DEV), ep_shift=sh.to(DEV), ep_act=ops.ACT_RELU6)
+    close(from_cl(y1), want1, TOL[dtype], "conv + bn + relu6")
+    want2 = conv * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1) + res
+    y2 = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, S, 3, 1, ep_scale=sc.to(DEV), ep_shift=sh.to(DEV), ep_res=to_cl(res, dtype))
+    close(from_cl(y2), want2, TOL[dtype], "conv + bn + res")
+    want3 = F.leaky_relu(conv + res, 0.01)
+    y3 = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, S, 3, 1, ep_res=to_cl(res, dtype), ep_act=ops.ACT_LRELU)
+    close(from_cl(y3), want3, TOL[dtype], "conv + res + lrelu")
