@@ -133,6 +133,12 @@ __device__ __forceinline__ float act_grad(float out, int act) {   // derivative 
   return 1.f;
 }
 
+__device__ __forceinline__ float act_grad_pre(float pre, int act) {   // derivative from the RECOMPUTED pre-activation
+  if (act == AM_ACT_LRELU) return pre > 0.f ? 1.f : 0.01f;
+  if (act == AM_ACT_RELU6) return (pre > 0.f && pre < 6.f) ? 1.f : 0.f;
+  return 1.f;
+}
+
 // ------------------------------------------------------------------ apply (forward)
 // y = act(x*scale + shift [+ res | + stem 1x1 shortcut]) on active voxels;
 // fill != nullptr: inactive voxels get the mask token (densify, P/AnatoMask.py:160-163), output dense.
@@ -186,16 +192,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                               const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, int fill,
-                                                              double* __restrict__ bsum) {
+                                                              double* __restrict__ bsum, const float* __restrict__ psc,
+                                                              const float* __restrict__ psh) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 3 * 8];
   Walk<T> wk(g.C);
-  float s1[EPC], s2[EPC], s3[EPC], mu[EPC], rs[EPC];
+  float s1[EPC], s2[EPC], s3[EPC], mu[EPC], rs[EPC], qs[EPC], qh[EPC];
 #pragma unroll
-  for (int i = 0; i < EPC; ++i) { s1[i] = s2[i] = s3[i] = 0.f; mu[i] = rs[i] = 0.f; }
+  for (int i = 0; i < EPC; ++i) { s1[i] = s2[i] = s3[i] = 0.f; mu[i] = rs[i] = qs[i] = qh[i] = 0.f; }
   if (wk.live) {
 #pragma unroll
-    for (int i = 0; i < EPC; ++i) { mu[i] = mean[wk.cl * EPC + i]; rs[i] = rstd[wk.cl * EPC + i]; }
+    for (int i = 0; i < EPC; ++i) {
+      mu[i] = mean[wk.cl * EPC + i]; rs[i] = rstd[wk.cl * EPC + i];
+      if (!out && act != AM_ACT_NONE) { qs[i] = psc[wk.cl * EPC + i]; qh[i] = psh[wk.cl * EPC + i]; }
+    }
     const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
     for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
       const size_t off = (size_t)v * g.C + wk.cl * EPC;
@@ -211,10 +221,15 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restric
       float f[EPC];
       chunk_to_f<T>(*(const u32x4*)(x + off), f);
       if (act != AM_ACT_NONE) {
-        float o[EPC];
-        chunk_to_f<T>(*(const u32x4*)(out + off), o);
+        if (out) {
+          float o[EPC];
+          chunk_to_f<T>(*(const u32x4*)(out + off), o);
 #pragma unroll
-        for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+        } else {                                     // same expression as norm_apply_kernel's forward
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+        }
       }
 #pragma unroll
       for (int i = 0; i < EPC; ++i) { s1[i] += d[i]; s2[i] += d[i] * (f[i] - mu[i]) * rs[i]; }
@@ -270,16 +285,20 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ k0,
                                                              const float* __restrict__ k1, const float* __restrict__ k2, int act,
-                                                             T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum) {
+                                                             T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum,
+                                                             const float* __restrict__ psc, const float* __restrict__ psh) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 8];
   Walk<T> wk(g.C);
-  float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC], sx[EPC];
+  float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC], sx[EPC], qs[EPC], qh[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) {
     const int c = wk.cl * EPC + i;
-    sx[i] = 0.f;
-    if (wk.live) { mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c]; }
+    sx[i] = 0.f; qs[i] = qh[i] = 0.f;
+    if (wk.live) {
+      mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c];
+      if (!out && act != AM_ACT_NONE) { qs[i] = psc[c]; qh[i] = psh[c]; }
+    }
   }
   const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
   if (wk.live)
@@ -290,10 +309,15 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
       chunk_to_f<T>(*(const u32x4*)(dout + off), d);
       chunk_to_f<T>(*(const u32x4*)(x + off), f);
       if (act != AM_ACT_NONE) {
-        float o[EPC];
-        chunk_to_f<T>(*(const u32x4*)(out + off), o);
+        if (out) {
+          float o[EPC];
+          chunk_to_f<T>(*(const u32x4*)(out + off), o);
 #pragma unroll
-        for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+        } else {
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+        }
       }
       if (dres) *(u32x4*)(dres + off) = f_to_chunk<T>(d);
       float r[EPC];
@@ -722,8 +746,9 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
 
 int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
-                       int fill, double* bsum, void* stream) {
+                       int fill, double* bsum, const float* pre_scale, const float* pre_shift, void* stream) {
   CHK_C(C);
+  if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
@@ -731,9 +756,9 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, act, fill, bsum),
+                                (const float*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift),
              AM_LAUNCH(norm_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,
-                                (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum));
+                                (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -750,17 +775,18 @@ int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double cou
 int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, float* dxsum_accum,
-                      void* stream) {
+                      const float* pre_scale, const float* pre_shift, void* stream) {
   CHK_C(C);
+  if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxsum_accum),
+                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxsum_accum, pre_scale, pre_shift),
              AM_LAUNCH(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxsum_accum));
+                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxsum_accum, pre_scale, pre_shift));
   AM_CHECK_LAUNCH();
   return 0;
 }

@@ -273,7 +273,7 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
         so = tuple(t["r"].shape[1:4])
         dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1)
         _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
-        dc1 = ops.norm_backward(dr, t["r"], t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
+        dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
                                 G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"])
         du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
         ptu.reduce(sum_accum=G[f"{q}.up_sample.bias"])           # ConvT bias gradient = per-channel sum of du
@@ -333,7 +333,7 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
             da1 = ops.conv3d(CONV_DGRAD, dy2, pk.get(W, f"{p}.conv2.weight", False, True), None, sp, 3, 1,
                              in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
             _wgrad_into(G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
-            dy1 = ops.norm_backward(da1, a1, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
+            dy1 = ops.norm_backward(da1, None, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
                                     G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"])
             stride = t["stride"]
             if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only

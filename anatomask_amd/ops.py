@@ -224,21 +224,22 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
                   dtoken: Optional[torch.Tensor] = None, fill: bool = False, dx: Optional[torch.Tensor] = None,
                   dres: Optional[torch.Tensor] = None, scratch: Optional[NormBwdScratch] = None,
                   dbeta2: Optional[torch.Tensor] = None, dxsum: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Backward of y = act(norm(x) [+res]) (or the densify fill).  Returns dx; accumulates dgamma/dbeta/dtoken."""
+    """Backward of y = act(norm(x) [+res]) (or the densify fill).  Returns dx; accumulates dgamma/dbeta/dtoken.
+    out=None with an activation (layers WITHOUT a residual): the derivative comes from the recomputed x*st.scale + st.shift."""
     B, D, H, W, Cc = x.shape
     sc = scratch or NormBwdScratch(Cc, x.device)
     mp, fd, fh, fw = _mk(mask)
     L = hip.lib()
     s = _stream()
     L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
-                      st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), sc.bsum.data_ptr(), s)
+                      st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), sc.bsum.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), s)
     L.norm_bwd_finalize(sc.bsum.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
                         sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
     if dx is None:
         dx = torch.empty_like(x)
     L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                      st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
-                     dx.data_ptr(), _p(dres), _p(dxsum), s)
+                     dx.data_ptr(), _p(dres), _p(dxsum), st.scale.data_ptr(), st.shift.data_ptr(), s)
     return dx
 
 

@@ -98,14 +98,17 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
 /* backward: bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout}, dpre = dout*act'(out) */
 int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
-                       int fill, double* bsum /* [AM_NREP][C][3], zeroed inside */, void* stream);
+                       int fill, double* bsum /* [AM_NREP][C][3], zeroed inside */,
+                       const float* pre_scale, const float* pre_shift /* out == NULL with an activation (no residual): the
+                       derivative is taken from the recomputed pre-activation x*pre_scale + pre_shift -- one read less */, void* stream);
 int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
                          const float* rstd, float* k0, float* k1, float* k2, float* dgamma_accum, float* dbeta_accum,
                          float* dtoken_accum, float* dbeta2_accum /* bias of a conv added after the norm: same sum */, void* stream);
 int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres,
-                      float* dxsum_accum /* NULL or += per-channel sum of dx: bias gradient of the conv feeding the norm */, void* stream);
+                      float* dxsum_accum /* NULL or += per-channel sum of dx: bias gradient of the conv feeding the norm */,
+                      const float* pre_scale, const float* pre_shift /* as in am_norm_bwd_reduce */, void* stream);
 int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                 int fw, float* out_accum, void* stream);   /* conv bias gradients */
 int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream);   /* x + to_dec[i], P/decoder3D.py:59 */

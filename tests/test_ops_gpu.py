@@ -253,6 +253,12 @@ def test_batchnorm_train_eval_relu6(ops, dtype):
     dx = ops.norm_backward(to_cl(dout, dtype), to_cl(yr.detach(), dtype), xd, st, p["bn.weight"].detach().to(DEV), ops.ACT_RELU6, None, 0, dg, db)
     close(from_cl(dx), x.grad, 2 * TOL[dtype], "BN dx")
     close(dg.cpu(), p["bn.weight"].grad, 2 * TOL[dtype], "BN dgamma"); close(db.cpu(), p["bn.bias"].grad, 2 * TOL[dtype], "BN dbeta")
+    # out=None: the ReLU6 gate is recomputed from x * scale + shift (what the engine does for norms without a residual)
+    dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dx2 = ops.norm_backward(to_cl(dout, dtype), None, xd, st, p["bn.weight"].detach().to(DEV), ops.ACT_RELU6, None, 0, dg2, db2)
+    close(from_cl(dx2), x.grad, 2 * TOL[dtype], "BN dx (recomputed gate)")
+    close(dg2.cpu(), p["bn.weight"].grad, 2 * TOL[dtype], "BN dgamma (recomputed gate)")
+    close(db2.cpu(), p["bn.bias"].grad, 2 * TOL[dtype], "BN dbeta (recomputed gate)")
     # eval: running statistics
     ye = O.batch_norm3d(p, "bn", x.detach(), False, None)
     ops.norm_fold_running(st, p["bn.weight"].detach().to(DEV), p["bn.bias"].detach().to(DEV), p["bn.running_mean"].to(DEV),

@@ -39,7 +39,7 @@ sc = ops.NormBwdScratch(C, dev)
 L = __import__("anatomask_amd.hip", fromlist=["lib"]).lib()
 s = torch.cuda.current_stream().cuda_stream
 timed(lambda: L.norm_bwd_reduce(1, d.data_ptr(), y.data_ptr(), x.data_ptr(), B, S, S, S, C, None, 0, 1, 1, 1, st.mean.data_ptr(),
-                                st.rstd.data_ptr(), ops.ACT_RELU6, 0, sc.bsum.data_ptr(), s), "bwd_reduce (3 reads)", 3 * nb)
+                                st.rstd.data_ptr(), ops.ACT_RELU6, 0, sc.bsum.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), s), "bwd_reduce (3 reads)", 3 * nb)
 timed(lambda: ops.norm_backward(d, y, x, st, gam, ops.ACT_RELU6, None, 0, None, None, dx=dx, scratch=sc), "bwd reduce+apply (6r 1w)", 7 * nb)
 out = torch.zeros(C, device=dev)
 timed(lambda: ops.chan_sum(x, None, 0, out), "chan_sum (1 read)", nb)
