@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const float* __restrict__ rstd, const float* __restrict__ k0,
                                                              const float* __restrict__ k1, const float* __restrict__ k2, int act,
                                                              T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum,
-                                                             const float* __restrict__ psc, const float* __restrict__ psh) {
+                                                             int dxrep, const float* __restrict__ psc, const float* __restrict__ psh) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 8];
   Walk<T> wk(g.C);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
 #pragma unroll
         for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[threadIdx.x * EPC + i], a1[i]);
+      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], a1[i]);
     }
   }
 }
@@ -637,6 +637,15 @@ __global__ void unpack_grad_kernel(const float* __restrict__ src, float* __restr
   }
 }
 
+// dst[c] += sum over the replicas rep[r][c]
+__global__ __launch_bounds__(256) void rep_reduce_kernel(const float* __restrict__ rep, int nrep, int C, float* __restrict__ dst) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < nrep; ++r) s += rep[(size_t)r * C + c];
+  dst[c] += s;
+}
+
 // per-workgroup conv partials [rows][C][2] -> sums[C][2] (double) and/or sum_accum[C] += sum   (one WG per channel)
 __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int rows, int C, double* __restrict__ sums,
                                                                float* __restrict__ sum_accum) {
@@ -664,6 +673,10 @@ inline int pick_vpw(long nvox, int C, int dtype, bool reduction) {
   const long target = reduction ? 1024 : 2048;
   long v = (nvox + target - 1) / target;
   v = (v + vpp - 1) / vpp * vpp;
+  // small tensors: at least 16 passes (64 KB of a tensor) per workgroup, but never fewer than ~256 workgroups -- thousands of
+  // 4 KB workgroups are launch- and atomic-bound (their per-channel sums all land on the same accumulators)
+  const long vmin = 16L * vpp, vcap = ((nvox + 255) / 256 + vpp - 1) / vpp * vpp;
+  if (v < vmin) v = vmin < vcap ? vmin : vcap;
   if (v < vpp) v = vpp;
   if (v > 65536) v = 65536;
   return (int)v;
@@ -775,19 +788,26 @@ int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double cou
 int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, float* dxsum_accum,
-                      const float* pre_scale, const float* pre_shift, void* stream) {
+                      float* dxsum_scratch, const float* pre_scale, const float* pre_shift, void* stream) {
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
   const int nb = nblk((long)B * D * H * W, g.vpw);
+  // bias-gradient sums: every workgroup adds C floats; on ONE accumulator 2048 workgroups serialise (measured 400 us on an
+  // 8 MB tensor), so they go to AM_DXREP replicas that a 1-block kernel folds afterwards
+  const bool rep = dxsum_accum && dxsum_scratch;
+  float* dxs = rep ? dxsum_scratch : dxsum_accum;
+  const int nrep = rep ? AM_DXREP : 1;
+  if (rep) hipMemsetAsync(dxsum_scratch, 0, sizeof(float) * AM_DXREP * C, st);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxsum_accum, pre_scale, pre_shift),
+                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift),
              AM_LAUNCH(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxsum_accum, pre_scale, pre_shift));
+                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift));
   AM_CHECK_LAUNCH();
+  if (rep) { AM_LAUNCH(rep_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dxsum_scratch, AM_DXREP, C, dxsum_accum); AM_CHECK_LAUNCH(); }
   return 0;
 }
 

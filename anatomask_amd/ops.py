@@ -162,6 +162,7 @@ def stem_conv_wgrad(x_b1: torch.Tensor, dy: torch.Tensor, ksize: int, mask: Opti
 
 # ------------------------------------------------------------------ norms
 NREP = 8   # AM_NREP
+DXREP = 64  # AM_DXREP
 
 
 class NormStats:
@@ -217,6 +218,7 @@ class NormBwdScratch:
     def __init__(self, C: int, device):
         self.bsum = torch.empty(NREP, C, 3, device=device, dtype=torch.float64)
         self.k = torch.empty(3, C, device=device, dtype=torch.float32)
+        self.dxrep = torch.empty(DXREP, C, device=device, dtype=torch.float32)
 
 
 def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tensor, st: NormStats, gamma: torch.Tensor, act: int,
@@ -239,7 +241,7 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
         dx = torch.empty_like(x)
     L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                      st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
-                     dx.data_ptr(), _p(dres), _p(dxsum), st.scale.data_ptr(), st.shift.data_ptr(), s)
+                     dx.data_ptr(), _p(dres), _p(dxsum), sc.dxrep.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), s)
     return dx
 
 

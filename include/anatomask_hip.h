@@ -32,6 +32,7 @@ extern "C" {
 #define AM_CONVT_FWD 2    /* y[o]  = sum_t x[(o + 1 - t)/2] W_t             (ConvTranspose3d k4 s2 p1)       */
 #define AM_CONVT_DGRAD 3  /* dx[i] = sum_t dy[2i - 1 + t] W_t^T                                              */
 
+#define AM_DXREP 64       /* replicas of the bias-gradient accumulator of am_norm_bwd_apply (2048 workgroups on one address serialise) */
 #define AM_NREP 8        /* replicated reduction accumulators (spread atomic contention), summed by the finalize kernels */
 
 #define AM_ACT_NONE 0
@@ -108,6 +109,7 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres,
                       float* dxsum_accum /* NULL or += per-channel sum of dx: bias gradient of the conv feeding the norm */,
+                      float* dxsum_scratch /* [AM_DXREP][C] workspace when dxsum_accum != NULL (NULL: direct atomics) */,
                       const float* pre_scale, const float* pre_shift /* as in am_norm_bwd_reduce */, void* stream);
 int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                 int fw, float* out_accum, void* stream);   /* conv bias gradients */
