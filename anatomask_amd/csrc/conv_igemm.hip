@@ -45,6 +45,7 @@ struct ConvArgs {
   int w_lds_off;              // byte offset of the weight-group buffers inside dynamic LDS
   MaskView in_mask, out_mask;
   int accumulate;
+  int brick_in_patch;         // block-sparse output and the q-brick lies inside one patch: one mask lookup decides the whole brick
   int nt_store;               // non-temporal output stores (outputs far larger than the 256 MB Infinity Cache)
   int dbg;                    // AM_CV_DBG ablation bits (timing experiments only): 1 no stores, 2 no source loads, 4 no weight loads
 };
@@ -91,7 +92,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   float* part = a.partials ? a.partials + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * a.Cout) * 2 : nullptr;
 
   // ---- skip bricks with no active output voxel (block-sparse outputs) ----
-  if (a.out_mask.m) {
+  if (a.out_mask.m && a.brick_in_patch) {                // (uniform) every voxel of the brick shares the patch of its first voxel
+    const int od = q0d * a.OS + pd, oh = q0h * a.OS + ph, ow = q0w * a.OS + pw;
+    if (!(od < a.Do && oh < a.Ho && ow < a.Wo && a.out_mask.active(b, od, oh, ow))) {
+      if (part && tid < NT && co0 + tid < a.Cout) { part[(co0 + tid) * 2] = 0.f; part[(co0 + tid) * 2 + 1] = 0.f; }
+      return;
+    }
+  } else if (a.out_mask.m) {
     int any = 0;
     for (int v = tid; v < MV; v += 256) {
       const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
@@ -440,11 +447,13 @@ int dispatch(Plan& P, int shape, hipStream_t st) {
 
 }  // namespace
 
-// brick of q-space voxels per workgroup: 0 = 4x8x8 (narrow grids), 1 = 4x4x16, 2 = 4x4x4 (tiny grids, chosen by the caller)
-static int brick_shape(int mode, int stride, int qw, int* bd, int* bh, int* bw) {
-  (void)mode; (void)stride;
+// brick of q-space voxels per workgroup: 0 = 4x8x8 (narrow grids), 1 = 4x4x16, 2 = 4x4x4 (tiny grids, chosen by the caller).
+// Block-sparse outputs whose patches are 8 q-voxels wide take the 4x8x8 brick: it lies inside ONE patch, so 60 % of the bricks
+// are skipped outright (a 4x4x16 brick spans two patches and is empty only 36 % of the time).
+static int brick_shape(int os, int qw, bool out_sparse, int out_bshift, int* bd, int* bh, int* bw) {
   *bd = 4;
-  if (qw >= 16) { *bh = 4; *bw = 16; return 1; }
+  const int qblock = out_sparse ? ((1 << out_bshift) / os) : 0;
+  if (qw >= 16 && qblock != 8) { *bh = 4; *bw = 16; return 1; }
   *bh = 8; *bw = 8; return 0;
 }
 
@@ -456,11 +465,12 @@ extern "C" int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int*
   return 0;
 }
 
-extern "C" int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout, int* rows) {
+extern "C" int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout, int out_sparse,
+                                       int out_bshift, int* rows) {
   const int os = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
   const int qd = (Do + os - 1) / os, qh = (Ho + os - 1) / os, qw = (Wo + os - 1) / os;
   int bd, bh, bw;
-  const int shape0 = brick_shape(mode, stride, qw, &bd, &bh, &bw);
+  const int shape0 = brick_shape(os, qw, out_sparse != 0, out_bshift, &bd, &bh, &bw);
   {
     const int tile = Cout <= 32 ? 32 : 64;
     const long q = (long)qd * qh * qw;
@@ -481,7 +491,7 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   Plan P;
   ConvArgs& a = P.a;
   const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
-  int shape = brick_shape(mode, stride, (Wo + os_ - 1) / os_, &P.bd, &P.bh, &P.bw);
+  int shape = brick_shape(os_, (Wo + os_ - 1) / os_, out_mask != nullptr, out_bshift, &P.bd, &P.bh, &P.bw);
   P.nt_tile = Cout <= 32 ? 32 : 64;
   {  // deep levels (8^3..16^3 grids, 256-512 channels): the default tiling gives a few dozen workgroups that each walk
      // 16 channel slabs serially while 90 % of the chip idles -> 64-voxel bricks x 32 channels = 8x more workgroups
@@ -504,6 +514,10 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   a.in_mask = MaskView{in_mask, fd, fh, fw, in_bshift};
   a.out_mask = MaskView{out_mask, fd, fh, fw, out_bshift};
   a.accumulate = accumulate;
+  {
+    const int qblock = out_mask ? ((1 << out_bshift) / a.OS) : 0;
+    a.brick_in_patch = qblock > 0 && qblock % P.bd == 0 && qblock % P.bh == 0 && qblock % P.bw == 0;
+  }
   { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
   // outputs far larger than the 256 MB Infinity Cache bypass it (measured +2.5 % on the 1 GB decoder tensors: the halo re-reads keep L2)
   a.nt_store = ((size_t)B * Do * Ho * Wo * Cout * 2 >= ((size_t)384 << 20) && !accumulate) || (a.dbg & 8);

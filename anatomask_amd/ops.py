@@ -58,10 +58,10 @@ def packed_dims(dtype: torch.dtype, rows: int, k: int):
 class ConvPartials:
     """Per-workgroup per-channel (sum, sumsq) rows a conv launch leaves behind for the norm / bias-grad that follows."""
 
-    def __init__(self, mode, ksize, stride, B, out_spatial, cout, device):
+    def __init__(self, mode, ksize, stride, B, out_spatial, cout, device, out_sparse=False, out_bshift=0):
         import ctypes
         n = ctypes.c_int(0)
-        hip.lib().conv3d_partials_rows(mode, ksize, stride, B, *out_spatial, cout, ctypes.addressof(n))
+        hip.lib().conv3d_partials_rows(mode, ksize, stride, B, *out_spatial, cout, int(out_sparse), out_bshift, ctypes.addressof(n))
         self.rows, self.C = n.value, cout
         self.t = torch.empty(self.rows, cout, 2, device=device, dtype=torch.float32)
 
@@ -110,7 +110,7 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     Cout, Kl = w_packed.logical
     assert Kl == Cin and w_packed.dtype == x.dtype, (w_packed.logical, x.shape)
     Do, Ho, Wo = out_spatial
-    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device) if want_partials else None
+    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift) if want_partials else None
     if out is None:
         out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
     mk = in_mask or out_mask

@@ -55,7 +55,8 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               const void* ep_res /* NULL or a tensor shaped like y that is added (x = x + to_dec[i], P/decoder3D.py:59) */,
               int ep_act /* AM_ACT_*: applied last */, void* stream);
 int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded);
-int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout, int* rows);
+int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout,
+                            int out_sparse, int out_bshift /* the launch's out_mask != NULL and its block shift: they select the brick */, int* rows);
 /* partials [rows][C][2] -> sums[C][2] (double, overwritten; may be NULL) and/or sum_accum[C] += sum (may be NULL) */
 int am_partials_reduce(const float* partials, int rows, int C, double* sums, float* sum_accum, void* stream);
 
