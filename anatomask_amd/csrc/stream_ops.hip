@@ -646,7 +646,8 @@ __global__ __launch_bounds__(256) void rep_reduce_kernel(const float* __restrict
   dst[c] += s;
 }
 
-// per-workgroup conv partials [rows][C][2] -> sums[C][2] (double) and/or sum_accum[C] += sum   (one WG per channel)
+// per-workgroup conv partials [rows][C][2] -> sums[C][2] (double) and/or sum_accum[C] += sum
+// v1 (any C): one workgroup per channel, strided 8-byte reads.
 __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __restrict__ part, int rows, int C, double* __restrict__ sums,
                                                                float* __restrict__ sum_accum) {
   __shared__ double sh[8];
@@ -663,6 +664,35 @@ __global__ __launch_bounds__(256) void partials_reduce_kernel(const float* __res
     s1 = sh[0] + sh[1] + sh[2] + sh[3]; s2 = sh[4] + sh[5] + sh[6] + sh[7];
     if (sums) { sums[2 * c] = s1; sums[2 * c + 1] = s2; }
     if (sum_accum) sum_accum[c] += (float)s1;
+  }
+}
+// v2 (256 % C == 0 or C % 256 == 0): each workgroup owns a contiguous run of rows and reads them as whole coalesced rows
+// (the 128^3 launches leave 32768 x 64 float2 = 17 MB: v1 touches a 64-byte sector per 8 useful bytes); a thread keeps its
+// channel(s), rows are folded through LDS, one double atomic per channel per workgroup into the zeroed sums.
+__global__ __launch_bounds__(256) void partials_reduce2_kernel(const float* __restrict__ part, int rows, int C, int rows_per_block,
+                                                                double* __restrict__ sums, float* __restrict__ sum_accum) {
+  __shared__ double sh1[256], sh2[256];
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const float2* __restrict__ p2 = (const float2*)part;
+  if (C <= 256) {
+    const int c = t % C, rstep = 256 / C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = r0 + t / C; r < r1; r += rstep) { const float2 v = p2[(size_t)r * C + c]; s1 += v.x; s2 += v.y; }
+    sh1[t] = s1; sh2[t] = s2;
+    __syncthreads();
+    if (t < C) {
+      for (int k = 1; k < rstep; ++k) { s1 += sh1[k * C + t]; s2 += sh2[k * C + t]; }
+      if (sums) { atomicAdd(&sums[2 * t], s1); atomicAdd(&sums[2 * t + 1], s2); }
+      if (sum_accum) atomicAdd(&sum_accum[t], (float)s1);
+    }
+  } else {
+    for (int c = t; c < C; c += 256) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int r = r0; r < r1; ++r) { const float2 v = p2[(size_t)r * C + c]; s1 += v.x; s2 += v.y; }
+      if (sums) { atomicAdd(&sums[2 * c], s1); atomicAdd(&sums[2 * c + 1], s2); }
+      if (sum_accum) atomicAdd(&sum_accum[c], (float)s1);
+    }
   }
 }
 
@@ -893,7 +923,18 @@ int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, c
 }
 
 int am_partials_reduce(const float* partials, int rows, int C, double* sums, float* sum_accum, void* stream) {
-  AM_LAUNCH(partials_reduce_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, partials, rows, C, sums, sum_accum);
+  hipStream_t st = (hipStream_t)stream;
+  if ((256 % C == 0 || C % 256 == 0) && rows >= 64) {
+    const int rstep = C <= 256 ? 256 / C : 1;
+    int nb = rows / (rstep * 16); nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+    const int rpb = ((rows + nb - 1) / nb + rstep - 1) / rstep * rstep;
+    nb = (rows + rpb - 1) / rpb;
+    if (sums) hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
+    AM_LAUNCH(partials_reduce2_kernel, dim3(nb), dim3(256), 0, st, partials, rows, C, rpb, sums, sum_accum);
+    AM_CHECK_LAUNCH();
+    return 0;
+  }
+  AM_LAUNCH(partials_reduce_kernel, dim3(C), dim3(256), 0, st, partials, rows, C, sums, sum_accum);
   AM_CHECK_LAUNCH();
   return 0;
 }

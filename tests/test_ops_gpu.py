@@ -464,3 +464,17 @@ def test_conv_fused_epilogue(ops, dtype, cout):
     want3 = F.leaky_relu(conv + res, 0.01)
     y3 = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, S, 3, 1, ep_res=to_cl(res, dtype), ep_act=ops.ACT_LRELU)
     close(from_cl(y3), want3, TOL[dtype], "conv + res + lrelu")
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 64), (37, 32), (4096, 32), (300, 512), (500, 96), (70, 256)])
+def test_partials_reduce_paths(ops, rows, C):
+    """[rows][C][2] per-workgroup partials -> per-channel double sums (+ float accumulate): strided v1 and coalesced v2 kernels."""
+    part = ops.ConvPartials.__new__(ops.ConvPartials)
+    part.rows, part.C = rows, C
+    part.t = torch.randn(rows, C, 2, generator=torch.Generator().manual_seed(rows + C)).to(DEV)
+    sums = torch.full((C, 2), 7.0, device=DEV, dtype=torch.float64)         # must be overwritten
+    acc = torch.ones(C, device=DEV)
+    part.reduce(sums=sums, sum_accum=acc)
+    want = part.t.double().sum(0)
+    assert torch.allclose(sums, want, rtol=0, atol=1e-9)
+    assert torch.allclose(acc.double(), 1.0 + want[:, 0], rtol=0, atol=1e-4)
