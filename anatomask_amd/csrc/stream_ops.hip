@@ -402,27 +402,36 @@ __global__ void add_kernel(const T* a, const T* b, T* y, size_t nchunk) {
 // neighbours' values from LDS instead of re-fetching them), one 16-byte chunk of output channels per lane.
 constexpr int SBD = 4, SBH = 8, SBW = 16;                   // divides the 16^3 patch: a brick never straddles patches
 
-template <typename T>
-__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, Geo g, int k,
+// Tap-outer form: a thread owns one 16-byte chunk of channels for its VPT voxels of the brick; per tap it reads the chunk's
+// weights once and one x value per voxel (LDS traffic 16 reads per 64 FMAs; the voxel-outer form needed 72).
+// part != nullptr: per-workgroup per-channel (sum, sum of squares) of the STORED values -> [brick][C][2] (zeros for inactive
+// bricks), the statistics of the norm that follows without another pass over y.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restrict__ x, Geo g,
                                                             const float* __restrict__ w, const float* __restrict__ bias,
-                                                            T* __restrict__ y) {
+                                                            T* __restrict__ y, float* __restrict__ part) {
   constexpr int EPC = TT<T>::EPC;
-  extern __shared__ float sm[];                              // [C][k^3] weights, then the haloed x brick
-  const int nt = k * k * k, pad = k / 2;
-  const int ED = SBD + 2 * pad, EH = SBH + 2 * pad, EW = SBW + 2 * pad;
+  constexpr int NTP = K * K * K, PAD = K / 2;
+  constexpr int ED = SBD + 2 * PAD, EH = SBH + 2 * PAD, EW = SBW + 2 * PAD;
+  constexpr int MV = SBD * SBH * SBW;
+  extern __shared__ float sm[];                              // [k^3][C] weights (tap-major), then the haloed x brick
   float* wl = sm;
-  float* xb = sm + g.C * nt;
+  float* xb = sm + g.C * NTP;
   int bid = blockIdx.x;
   const int nbw = g.W / SBW, nbh = g.H / SBH, nbd = g.D / SBD;
   const int bw_ = bid % nbw; bid /= nbw;
   const int bh_ = bid % nbh; bid /= nbh;
   const int bd_ = bid % nbd; const int b = bid / nbd;
   const int d0 = bd_ * SBD, h0 = bh_ * SBH, w0 = bw_ * SBW;
-  if (!g.mask.active(b, d0, h0, w0)) return;                  // whole brick inactive (wave-uniform)
-  for (int i = threadIdx.x; i < g.C * nt; i += 256) wl[i] = w[i];
+  float* prow = part ? part + (size_t)blockIdx.x * g.C * 2 : nullptr;
+  if (!g.mask.active(b, d0, h0, w0)) {                        // whole brick inactive (wave-uniform)
+    if (prow) for (int i = threadIdx.x; i < g.C * 2; i += 256) prow[i] = 0.f;
+    return;
+  }
+  for (int i = threadIdx.x; i < g.C * NTP; i += 256) wl[(i % NTP) * g.C + i / NTP] = w[i];
   for (int e = threadIdx.x; e < ED * EH * EW; e += 256) {
     const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
-    const int id = d0 + ez - pad, ih = h0 + ey - pad, iw = w0 + ex - pad;
+    const int id = d0 + ez - PAD, ih = h0 + ey - PAD, iw = w0 + ex - PAD;
     float v = 0.f;
     if (id >= 0 && id < g.D && ih >= 0 && ih < g.H && iw >= 0 && iw < g.W && g.mask.active(b, id, ih, iw))
       v = x[((size_t)(b * g.D + id) * g.H + ih) * g.W + iw];
@@ -430,23 +439,77 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
   }
   __syncthreads();
   Walk<T> wk(g.C);
-  if (!wk.live) return;
-  float bs[EPC];
+  float s1[EPC], s2[EPC];
 #pragma unroll
-  for (int i = 0; i < EPC; ++i) bs[i] = bias ? bias[wk.cl * EPC + i] : 0.f;
-  for (int v = wk.vl; v < SBD * SBH * SBW; v += wk.vpp) {
-    const int lw = v % SBW, lh = (v / SBW) % SBH, ld = v / (SBW * SBH);
-    float o[EPC];
+  for (int i = 0; i < EPC; ++i) s1[i] = s2[i] = 0.f;
+  if (wk.live) {
+    float bs[EPC];
 #pragma unroll
-    for (int i = 0; i < EPC; ++i) o[i] = bs[i];
-    int ti = 0;
-    for (int td = 0; td < k; ++td) for (int th = 0; th < k; ++th) for (int tw = 0; tw < k; ++tw, ++ti) {
-      const float xv = xb[((ld + td) * EH + lh + th) * EW + lw + tw];
+    for (int i = 0; i < EPC; ++i) bs[i] = bias ? bias[wk.cl * EPC + i] : 0.f;
+    constexpr int VPT = 8;                                   // voxels per thread per round
+    for (int vb = wk.vl; vb < MV; vb += wk.vpp * VPT) {
+      float o[VPT][EPC];
+      int xo[VPT];
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) o[i] += wl[(wk.cl * EPC + i) * nt + ti] * xv;
+      for (int q = 0; q < VPT; ++q) {
+        const int v = vb + q * wk.vpp;
+        const int vv = v < MV ? v : 0;
+        xo[q] = ((vv / (SBW * SBH)) * EH + (vv / SBW) % SBH) * EW + vv % SBW;
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) o[q][i] = bs[i];
+      }
+#pragma unroll 1
+      for (int td = 0; td < K; ++td)                          // (rolled: unrolled, hipcc preloads all 27 x EPC weights -> 256 VGPRs, spills)
+#pragma unroll 1
+        for (int th = 0; th < K; ++th)
+#pragma unroll
+          for (int tw = 0; tw < K; ++tw) {
+            const int ti = (td * K + th) * K + tw;
+            const f32x4 wa = *(const f32x4*)(wl + ti * g.C + wk.cl * EPC);
+            f32x4 wb = wa;
+            if constexpr (EPC == 8) wb = *(const f32x4*)(wl + ti * g.C + wk.cl * EPC + 4);
+#pragma unroll
+            for (int q = 0; q < VPT; ++q) {
+              const float xv = xb[xo[q] + (td * EH + th) * EW + tw];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) o[q][i] += wa[i] * xv;
+              if constexpr (EPC == 8) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[q][4 + i] += wb[i] * xv;
+              }
+            }
+          }
+#pragma unroll
+      for (int q = 0; q < VPT; ++q) {
+        const int v = vb + q * wk.vpp;
+        if (v >= MV) continue;
+        const int lw = v % SBW, lh = (v / SBW) % SBH, ld = v / (SBW * SBH);
+        const size_t vox = ((size_t)(b * g.D + d0 + ld) * g.H + h0 + lh) * g.W + w0 + lw;
+        const u32x4 pk = f_to_chunk<T>(o[q]);
+        *(u32x4*)(y + vox * g.C + wk.cl * EPC) = pk;
+        if (prow) {
+          float r[EPC];
+          chunk_to_f<T>(pk, r);
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) { s1[i] += r[i]; s2[i] += r[i] * r[i]; }
+        }
+      }
     }
-    const size_t vox = ((size_t)(b * g.D + d0 + ld) * g.H + h0 + lh) * g.W + w0 + lw;
-    *(u32x4*)(y + vox * g.C + wk.cl * EPC) = f_to_chunk<T>(o);
+  }
+  if (prow) {                                                 // fold the voxel lanes: red[vl][cl][EPC][2] reuses the weight area
+    __syncthreads();
+    float* red = sm;
+    if (wk.live) {
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { red[(threadIdx.x * EPC + i) * 2] = s1[i]; red[(threadIdx.x * EPC + i) * 2 + 1] = s2[i]; }
+    }
+    __syncthreads();
+    for (int c2 = threadIdx.x; c2 < g.C * 2; c2 += 256) {    // c2 = channel * 2 + {sum, sumsq}
+      const int c = c2 >> 1, cl = c / EPC, i = c % EPC;
+      float a = 0.f;
+      for (int vl = 0; vl < wk.vpp; ++vl) a += red[((vl * wk.cpv + cl) * EPC + i) * 2 + (c2 & 1)];
+      prow[c2] = a;
+    }
   }
 }
 
@@ -865,7 +928,7 @@ int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void*
 }
 
 int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int C, int ksize, const uint8_t* mask, int bshift,
-                     int fd, int fh, int fw, const float* w, const float* bias, void* y, void* stream) {
+                     int fd, int fh, int fw, const float* w, const float* bias, void* y, float* partials, void* stream) {
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
@@ -874,9 +937,16 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;      // stage-0 tensor: 16^3 patches
   const int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
   const int pad_ = ksize / 2;
-  const size_t sm = sizeof(float) * ((size_t)C * ksize * ksize * ksize + (size_t)(SBD + 2 * pad_) * (SBH + 2 * pad_) * (SBW + 2 * pad_));
-  DISPATCH_T(dtype, AM_LAUNCH(stem_conv_fwd_kernel<float>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (float*)y),
-             AM_LAUNCH(stem_conv_fwd_kernel<bf16_t>, dim3(nb), dim3(256), sm, st, x, g, ksize, w, bias, (bf16_t*)y));
+  size_t fl = (size_t)C * ksize * ksize * ksize;
+  if (partials && fl < (size_t)256 * 8 * 2) fl = (size_t)256 * 8 * 2;    // the statistics fold reuses the weight area
+  const size_t sm = sizeof(float) * (fl + (size_t)(SBD + 2 * pad_) * (SBH + 2 * pad_) * (SBW + 2 * pad_));
+  if (ksize == 3) {
+    DISPATCH_T(dtype, AM_LAUNCH((stem_conv_fwd_kernel<float, 3>), dim3(nb), dim3(256), sm, st, x, g, w, bias, (float*)y, partials),
+               AM_LAUNCH((stem_conv_fwd_kernel<bf16_t, 3>), dim3(nb), dim3(256), sm, st, x, g, w, bias, (bf16_t*)y, partials));
+  } else {
+    DISPATCH_T(dtype, AM_LAUNCH((stem_conv_fwd_kernel<float, 1>), dim3(nb), dim3(256), sm, st, x, g, w, bias, (float*)y, partials),
+               AM_LAUNCH((stem_conv_fwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), sm, st, x, g, w, bias, (bf16_t*)y, partials));
+  }
   AM_CHECK_LAUNCH();
   return 0;
 }

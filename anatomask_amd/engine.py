@@ -138,7 +138,7 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
     stride = 2 if (first and s > 0) else 1
     rec_ = {"p": p, "s": s, "first": first, "stride": stride, "x": x}
     if s == 0 and first:
-        y1, pt1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt), None
+        y1, pt1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt, want_partials=True)
     else:
         y1, pt1 = ops.conv3d(CONV_FWD, x, pk.get(W, f"{p}.conv1.weight", False, False), W[f"{p}.conv1.bias"], sp, 3, stride,
                              in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs,

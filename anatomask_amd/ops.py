@@ -141,15 +141,20 @@ def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, strid
 
 
 def stem_conv_fwd(x_b1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mask: Optional[MaskInfo], bshift: int,
-                  dtype: torch.dtype) -> torch.Tensor:
-    """x_b1: fp32 [B,D,H,W]; w: (C,1,k,k,k) fp32."""
+                  dtype: torch.dtype, want_partials: bool = False):
+    """x_b1: fp32 [B,D,H,W]; w: (C,1,k,k,k) fp32.  want_partials: also return the (sum, sumsq) rows for the norm that follows."""
     B, D, H, W = x_b1.shape
     Cc, k = w.shape[0], w.shape[2]
     y = torch.empty(B, D, H, W, Cc, device=x_b1.device, dtype=dtype)
     mp, fd, fh, fw = _mk(mask)
+    part = None
+    if want_partials:
+        part = ConvPartials.__new__(ConvPartials)
+        part.rows, part.C = B * (D // 4) * (H // 8) * (W // 16), Cc
+        part.t = torch.empty(part.rows, Cc, 2, device=x_b1.device, dtype=torch.float32)
     hip.lib().stem_conv_fwd(_dt(y), x_b1.data_ptr(), B, D, H, W, Cc, k, mp, bshift, fd, fh, fw, w.data_ptr(), _p(bias),
-                            y.data_ptr(), _stream())
-    return y
+                            y.data_ptr(), part.t.data_ptr() if part else None, _stream())
+    return (y, part) if want_partials else y
 
 
 def stem_conv_wgrad(x_b1: torch.Tensor, dy: torch.Tensor, ksize: int, mask: Optional[MaskInfo], bshift: int,

@@ -78,7 +78,9 @@ int am_unpack_grad(const float* src_packed, float* dst, int R, int K, int taps, 
 /* Cin = 1 stem convolutions (STUNet stage 0 conv1 k3 / conv3 k1 on the masked input volume,
  * P/STUNet_head.py:81,92 under P/encoder3D.py:12-15) and their weight/bias gradients. */
 int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int C, int ksize, const uint8_t* mask, int bshift,
-                     int fd, int fh, int fw, const float* w, const float* bias, void* y, void* stream);
+                     int fd, int fh, int fw, const float* w, const float* bias, void* y,
+                     float* partials /* NULL or [B*(D/4)*(H/8)*(W/16)][C][2]: per-workgroup sum / sum of squares of y, as am_conv3d */,
+                     void* stream);
 int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum, void* stream);
 

@@ -185,8 +185,17 @@ def test_stem_conv(ops, dtype, k):
     dy = q(rnd(B, C, *sp, seed=4), dtype) * O.upsample_mask(mask, sp).float()
     yr = O.sparse_conv3d(x * O.upsample_mask(mask, sp).float(), w, b, 1, mask)
     yr.backward(dy)
-    y = ops.stem_conv_fwd(x[:, 0].contiguous().to(DEV), w.detach().to(DEV), b.detach().to(DEV), mi, 4, dtype)
+    y, part = ops.stem_conv_fwd(x[:, 0].contiguous().to(DEV), w.detach().to(DEV), b.detach().to(DEV), mi, 4, dtype, want_partials=True)
     close(from_cl(y), yr.detach(), TOL[dtype], "stem fwd", O.upsample_mask(mask, sp).float())
+    sums = torch.zeros(C, 2, device=DEV, dtype=torch.float64)            # statistics partials = sums of the STORED active values
+    part.reduce(sums=sums)
+    ya = torch.where(O.upsample_mask(mask, sp).expand(B, C, *sp), from_cl(y), torch.zeros(())).double()   # inactive voxels: don't-care bits
+    n_act = float(O.upsample_mask(mask, sp).sum())
+    e1 = (sums[:, 0].cpu() - ya.sum((0, 2, 3, 4))).abs().max().item()
+    e2 = (sums[:, 1].cpu() - (ya * ya).sum((0, 2, 3, 4))).abs().max().item()
+    # per-workgroup partials are fp32 sums of 512 values: error ~1e-7 * |values| * n
+    assert e1 <= 2e-6 * n_act * ya.abs().max().item(), (e1, n_act)
+    assert e2 <= 2e-6 * n_act * (ya * ya).max().item(), (e2, n_act)
     dw = torch.zeros(C, k ** 3, device=DEV); db = torch.zeros(C, device=DEV)
     ops.stem_conv_wgrad(x[:, 0].contiguous().to(DEV), to_cl(dy, dtype), k, mi, 4, dw, db)
     close(dw.cpu().view_as(w), w.grad, 5e-4, "stem wgrad")
