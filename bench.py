@@ -54,7 +54,7 @@ def dominant_kernel_roofline(B, dev):
     achieved = flops / t / 1e12
     # HBM bytes per launch from the PMC counters of the SAME launch shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc_traffic.md, measured at B=2 -> linear in B
-    traffic = (615e6 + 537e6) * B / 2
+    traffic = (605.5e6 + 536.9e6) * B / 2
     return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4,11> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
             "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, scaled from B=2)",
