@@ -687,6 +687,38 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
     if (k0 + kk < Kp) TT<T>::st(dst + ((size_t)tp * Rp + r) * Kp + k0 + kk, tile[kk * taps + tp]);
   }
 }
+// the same repack for a table of weights: block -> (descriptor by binary search on first_block, row, 64-wide k block)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const am_pack_desc* __restrict__ descs, int nd) {
+  __shared__ float tile[64 * 64];                          // taps <= 64
+  int lo = 0, hi = nd;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid; }
+  const am_pack_desc d = descs[lo];
+  const int local = blockIdx.x - d.first_block, nkb = (d.Kp + 63) / 64;
+  const int r = local / nkb, k0 = (local % nkb) * 64;
+  const int taps = d.taps, n = 64 * taps;
+  const float* __restrict__ src = d.src;
+  T* __restrict__ dst = (T*)d.dst;
+  if (r < d.R) {
+    if (d.stride_k == taps) {
+      const float* base = src + r * d.stride_r + (long)k0 * taps;
+      const int lim = (d.K - k0 < 64 ? (d.K - k0 > 0 ? d.K - k0 : 0) : 64) * taps;
+      for (int i = threadIdx.x; i < n; i += 256) tile[i] = i < lim ? base[i] : 0.f;
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) {
+        const int kk = i / taps, tp = i - kk * taps;
+        tile[i] = (k0 + kk < d.K) ? src[r * d.stride_r + (long)(k0 + kk) * d.stride_k + tp] : 0.f;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += 256) tile[i] = 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int kk = i % 64, tp = i / 64;
+    if (k0 + kk < d.Kp) TT<T>::st(dst + ((size_t)tp * d.Rp + r) * d.Kp + k0 + kk, tile[kk * taps + tp]);
+  }
+}
 // dst[r*sr + k*sk + t] (+)= src[t][r][k]
 __global__ void unpack_grad_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int K, int taps, long sr, long sk, int accumulate) {
   const long n = (long)taps * R * K;
@@ -1017,6 +1049,15 @@ int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int tap
   const size_t sm = sizeof(float) * 64 * taps;
   DISPATCH_T(dtype, AM_LAUNCH(pack_weight_kernel<float>, grid, dim3(256), sm, st, src, (float*)dst, R, K, taps, stride_r, stride_k, Rp, Kp),
              AM_LAUNCH(pack_weight_kernel<bf16_t>, grid, dim3(256), sm, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k, Rp, Kp));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_pack_weights_batched(int dtype, const am_pack_desc* descs, int ndesc, int total_blocks, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (ndesc <= 0 || total_blocks <= 0) return 0;
+  DISPATCH_T(dtype, AM_LAUNCH(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, st, descs, ndesc),
+             AM_LAUNCH(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, descs, ndesc));
   AM_CHECK_LAUNCH();
   return 0;
 }

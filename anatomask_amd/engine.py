@@ -110,21 +110,43 @@ def _batch_norm(x, W, prefix, train: bool, part=None, update_running: bool = Tru
 
 
 class PackCache:
-    """Compute-dtype MFMA-layout copies of the conv weights, rebuilt when the fp32 master changes."""
+    """Compute-dtype MFMA-layout copies of the conv weights, rebuilt when the fp32 master changes.
+    The first step packs each weight when it is first used; from then on the packed copies persist and ONE batched launch
+    (`am_pack_weights_batched`) rebuilds all of them after every optimizer / EMA update (84 launches -> 1)."""
 
     def __init__(self, dtype):
         self.dtype = dtype
         self.store: Dict[Tuple[str, bool], torch.Tensor] = {}
+        self.src: Dict[Tuple[str, bool], torch.Tensor] = {}
+        self.dirty = False
+        self.table = None
 
     def invalidate(self):
-        self.store.clear()
+        self.dirty = bool(self.store)
+
+    def _refresh(self):
+        pairs = [(self.src[k], self.store[k]) for k in self.store]
+        if self.table is None or not self.table.matches(pairs):
+            self.table = ops.PackTable(pairs, self.dtype, pairs[0][1].device)
+        self.table.repack()
+        self.dirty = False
 
     def get(self, W, name: str, transposed: bool, dgrad: bool) -> torch.Tensor:
         key = (name, dgrad)
         t = self.store.get(key)
+        if t is not None and self.src[key].data_ptr() != W[name].data_ptr():    # the master moved (new flat buffer): start over
+            self.store.clear(); self.src.clear(); self.table = None; self.dirty = False
+            t = None
         if t is None:
+            if self.dirty:
+                self._refresh()
             t = ops.pack_weight(W[name], self.dtype, transposed, dgrad)
             self.store[key] = t
+            self.src[key] = W[name]
+            self.table = None
+            return t
+        if self.dirty:
+            self._refresh()
         return t
 
 

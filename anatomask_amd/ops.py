@@ -85,7 +85,30 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_
     out = torch.empty(taps, Rp, Kp, device=w.device, dtype=dtype)
     hip.lib().pack_weight(_dt(out), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, Rp, Kp, _stream())
     out.logical = (R, K)
+    out.pack_args = (R, K, taps, sr, sk, Rp, Kp)
     return out
+
+
+class PackTable:
+    """Device table of am_pack_desc for `am_pack_weights_batched`: every (master weight, packed copy) pair of a model."""
+
+    def __init__(self, pairs, dtype: torch.dtype, device):
+        import struct
+        blob, first = b"", 0
+        for w, out in pairs:
+            R, K, taps, sr, sk, Rp, Kp = out.pack_args
+            assert taps <= 64
+            blob += struct.pack("<QQqqiiiiii", w.data_ptr(), out.data_ptr(), sr, sk, R, K, taps, Rp, Kp, first)
+            first += Rp * ((Kp + 63) // 64)
+        self.n, self.blocks, self.dtype = len(pairs), first, dtype
+        self.ptrs = [(w.data_ptr(), out.data_ptr()) for w, out in pairs]
+        self.dev = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+
+    def matches(self, pairs) -> bool:
+        return len(pairs) == self.n and all(p == (w.data_ptr(), o.data_ptr()) for p, (w, o) in zip(self.ptrs, pairs))
+
+    def repack(self):
+        hip.lib().pack_weights_batched(hip.DT_BF16 if self.dtype == torch.bfloat16 else hip.DT_F32, self.dev.data_ptr(), self.n, self.blocks, _stream())
 
 
 def unpack_grad(dw_packed: torch.Tensor, grad_out: torch.Tensor, transposed_conv: bool, accumulate: bool):

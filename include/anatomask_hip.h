@@ -71,6 +71,12 @@ int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, c
 /* dst[t][r][k] = src[r*stride_r + k*stride_k + t] (zero in the padding): torch-layout fp32 master -> packed [taps][Rp][Kp]. */
 int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, int Rp, int Kp,
                    void* stream);
+/* All weight repacks of a step in ONE launch (the masters are views of one flat buffer and the packed copies persist, so the
+ * descriptor table is built once): descs[i] repacks like am_pack_weight; first_block is the running sum of Rp * ceil(Kp/64). */
+typedef struct am_pack_desc {
+  const float* src; void* dst; long stride_r, stride_k; int R, K, taps, Rp, Kp, first_block;
+} am_pack_desc;                                       /* 56 bytes, device memory */
+int am_pack_weights_batched(int dtype, const am_pack_desc* descs, int ndesc, int total_blocks, void* stream);
 /* dst[r*stride_r + k*stride_k + t] (+)= src[t][r][k]: packed fp32 gradient -> torch layout. */
 int am_unpack_grad(const float* src_packed, float* dst, int R, int K, int taps, long stride_r, long stride_k, int accumulate,
                    void* stream);
