@@ -213,7 +213,8 @@ def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, 
 
 
 def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
-            tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False, recompute: bool = False):
+            tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False, recompute: bool = False,
+            want_to_dec0: bool = False):
     """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps).
     recompute=True is the P/GC.py policy (torch.utils.checkpoint per encoder stage :324 and per decoder block :68): the tape
     keeps only stage / block INPUTS; backward re-runs that stage's forward before differentiating it."""
@@ -262,6 +263,8 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
     rec = ops.proj_fwd(x, W["dense_decoder.proj.weight"].view(-1), W["dense_decoder.proj.bias"])
     if tape is not None:
         tape.last = x
+    if want_to_dec0:                         # coarsest densified map, channels-last (SparK.forward(return_feat=True), P/AnatoMask.py:172-173)
+        return rec, to_dec[0]
     return (rec, feats) if want_feats else rec
 
 

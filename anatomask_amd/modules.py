@@ -179,8 +179,10 @@ class _SparKFn(torch.autograd.Function):
     def forward(ctx, model: "SparK", inp_b1, mask_info, *params):
         need_grad = any(ctx.needs_input_grad[3:])          # False under torch.no_grad() (teacher pass)
         tape = engine.Tape() if need_grad else None
-        rec = engine.forward(model.spec, model._W, model._pack, inp_b1, mask_info, model.training, tape, recompute=model.recompute)
+        rec, dec0 = engine.forward(model.spec, model._W, model._pack, inp_b1, mask_info, model.training, tape, recompute=model.recompute,
+                                   want_to_dec0=True)
         ctx.model, ctx.tape, ctx.inp, ctx.mask = model, tape, inp_b1, mask_info
+        model._last_dec0 = dec0                             # (B,f,f,f,C) channels-last; read by forward(return_feat=True), carries no gradient
         return rec
 
     @staticmethod
@@ -352,10 +354,11 @@ class SparK(nn.Module):
     def forward(self, inp_bchwd: torch.Tensor, active_b1ff=None, vis=False, return_feat=False):
         if active_b1ff is None:
             active_b1ff = self.mask(inp_bchwd.shape[0], inp_bchwd.device)
-        if return_feat:
-            raise NotImplementedError("return_feat is unused by the AnatoMask drivers")
         rec_bchwd = self.reconstruct(inp_bchwd, active_b1ff)
         inp, rec = self.patchify(inp_bchwd), self.patchify(rec_bchwd)
+        if return_feat:                                            # P/AnatoMask.py:172-173: to_dec[0].flatten(2).permute(0, 2, 1)
+            d0 = self._last_dec0                                   # (no caller of the reference differentiates through it)
+            return inp, rec, d0.reshape(d0.shape[0], -1, d0.shape[-1]).float()
         if vis:                                                    # P/AnatoMask.py:179-185
             p = self.downsample_ratio
             act = active_b1ff.repeat_interleave(p, 2).repeat_interleave(p, 3).repeat_interleave(p, 4)

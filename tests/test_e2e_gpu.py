@@ -380,3 +380,44 @@ def test_plain_spark_step_vs_oracle():
     assert torch.equal(o["mask"].cpu().bool().view(mask.shape), mask)
     assert abs(o["loss"].item() - float(loss_o)) < 2e-4 * abs(float(loss_o))
     assert abs(o["grad_norm"].item() - gn_o) < 5e-2 * gn_o
+
+
+def test_forward_return_feat_and_vis():
+    """SparK.forward(return_feat=True) / (vis=True) outputs (P/AnatoMask.py:172-185) vs the oracle's densify / unpatchify."""
+    f = load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    W0 = O.closed_form_state(cfg)
+    x = np_volume(2, cfg.input_size, 43)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(9))
+    m = make_model(cfg, W0).eval()
+    with torch.no_grad():
+        inp, rec, feat = m(x.to(DEV), active_b1ff=mask.to(DEV), return_feat=True)
+        vin, vmasked, vrec = m(x.to(DEV), active_b1ff=mask.to(DEV), vis=True)
+    p = {k: v.clone() for k, v in W0.items()}
+    act = O.upsample_mask(mask, cfg.input_size)
+    feats = O.encoder_forward(cfg, p, x * act.float(), mask)
+    to_dec = O.densify(cfg, p, feats, mask)
+    want_feat = to_dec[0].flatten(start_dim=2).permute(0, 2, 1)
+    assert feat.shape == want_feat.shape
+    assert (feat.cpu() - want_feat).abs().max() <= 2e-4 * want_feat.abs().max()
+    inp_o, rec_o = O.spark_forward(cfg, p, x, mask, False)
+    mean, var = inp_o.mean(-1, keepdim=True), (inp_o.var(-1, keepdim=True) + 1e-6) ** .5
+    want_rec = torch.where(act, x, O.unpatchify(cfg, rec_o * var + mean))
+    assert torch.equal(vin.cpu(), x) and torch.equal(vmasked.cpu(), x * act)
+    assert (vrec.cpu() - want_rec).abs().max() <= 2e-4 * want_rec.abs().max()
+
+
+def test_config1_stunet_small_plain_spark_step():
+    """BASELINE.json configs[0]: STUNet-small (dims 16..256, width 256), 48^3 patch, bs 2, plain SparK (random mask, no teacher):
+    one fused HIP step vs the CPU oracle step on the same volumes, fp32."""
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    cfg = O.Config([16, 32, 64, 128, 256, 256], [1] * 6, 256, (48, 48, 48), 0.6)
+    W0 = O.closed_form_state(cfg)
+    x = np_volume(2, cfg.input_size, 51)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(10))
+    loss_o, _, grads, _ = O.student_loss_and_grads(cfg, {k: v.clone() for k, v in W0.items()}, x, mask)
+    gn_o = float(O.clip_grad_norm({k: g for k, g in grads.items() if g is not None}, 12.0))
+    tr = AnatoMaskTrainer(make_model(cfg, W0), lr=1e-4, total_epochs=1000, distributed=False, self_distill=False)
+    o = tr.step(x.to(DEV), epoch=0, mask1=mask)
+    assert abs(o["loss"].item() - float(loss_o)) < 2e-4 * abs(float(loss_o))
+    assert abs(o["grad_norm"].item() - gn_o) < 5e-2 * gn_o
