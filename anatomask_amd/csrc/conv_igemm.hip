@@ -7,21 +7,26 @@
 //   its data gradient               (a k4 s2 p1 convolution of dy)
 //
 // Formulation.  Output voxels are enumerated as o = q*OS + p (OS in {1,2}; p = parity class when
-// OS == 2) and every tap t of the class reads the source voxel  q*IS + shift_t  (IS in {1,2}):
+// OS == 2) and every tap t reads the source voxel  q*IS + shift_t  (IS in {1,2}):
 //     y[o][co] = sum_t sum_ci  x[q*IS + shift_t][ci] * W[widx_t][co][ci]
-// so all taps of a class are wave-uniform.  A workgroup (4 waves) owns a BDxBHxBW brick of q and
-// NT = 16*NS output channels.  Per 64-byte channel slab (32 bf16 / 16 f32 channels) the haloed
-// source brick is staged ONCE into LDS (branch-free coalesced 16-byte loads; out-of-range voxels and
-// voxels of inactive 16^3-patches become zeros), then every tap reads its shifted window from LDS
+// Taps are grouped into UNITS = one dense source sub-brick + the taps that read it (an output parity class when OS == 2,
+// a source parity sub-lattice when IS == 2), so all taps of a unit are wave-uniform shifts inside one LDS brick.
+// A workgroup (4 waves) owns a BDxBHxBW brick of q and NT = 16*NS output channels.  Per 64-byte channel slab (32 bf16 /
+// 16 f32 channels) the haloed source brick is staged ONCE into LDS (branch-free coalesced 16-byte buffer loads; out-of-range
+// voxels and voxels of inactive patches are the hardware's zero fill), then every tap reads its shifted window from LDS
 // (the 3x3x3 stencil reuse) and contracts channels on the matrix cores:
-//     D(16 cout x 16 voxel) += A(weight fragments) * B(voxel fragments), both ds_read_b128 from XOR-swizzled,
-//     bank-conflict-free LDS images.  Weights reach LDS in groups of 3 taps, double-buffered: the next group's
-//     global loads are in flight while the current group's MFMAs issue, and the 4 waves share one copy
-//     (per-wave weight loads from L1/L2 would need 128 B/clk/CU -- twice what the vector memory path delivers).
+//     D(16 cout x 16 voxel) += A(weight fragments) * B(voxel fragments), both ds_read_b128.
+//   * source brick: 80-byte rows, so a fragment address is (lane constant) + (scalar tap offset): zero VALU per read.  These
+//     reads are 2-way bank-conflicted; the conflict-free alternatives were measured slower (profiles/r01_conv_ablation.md).
+//   * weights: XOR-swizzled 64-byte rows (conflict-free), in double-buffered groups of 3 taps shared by the 4 waves: the next
+//     group's global loads fly while the current group's MFMAs issue (per-wave weight loads from L1/L2 would need
+//     128 B/clk/CU -- twice what the vector memory path delivers).
+//   * slabs are software-pipelined: slab k+1 and its first weight group are loaded into registers during slab k's MFMAs.
 // Packed weights are zero-padded to whole tiles, so the inner loop has no bounds logic at all.
-// Accumulators stay in registers across all slabs and taps; the epilogue adds the bias, applies the
-// output patch mask, writes 4 consecutive channels per lane and (optionally) leaves per-workgroup
-// per-channel partial sums (sum, sum of squares) for the norm that follows -- no extra pass over y.
+// Accumulators stay in registers across all slabs, taps and units; the epilogue adds the bias, optionally an eval-mode
+// BatchNorm (scale/shift), a skip tensor and an activation, applies the output patch mask, writes 8 consecutive channels
+// (16 bytes) per lane and (optionally) leaves per-workgroup per-channel partial sums (sum, sum of squares) for the norm
+// that follows -- no extra pass over y.
 #include "common.h"
 #include "../../include/anatomask_hip.h"
 
