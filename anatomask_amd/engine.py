@@ -15,6 +15,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -269,9 +271,46 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
 
 
 # ====================================================================================== backward
+# Weight gradients leave the critical chain (norm backward -> dgrad -> norm backward ...): they run on a side HIP stream, where
+# the MFMA-bound wgrad kernels overlap the HBM-bound norm-backward passes of the next layer.  Ordering: the side stream waits
+# for an event recorded when dy exists; the main stream waits for the side stream before a parameter group is declared final
+# (all-reduce hook) and at the end of backward.  record_stream keeps the caching allocator from recycling x / dy early.
+_SIDE: Dict[int, "torch.cuda.Stream"] = {}
+_USE_SIDE = not os.environ.get("AM_NO_SIDE_STREAM")
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    if i not in _SIDE:
+        _SIDE[i] = torch.cuda.Stream(device=dev)
+    return _SIDE[i]
+
+
+def _on_side(dev, tensors, fn):
+    if not _USE_SIDE:
+        return fn()
+    s2 = _side_stream(dev)
+    ev = torch.cuda.Event()
+    ev.record()
+    s2.wait_event(ev)
+    with torch.cuda.stream(s2):
+        fn()
+    for t in tensors:
+        t.record_stream(s2)
+
+
+def _join_side(dev):
+    if _USE_SIDE and _SIDE:
+        ev = torch.cuda.Event()
+        ev.record(_side_stream(dev))
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def _wgrad_into(G, name, mode, x, dy, k, stride, transposed=False, **masks):
-    dwp = ops.conv3d_wgrad(mode, x, dy, k, stride, **masks)
-    ops.unpack_grad(dwp, G[name], transposed, accumulate=True)
+    def run():
+        dwp = ops.conv3d_wgrad(mode, x, dy, k, stride, **masks)
+        ops.unpack_grad(dwp, G[name], transposed, accumulate=True)
+    _on_side(x.device, (x, dy), run)
 
 
 def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo,
@@ -312,6 +351,7 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
         _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
     dproj[0] = g
     if after_group:
+        _join_side(drec.device)
         after_group("decoder")
     # ---- densify: grads wrt the encoder feature maps (active voxels only)
     dfeat: List[Optional[torch.Tensor]] = [None] * spec.n_stage
@@ -330,6 +370,7 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
                                          G[f"densify_norms.{i}.weight"], G[f"densify_norms.{i}.bias"],
                                          dtoken=G[f"mask_tokens.{i}"].view(-1), fill=True)
     if after_group:
+        _join_side(drec.device)
         after_group("densify")
     # ---- encoder, deep -> shallow.  gstage[s] = gradient wrt the stage-s output map (active voxels only)
     gstage: List[Optional[torch.Tensor]] = list(dfeat)
@@ -384,4 +425,6 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
                                 in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
                 gout = ops.add(gx, dpre, out=gx)
         if after_group:
+            _join_side(drec.device)
             after_group(f"stage{s}")
+    _join_side(drec.device)
