@@ -1,0 +1,46 @@
+"""Host-side mirror of the reference interface: names, state_dict contract and error conventions.  No GPU needed."""
+import pytest
+import torch
+
+from anatomask_amd import modules as M
+from oracle import anatomask_oracle as O
+
+DIMS, WIDTH, SIZE = [8, 16, 32, 64, 128, 128], 128, (32, 48, 64)
+
+
+def build(mask_ratio=0.6):
+    return M.build_spark(DIMS, [1] * 6, WIDTH, SIZE, mask_ratio)
+
+
+def test_state_dict_contract_131_keys_and_shapes():
+    """Same 131 keys / shapes as the reference model (pinned through the oracle's inventory, tests/test_oracle_golden.py)."""
+    sd = build().state_dict()
+    ps = O.param_shapes(O.Config(DIMS, [1] * 6, WIDTH, SIZE, 0.6))
+    assert len(sd) == 131 and set(sd) == set(ps)
+    assert all(tuple(sd[k].shape) == tuple(ps[k]) for k in ps)
+    assert "config" in build().state_dict(with_config=True)                       # P/AnatoMask.py:257-262
+
+
+def test_error_conventions():
+    m = build()
+    with pytest.raises(RuntimeError, match="HIP engine"):                         # no CPU / torch fallback path exists
+        m(torch.randn(1, 1, *SIZE))
+    with pytest.raises(AttributeError, match="config mismatch"):                  # P/AnatoMask.py:268-276
+        build(0.5).load_state_dict(m.state_dict(with_config=True), strict=True)
+    with pytest.raises(RuntimeError):                                             # P/AnatoMask.py:225: extent not divisible by 16
+        m.patchify(torch.randn(1, 1, 30, 48, 64))
+
+
+def test_mask_and_schedules_and_wrappers():
+    m = build()
+    mk = m.mask(3, "cpu", generator=torch.Generator().manual_seed(0))             # P/AnatoMask.py:75-79
+    assert mk.shape == (3, 1, 2, 3, 4) and mk.dtype == torch.bool and int(mk.sum()) == 3 * m.len_keep
+    assert m.len_keep == round(24 * 0.4)
+    assert m.sparse_encoder.downsample_ratio == 16 and m.dense_decoder.width == WIDTH
+    ema = M.ModelEma(m, 0.999, device=None)
+    assert isinstance(ema.ema, M.SparK) and ema.decay == 0.999 and not ema.ema.training      # teacher is always eval
+    ddp = M.LocalDDP(m)
+    assert next(iter(ddp.state_dict())).startswith("module.")                     # P/pretrain_AntoMask.py:201-207
+    groups = M.get_param_groups(m, nowd_keys={"mask_token"})
+    assert len(groups) == 2 and sum(len(g["params"]) for g in groups) == sum(1 for _ in m.parameters())
+    assert M.ema_decay_for_epoch(0, 1000) == pytest.approx(0.999) and M.ema_decay_for_epoch(999, 1000) == pytest.approx(0.9999)

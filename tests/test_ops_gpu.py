@@ -487,3 +487,20 @@ def test_partials_reduce_paths(ops, rows, C):
     want = part.t.double().sum(0)
     assert torch.allclose(sums, want, rtol=0, atol=1e-9)
     assert torch.allclose(acc.double(), 1.0 + want[:, 0], rtol=0, atol=1e-4)
+
+
+def test_abi_rejects_bad_arguments(ops):
+    """Error convention of the C ABI: negative return codes for argument errors (surfaced as RuntimeError by the binding), no launch."""
+    x = torch.zeros(1, 8, 8, 8, 12, device=DEV, dtype=torch.bfloat16)            # C % 8 != 0
+    w = ops.pack_weight(torch.zeros(16, 16, 3, 3, 3, device=DEV), torch.bfloat16, False, False)
+    w.logical = (16, 12)
+    with pytest.raises(RuntimeError, match="am_conv3d failed with code -1"):
+        ops.conv3d(ops.CONV_FWD, x, w, None, (8, 8, 8), 3, 1)
+    x16 = torch.zeros(1, 8, 8, 8, 16, device=DEV, dtype=torch.bfloat16)
+    w5 = ops.pack_weight(torch.zeros(16, 16, 3, 3, 3, device=DEV), torch.bfloat16, False, False)
+    with pytest.raises(RuntimeError, match="am_conv3d failed with code -2"):      # ConvTranspose3d is k4 s2 only
+        ops.conv3d(ops.CONVT_FWD, x16, w5, None, (16, 16, 16), 3, 2)
+    with pytest.raises(RuntimeError, match="am_conv3d_wgrad failed with code -2"):
+        ops.conv3d_wgrad(ops.CONV_FWD, x16, x16, 5, 1)
+    with pytest.raises(RuntimeError, match="am_stem_conv_fwd failed with code -2"):   # the stem kernels need the 16^3 patch mask
+        ops.stem_conv_fwd(torch.zeros(1, 16, 16, 16, device=DEV), torch.zeros(16, 1, 3, 3, 3, device=DEV), None, None, 4, torch.bfloat16)
