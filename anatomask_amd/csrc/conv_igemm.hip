@@ -57,7 +57,9 @@ struct ConvArgs {
 
 constexpr int ROWB = 64;      // channel-slab bytes staged per voxel / per weight row (unpadded, XOR-swizzled)
 constexpr int LROWB = 80;     // LDS row stride of the source brick (16 B pad; B-fragment address = lane const + scalar tap offset)
-constexpr int TG_OF(int ns) { return ns == 2 ? 6 : 3; }   // taps per weight group staged in LDS: ~48 MFMAs per wave between barriers
+// taps per weight group staged in LDS (TGS = 3: ~48 MFMAs per wave between barriers).  Multi-unit plans (strided / transposed:
+// units of 1, 2, 4 or 8 taps) take TGS = 2: groups of 3 would pad 27 real taps to 39 issued ones (8 to 9 for ConvT), groups of 2 to 28.
+constexpr int TG_OF(int ns, int tgs) { return ns == 2 ? 2 * tgs : tgs; }
 
 // LDS image of a [rows][64 B] tile: 16-byte chunk c of row r lives at r*64 + ((c ^ 2*bit2(r)) * 16).
 // With this swizzle a ds_read_b128 of 16 consecutive rows (any alignment) x 4 chunks is bank-conflict free
@@ -69,14 +71,14 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row << 6) + ((c
 // lane and the 4 lane groups of a voxel write one contiguous 64-byte run (instead of 8-byte pieces of four 32-byte runs).
 __device__ __forceinline__ int crow(int R) { return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3); }
 
-template <typename T, int BD, int BH, int BW, int NS, int NIT>
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
   constexpr int MV = BD * BH * BW;
   constexpr int VS = MV / 64;                           // 16-voxel subtiles per wave
   constexpr int NT = 16 * NS;                           // output channels per workgroup
-  constexpr int TG = TG_OF(NS);
+  constexpr int TG = TG_OF(NS, TGS);
   constexpr int WBUF = TG * NT * ROWB;                  // bytes of one weight-group buffer
   constexpr int WCH = TG * NT * 4;                      // 16-byte chunks per weight group
   constexpr int WIT = (WCH + 255) / 256;
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 }
 
 // host: tap tables ------------------------------------------------------------------------------
-struct Plan { ConvArgs a; int bd, bh, bw; size_t lds; int nit, nt_tile; };
+struct Plan { ConvArgs a; int bd, bh, bw; size_t lds; int nit, nt_tile, tgs; };
 
 int build_plan(Plan& P, int mode, int k, int stride) {
   ConvArgs& a = P.a;
@@ -407,14 +409,15 @@ int build_plan(Plan& P, int mode, int k, int stride) {
   size_t brick = mxv * LROWB;
   if (brick < 4096) brick = 4096;                        // the stats epilogue reuses the head of the brick
   a.w_lds_off = (int)brick;
-  P.lds = a.w_lds_off + 2 * TG_OF(P.nt_tile / 16) * P.nt_tile * ROWB;
+  P.tgs = a.nunit > 1 ? 2 : 3;
+  P.lds = a.w_lds_off + 2 * TG_OF(P.nt_tile / 16, P.tgs) * P.nt_tile * ROWB;
   return 0;
 }
 
-template <typename T, int BD, int BH, int BW, int NS, int NIT>
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3>
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
-  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT>;
+  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS>;
   static size_t attr_lds = 48 * 1024;             // raise the dynamic-LDS cap only when a launch needs it
   if (P.lds > attr_lds) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds) == hipSuccess) attr_lds = P.lds;
@@ -429,6 +432,11 @@ int launch(Plan& P, hipStream_t st) {
 template <typename T, int NS>
 int dispatch_nit(Plan& P, int shape, hipStream_t st) {
   const int n = P.nit;
+  if (P.tgs == 2) {                              // multi-unit plans: sub-bricks of at most (BD+1)(BH+1)(BW+1) voxels
+    if (shape == 2) return n <= 4 ? launch<T, 4, 4, 4, NS, 4, 2>(P, st) : -3;
+    if (shape == 1) return n <= 4 ? launch<T, 4, 4, 16, NS, 4, 2>(P, st) : n <= 7 ? launch<T, 4, 4, 16, NS, 7, 2>(P, st) : -3;
+    return n <= 4 ? launch<T, 4, 8, 8, NS, 4, 2>(P, st) : n <= 7 ? launch<T, 4, 8, 8, NS, 7, 2>(P, st) : -3;
+  }
   if (shape == 2) {                              // 4x4x4 brick: tiny grids only (more workgroups)
     if (n <= 4) return launch<T, 4, 4, 4, NS, 4>(P, st);
     return -3;
