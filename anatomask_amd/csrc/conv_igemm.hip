@@ -118,6 +118,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 
   const int u0 = a.OS == 2 ? cls : 0, u1 = a.OS == 2 ? cls + 1 : a.nunit;
+  // an output parity class without taps (k1 s2 data gradient: 7 of 8 classes) contributes zeros: when the launch accumulates into
+  // y there is nothing to do -- do not read-modify-write 7/8 of the tensor
+  if (a.OS == 2 && a.accumulate && !part && a.tap_begin[cls + 1] == a.tap_begin[cls]) return;
 
   // tap table -> one VGPR (lane t = tap t of the plan, <= 64 taps): byte offset of the tap's window inside its unit's brick | widx << 20.
   // Taps are fetched with v_readlane (no LDS round trip in front of every weight load / fragment read).
