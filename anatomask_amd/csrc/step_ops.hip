@@ -26,6 +26,10 @@ __global__ __launch_bounds__(256) void patch_loss_fwd_kernel(const float* __rest
   const int b = blockIdx.x / L, l = blockIdx.x % L;
   const int pw = l % fw, ph = (l / fw) % fh, pd = l / (fw * fh);
   const int z = threadIdx.x >> 4, y = threadIdx.x & 15;
+  if (active[blockIdx.x] && !pmean) {                      // visible patch of a loss-only pass: contributes 0, its rec voxels may be unwritten
+    if (threadIdx.x == 0) l2m[blockIdx.x] = 0.f;
+    return;
+  }
   const size_t base = (((size_t)b * D + pd * 16 + z) * H + ph * 16 + y) * W + pw * 16;
   float xi[16], xr[16];
 #pragma unroll

@@ -184,7 +184,7 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
     return out, rec_
 
 
-def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False):
+def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False, out_skip=None):
     """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record)."""
     q = f"{DEC}.{i}"
     so = tuple(2 * v for v in x.shape[1:4])
@@ -198,8 +198,10 @@ def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, 
         ops.norm_fold_running(st2, W[f"{q}.conv.4.weight"], W[f"{q}.conv.4.bias"], W[f"{q}.conv.4.running_mean"], W[f"{q}.conv.4.running_var"], 1e-5)
         r = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1,
                        ep_scale=st1.scale, ep_shift=st1.shift, ep_act=ACT_RELU6)
+        # out_skip (last block of a loss-only teacher pass): patch mask of the output voxels anyone will read -- the rest of the
+        # brick grid is not computed at all (P/pretrain_AntoMask.py:421-425 keeps the teacher's l2 of the MASKED patches only)
         o = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1,
-                       ep_scale=st2.scale, ep_shift=st2.shift, ep_res=nxt)
+                       ep_scale=st2.scale, ep_shift=st2.shift, ep_res=nxt, out_mask=out_skip, out_bshift=4 if out_skip is not None else 0)
         return o, None
     c1, pt1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1, want_partials=train), None
     if train:
@@ -216,7 +218,7 @@ def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, 
 
 def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
             tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False, recompute: bool = False,
-            want_to_dec0: bool = False):
+            want_to_dec0: bool = False, needed_patches: Optional[MaskInfo] = None):
     """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps).
     recompute=True is the P/GC.py policy (torch.utils.checkpoint per encoder stage :324 and per decoder block :68): the tape
     keeps only stage / block INPUTS; backward re-runs that stage's forward before differentiating it."""
@@ -258,7 +260,8 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
     x = to_dec[0]
     for i in range(n_dec):
         nxt = to_dec[i + 1] if i + 1 < n_dec else None
-        o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=tape is None)
+        o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=tape is None,
+                             out_skip=needed_patches if (i == n_dec - 1 and tape is None and not train) else None)
         if tape is not None:
             tape.dec.append({"q": rec_["q"], "xin": x, "nxt": nxt} if recompute else rec_)
         x = o

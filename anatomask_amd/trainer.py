@@ -97,7 +97,9 @@ class AnatoMaskTrainer:
         mi1 = ops.MaskInfo(m1.view(B, *spec.fmap))
         if self.self_distill:
             # 2. teacher pass + raw per-patch loss (:421-425)
-            rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False)
+            # (only the masked patches' teacher loss is used: the last decoder conv skips the visible 40 % of the volume)
+            need = ops.MaskInfo((1 - m1).view(B, *spec.fmap)) if spec.input_size[0] // spec.fmap[0] == 16 else None
+            rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False, needed_patches=need)
             recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
             del rec1
             # 3. hard-mask sampler (:427)
