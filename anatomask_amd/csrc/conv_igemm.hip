@@ -51,6 +51,7 @@ struct ConvArgs {
   MaskView in_mask, out_mask;
   int accumulate;
   int brick_in_patch;         // block-sparse output and the q-brick lies inside one patch: one mask lookup decides the whole brick
+  int hreuse;                 // taps ordered in h-runs of 3 (see build_plan): the HR kernel variant shares fragment rows across a run
   int nt_store;               // non-temporal output stores (outputs far larger than the 256 MB Infinity Cache)
   int dbg;                    // AM_CV_DBG ablation bits (timing experiments only): 1 no stores, 2 no source loads, 4 no weight loads
 };
@@ -71,7 +72,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return (row << 6) + ((c
 // lane and the 4 lane groups of a voxel write one contiguous 64-byte run (instead of 8-byte pieces of four 32-byte runs).
 __device__ __forceinline__ int crow(int R) { return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3); }
 
-template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3>
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
@@ -241,6 +242,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // straight-line over the TG taps of the group (padding taps multiply zero weights): no per-tap branch, so the
         // fragment reads of tap t+1 can be scheduled under the MFMAs of tap t
+        if constexpr (HR) {
+          // h-runs: taps 3r, 3r+1, 3r+2 of the group differ only by one h-row of the source brick, and subtile j IS h-row j of the
+          // wave's d-plane (4x4x16 brick): fragment row j+th serves (subtile j, tap th) -- 6 row reads per run instead of 12
+          static_assert(TG % 3 == 0 && BD == 4 && BH == 4 && BW == 16 && VS == 4, "h-run reuse needs the 4x4x16 brick and 3-tap runs");
+          const int ewb = EW * LROWB;
+#pragma unroll
+          for (int tr = 0; tr < TG / 3; ++tr) {
+            const int tob = AM_TAP(gi * TG + tr * 3) & 0xFFFFF;
+            u32x4 brow[VS + 2];
+#pragma unroll
+            for (int r = 0; r < VS + 2; ++r) brow[r] = *(const u32x4*)(lds + bb[0] + tob + r * ewb);
+#pragma unroll
+            for (int th = 0; th < 3; ++th) {
+              u32x4 af[NS];
+#pragma unroll
+              for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + (tr * 3 + th) * NT * ROWB + aoff[i]);
+#pragma unroll
+              for (int j = 0; j < VS; ++j)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], brow[j + th], acc[i][j]);
+            }
+          }
+        } else {
 #pragma unroll
         for (int tl = 0; tl < TG; ++tl) {
           const int tt = gi * TG + tl;
@@ -254,6 +278,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
           }
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (more) { if (!(a.dbg & 32)) { AM_WSTORE(wr, buf ^ 1); } if (!(a.dbg & 16)) __syncthreads(); }
@@ -406,6 +431,16 @@ int build_plan(Plan& P, int mode, int k, int stride) {
     a.mdiv_hw[c] = (1 << 20) / (a.ew[c] * a.eh[c]) + 1;
   }
   for (int c = a.nunit; c <= 8; ++c) a.tap_begin[c] = n;
+  // k3 s1 plans (one unit, 27 taps): order the taps as (ud, uw) runs of uh = min, min+1, min+2.  With the 4x4x16 brick the wave's
+  // four voxel subtiles are four consecutive h-rows, so the three taps of a run read 6 distinct fragment rows instead of 12.
+  a.hreuse = 0;
+  if (a.nunit == 1 && k == 3 && n == 27 && P.bd == 4 && P.bh == 4 && P.bw == 16) {
+    int srt[27], m = 0;
+    for (int ud = -1; ud <= 1; ++ud) for (int uw = -1; uw <= 1; ++uw) for (int uh = -1; uh <= 1; ++uh)
+      for (int t = 0; t < 27; ++t)
+        if ((a.taps[t] & 15) - 8 == ud && ((a.taps[t] >> 4) & 15) - 8 == uh && ((a.taps[t] >> 8) & 15) - 8 == uw) srt[m++] = a.taps[t];
+    if (m == 27) { for (int t = 0; t < 27; ++t) a.taps[t] = srt[t]; a.hreuse = 1; }
+  }
   size_t mxv = 0;
   for (int c = 0; c < a.nunit; ++c) { size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
   P.nit = (int)((mxv * (ROWB / 16) + 255) / 256);
@@ -417,10 +452,10 @@ int build_plan(Plan& P, int mode, int k, int stride) {
   return 0;
 }
 
-template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3>
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false>
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
-  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS>;
+  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS, HR>;
   static size_t attr_lds = 48 * 1024;             // raise the dynamic-LDS cap only when a launch needs it
   if (P.lds > attr_lds) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds) == hipSuccess) attr_lds = P.lds;
@@ -447,7 +482,7 @@ int dispatch_nit(Plan& P, int shape, hipStream_t st) {
   if (shape == 1) {                              // 4x4x16: every 16-lane fragment is 16 consecutive voxels (conflict-free reads)
     if (n <= 4) return launch<T, 4, 4, 16, NS, 4>(P, st);
     if (n <= 7) return launch<T, 4, 4, 16, NS, 7>(P, st);
-    if (n <= 11) return launch<T, 4, 4, 16, NS, 11>(P, st);
+    if (n <= 11) return (P.a.hreuse && !getenv("AM_CV_NOHR")) ? launch<T, 4, 4, 16, NS, 11, 3, true>(P, st) : launch<T, 4, 4, 16, NS, 11>(P, st);
     return -3;
   }
   if (n <= 4) return launch<T, 4, 8, 8, NS, 4>(P, st);          // narrow grids (W < 16)

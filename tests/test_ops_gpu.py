@@ -64,6 +64,36 @@ CONV_CASES = [  # Cin, Cout, k, stride
 ]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(16, 24), (40, 64), (72, 32)])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_conv_k3_wide_grid_h_run_variant(ops, dtype, case, sparse):
+    """k3 s1 forward + data gradient on W >= 16 grids: the 4x4x16-brick kernel variant that shares fragment rows across h-runs of taps."""
+    cin, cout = case
+    B, f, bs = 2, (2, 2, 4), 2
+    so = tuple(v << bs for v in f)               # (8, 8, 16)
+    x = q(rnd(B, cin, *so, seed=31), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=32, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    bias = rnd(cout, seed=33)
+    dy = q(rnd(B, cout, *so, seed=34), dtype)
+    mask = mk_mask(B, f, 9) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    mo = O.upsample_mask(mask, so).float() if sparse else None
+    if sparse:
+        x, dy = x * mo, dy * mo
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, bias, padding=1)
+    if sparse:
+        yr = yr * mo
+    yr.backward(dy)
+    wp = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=False)
+    y = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, bias.to(DEV), so, 3, 1, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs)
+    close(from_cl(y), yr.detach(), TOL[dtype], "conv fwd (h-run)", mo)
+    wpd = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=True)
+    dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), wpd, None, so, 3, 1, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs)
+    close(from_cl(dx), xr.grad, TOL[dtype], "conv dgrad (h-run)", mo)
+
+
 @pytest.mark.parametrize("case", [(32, 32, 3, 1), (64, 32, 3, 1), (32, 64, 3, 1), (32, 64, 3, 2), (32, 64, 1, 2), (24, 16, 3, 1)])
 @pytest.mark.parametrize("sparse", [False, True])
 def test_conv_wgrad_narrow_channels_wide_grid(ops, case, sparse):
