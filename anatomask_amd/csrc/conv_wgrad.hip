@@ -202,27 +202,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
         const int v1 = ks * 32 + g * 4 + q, v2 = v1 + 16;
         const int xa1 = (((v1 / (BW * BH)) * EH + (v1 / BW) % BH) * EW + v1 % BW) * RSX + (16 * wx + 4 * p) * 2;
         const int xa2 = (((v2 / (BW * BH)) * EH + (v2 / BW) % BH) * EW + v2 % BW) * RSX + (16 * wx + 4 * p) * 2;
-        s16x4 alo[MI], ahi[MI], blo[NTAP], bhi[NTAP];
+        s16x4 alo[MI], ahi[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           alo[i] = tr_read(ldsY + v1 * RSY + (16 * i + 4 * p) * 2);
           ahi[i] = tr_read(ldsY + v2 * RSY + (16 * i + 4 * p) * 2);
-        }
-#pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-          blo[t] = tr_read(ldsX + xa1 + tapoff[t]);
-          bhi[t] = tr_read(ldsX + xa2 + tapoff[t]);
         }
         typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
         bfx8 af[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           af[i] = __builtin_bit_cast(bfx8, s16x8{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]});
+        if constexpr (NTAP == 9 && BW == 16) {
+          // conv k3 unit = 9 taps (th, tw) of one d-shift (tap t = 3*th + tw, window offset (th*EW + tw) rows).  The two voxel
+          // halves of a k-step are the h-rows h and h+1 of the brick, so tap th needs the X rows h+th and h+th+1: the three th of
+          // a tw share 4 rows -- 12 transposing reads per k-step instead of 18
+          s16x4 xr[3][4];
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) {
-          const bfx8 bf = __builtin_bit_cast(bfx8, s16x8{blo[t][0], blo[t][1], blo[t][2], blo[t][3], bhi[t][0], bhi[t][1], bhi[t][2], bhi[t][3]});
+          for (int tw = 0; tw < 3; ++tw)
 #pragma unroll
-          for (int i = 0; i < MI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) xr[tw][r] = tr_read(ldsX + xa1 + (r * EW + tw) * RSX);
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) {
+            const s16x4 lo = xr[t % 3][t / 3], hi = xr[t % 3][t / 3 + 1];
+            const bfx8 bf = __builtin_bit_cast(bfx8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
+          }
+        } else {
+          s16x4 blo[NTAP], bhi[NTAP];
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) {
+            blo[t] = tr_read(ldsX + xa1 + tapoff[t]);
+            bhi[t] = tr_read(ldsX + xa2 + tapoff[t]);
+          }
+#pragma unroll
+          for (int t = 0; t < NTAP; ++t) {
+            const bfx8 bf = __builtin_bit_cast(bfx8, s16x8{blo[t][0], blo[t][1], blo[t][2], blo[t][3], bhi[t][0], bhi[t][1], bhi[t][2], bhi[t][3]});
+#pragma unroll
+            for (int i = 0; i < MI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[t][i], 0, 0, 0);
+          }
         }
       } else {
         const int v = ks * 4 + g;
