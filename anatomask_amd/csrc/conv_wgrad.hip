@@ -96,31 +96,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   }
 
   // ---- per-thread staging plans (brick-relative, computed once) ----
-  int yrel[NITY], ydst[NITY];                            // voxel offset relative to the brick origin ; LDS byte offset (-1: none)
+  // Row `it` of a thread = voxel (tid / CPR + it * 256 / CPR) of the brick, always the same 16-byte channel chunk.  Everything a
+  // brick needs per row is ONE add: its global BYTE offset relative to the brick origin is precomputed here (channel chunk
+  // included), the LDS destination is an immediate multiple of the row stride, and the brick-relative coordinates (needed only
+  // by border / masked bricks) are packed in one register.  The brick loop itself touches no kernel argument per row.
+  constexpr int VPI_Y = 256 / CPRY, VPI_X = 256 / CPRX;   // voxel rows per staging iteration
+  static_assert(256 % CPRY == 0 && 256 % CPRX == 0, "a thread keeps its channel chunk across iterations");
+  const int ychan = (tid % CPRY) * EPC, xchan = (tid % CPRX) * EPC;
+  const bool ycok = cy0 + ychan < a.Cy, xcok = cx0 + xchan < a.Cx;
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned yoffB[NITY], xoffB[NITX];                     // OOB: this thread has no such row (or its channel chunk is padding)
+  int yq[NITY], xq[NITX];                                // brick-relative (d, h, w) of the row: d | h << 8 | w << 16
 #pragma unroll
   for (int it = 0; it < NITY; ++it) {
-    const int idx = tid + it * 256;
-    const int v = idx / CPRY, c = idx % CPRY;
-    yrel[it] = (((v / (BW * BH)) * a.OS) * a.Hy + ((v / BW) % BH) * a.OS) * a.Wy + (v % BW) * a.OS;
-    ydst[it] = idx < MV * CPRY ? v * RSY + c * 16 : -1;
+    const int v = tid / CPRY + it * VPI_Y;
+    const int vd = v / (BW * BH), vh = (v / BW) % BH, vw = v % BW;
+    yq[it] = vd | (vh << 8) | (vw << 16);
+    yoffB[it] = (v < MV && ycok) ? (unsigned)(((((vd * a.OS) * a.Hy + vh * a.OS) * a.Wy + vw * a.OS) * a.Cy + cy0 + ychan) * (int)sizeof(T)) : OOB;
   }
-  int xrel[NITX], xdst[NITX];
 #pragma unroll
   for (int it = 0; it < NITX; ++it) {
-    const int idx = tid + it * 256;
-    const int e = idx / CPRX, c = idx % CPRX;
-    const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
-    xrel[it] = e < nvox ? ((ez * a.Hx + ey) * a.Wx + (rem - ey * EW)) * a.GS : 0;
-    xdst[it] = e < nvox ? e * RSX + c * 16 : -1;
+    const int e = tid / CPRX + it * VPI_X;
+    const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20, ex = rem - ey * EW;
+    xq[it] = ez | (ey << 8) | (ex << 16);
+    xoffB[it] = (e < nvox && xcok) ? (unsigned)((((ez * a.Hx + ey) * a.Wx + ex) * a.GS * a.Cx + cx0 + xchan) * (int)sizeof(T)) : OOB;
   }
-  const int ychan = (tid % CPRY) * EPC, xchan = (tid % CPRX) * EPC;   // 256 % CPR == 0: a thread keeps its channel chunk across iterations
-  const bool ycok = cy0 + ychan < a.Cy, xcok = cx0 + xchan < a.Cx;
-  const int ycoff = ycok ? cy0 + ychan : 0, xcoff = xcok ? cx0 + xchan : 0;
+  const int ydst0 = (tid / CPRY) * RSY + (tid % CPRY) * 16, xdst0 = (tid / CPRX) * RSX + (tid % CPRX) * 16;
 
   const T* __restrict__ xg = (const T*)a.x;
   const T* __restrict__ yg = (const T*)a.dy;
   const int nbrick = a.B * a.nbd * a.nbh * a.nbw;
   const size_t yplane = (size_t)a.Hy * a.Wy * a.Cy, xplane = (size_t)a.Hx * a.Wx * a.Cx;
+  const bool masked = a.x_mask.m != nullptr || a.y_mask.m != nullptr;
+  const int Dy_ = a.Dy, Hy_ = a.Hy, Wy_ = a.Wy, Dx_ = a.Dx, Hx_ = a.Hx, Wx_ = a.Wx, OS_ = a.OS, GS_ = a.GS;
 
   for (int brick = slot; brick < nbrick; brick += a.split) {
     int bid = brick;
@@ -129,67 +137,73 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     const int bd_ = bid % a.nbd; const int b = bid / a.nbd;
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
     // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
-    const int i0d = (q0d + a.mind[grp]) * a.GS + upd, i0h = (q0h + a.minh[grp]) * a.GS + uph, i0w = (q0w + a.minw[grp]) * a.GS + upw;
-
-    // ---- addresses + validity of this brick's rows (clamped; zero-selected after the load) ----
-    int yv[NITY], xv[NITX];
-    unsigned yok = 0, xok = 0;
+    const int i0d = (q0d + a.mind[grp]) * GS_ + upd, i0h = (q0h + a.minh[grp]) * GS_ + uph, i0w = (q0w + a.minw[grp]) * GS_ + upw;
+    const int o0d = q0d * OS_ + pd, o0h = q0h * OS_ + ph, o0w = q0w * OS_ + pw;
     // descriptors anchored at the first d-plane of this brick (32-bit offsets span a few planes only: any tensor size works)
-    const int yd0 = q0d * a.OS + pd < a.Dy ? q0d * a.OS + pd : a.Dy, xd0 = i0d < 0 ? 0 : (i0d > a.Dx ? a.Dx : i0d);
-    const int ybase = ((q0d * a.OS + pd - yd0) * a.Hy + q0h * a.OS + ph) * a.Wy + q0w * a.OS + pw;   // relative to plane yd0 of sample b
-    const int xbase = ((i0d - xd0) * a.Hx + i0h) * a.Wx + i0w;
-    const size_t yleft = (size_t)(a.Dy - yd0) * yplane * sizeof(T), xleft = (size_t)(a.Dx - xd0) * xplane * sizeof(T);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + ((size_t)b * a.Dy + yd0) * yplane), 0,
+    const int yd0 = o0d < Dy_ ? o0d : Dy_, xd0 = i0d < 0 ? 0 : (i0d > Dx_ ? Dx_ : i0d);
+    const int ybaseB = ((((o0d - yd0) * Hy_ + o0h) * Wy_ + o0w) * a.Cy) * (int)sizeof(T);   // brick origin relative to plane yd0 of sample b
+    const int xbaseB = ((((i0d - xd0) * Hx_ + i0h) * Wx_ + i0w) * a.Cx) * (int)sizeof(T);
+    const size_t yleft = (size_t)(Dy_ - yd0) * yplane * sizeof(T), xleft = (size_t)(Dx_ - xd0) * xplane * sizeof(T);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + ((size_t)b * Dy_ + yd0) * yplane), 0,
                                                                         (int)(yleft < 0x7fffff00ull ? yleft : 0x7fffff00ull), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + ((size_t)b * a.Dx + xd0) * xplane), 0,
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + ((size_t)b * Dx_ + xd0) * xplane), 0,
                                                                         (int)(xleft < 0x7fffff00ull ? xleft : 0x7fffff00ull), 0x00020000);
-    // interior brick of a dense tensor (wave-uniform): everything in range, one add per row instead of the bounds logic
-    const bool interior = !a.x_mask.m && !a.y_mask.m && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + (ED - 1) * a.GS < a.Dx &&
-                          i0h + (EH - 1) * a.GS < a.Hx && i0w + (EW - 1) * a.GS < a.Wx && (q0d + BD - 1) * a.OS + pd < a.Dy && (q0h + BH - 1) * a.OS + ph < a.Hy &&
-                          (q0w + BW - 1) * a.OS + pw < a.Wy;
-    if (interior) {
+    // interior brick of a dense tensor (wave-uniform): every row in range, the row offsets are used as they are
+    const bool interior = !masked && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + (ED - 1) * GS_ < Dx_ &&
+                          i0h + (EH - 1) * GS_ < Hx_ && i0w + (EW - 1) * GS_ < Wx_ && o0d + (BD - 1) * OS_ < Dy_ && o0h + (BH - 1) * OS_ < Hy_ &&
+                          o0w + (BW - 1) * OS_ < Wy_;
+    unsigned yo[NITY], xo[NITX];
 #pragma unroll
-      for (int it = 0; it < NITY; ++it) yv[it] = ybase + yrel[it];
+    for (int it = 0; it < NITY; ++it) yo[it] = yoffB[it];
 #pragma unroll
-      for (int it = 0; it < NITX; ++it) xv[it] = xbase + xrel[it];
-      yok = xok = 0xffffffffu;
-    } else {
+    for (int it = 0; it < NITX; ++it) xo[it] = xoffB[it];
+    if (!interior) {
+      if (!masked) {                                     // border brick of a dense tensor: range tests only, branch-free
 #pragma unroll
-      for (int it = 0; it < NITY; ++it) {
-        const int v = (tid + it * 256) / CPRY;
-        const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
-        const bool ok = ydst[it] >= 0 && od < a.Dy && oh < a.Hy && ow < a.Wy && a.y_mask.active(b, od, oh, ow);
-        yv[it] = ok ? ybase + yrel[it] : 0;
-        yok |= (ok ? 1u : 0u) << it;
-      }
-      if (a.y_mask.m && !__syncthreads_or(yok != 0)) continue;    // nothing active in this brick (block-sparse dY)
+        for (int it = 0; it < NITY; ++it) {
+          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
+          if (!(od < Dy_ && oh < Hy_ && ow < Wy_)) yo[it] = OOB;
+        }
 #pragma unroll
-      for (int it = 0; it < NITX; ++it) {
-        const int e = (tid + it * 256) / CPRX;
-        const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20;
-        const int id = i0d + ez * a.GS, ih = i0h + ey * a.GS, iw = i0w + (rem - ey * EW) * a.GS;
-        const bool ok = xdst[it] >= 0 && id >= 0 && id < a.Dx && ih >= 0 && ih < a.Hx && iw >= 0 && iw < a.Wx && a.x_mask.active(b, id, ih, iw);
-        xv[it] = ok ? xbase + xrel[it] : 0;
-        xok |= (ok ? 1u : 0u) << it;
+        for (int it = 0; it < NITX; ++it) {
+          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
+          if (!((unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_)) xo[it] = OOB;
+        }
+      } else {                                           // block-sparse operands: patch-mask lookups per row
+        unsigned yany = 0;
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
+          const bool ok = yo[it] != OOB && od < Dy_ && oh < Hy_ && ow < Wy_ && a.y_mask.active(b, od, oh, ow);
+          if (!ok) yo[it] = OOB;
+          yany |= ok ? 1u : 0u;
+        }
+        if (a.y_mask.m && !__syncthreads_or(yany != 0)) continue;    // nothing active in this brick (block-sparse dY)
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
+          const bool ok = xo[it] != OOB && (unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_ &&
+                          a.x_mask.active(b, id, ih, iw);
+          if (!ok) xo[it] = OOB;
+        }
       }
     }
     u32x4 ys[NITY], xs[NITX];
-    // buffer loads: per-lane 32-bit byte offset, hardware zero-fill for rows marked out of range (offset >= num_records)
+    // buffer loads: per-lane 32-bit byte offset (row offset + the brick's scalar origin, which may be negative for halo rows that
+    // are then OOB-marked); hardware zero-fill for OOB rows
 #pragma unroll
     for (int it = 0; it < NITY; ++it)
-      ys[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-          ry, (ycok && ((yok >> it) & 1u)) ? (unsigned)((yv[it] * a.Cy + ycoff) * (int)sizeof(T)) : 0x80000000u, 0, 0));
+      ys[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yo[it] == OOB ? OOB : yo[it] + (unsigned)ybaseB, 0, 0));
 #pragma unroll
     for (int it = 0; it < NITX; ++it)
-      xs[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-          rx, (xcok && ((xok >> it) & 1u)) ? (unsigned)((xv[it] * a.Cx + xcoff) * (int)sizeof(T)) : 0x80000000u, 0, 0));
+      xs[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[it] == OOB ? OOB : xo[it] + (unsigned)xbaseB, 0, 0));
     __syncthreads();                                     // previous brick's fragment reads are done
 #pragma unroll
     for (int it = 0; it < NITY; ++it)
-      if (ydst[it] >= 0) *(u32x4*)(ldsY + ydst[it]) = ys[it];
+      if (tid / CPRY + it * VPI_Y < MV) *(u32x4*)(ldsY + ydst0 + it * VPI_Y * RSY) = ys[it];
 #pragma unroll
     for (int it = 0; it < NITX; ++it)
-      if (xdst[it] >= 0) *(u32x4*)(ldsX + xdst[it]) = xs[it];
+      if (tid / CPRX + it * VPI_X < nvox) *(u32x4*)(ldsX + xdst0 + it * VPI_X * RSX) = xs[it];
     __syncthreads();
 
     // ---- contract over the brick's voxels ----
