@@ -130,11 +130,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const bool masked = a.x_mask.m != nullptr || a.y_mask.m != nullptr;
   const int Dy_ = a.Dy, Hy_ = a.Hy, Wy_ = a.Wy, Dx_ = a.Dx, Hx_ = a.Hx, Wx_ = a.Wx, OS_ = a.OS, GS_ = a.GS;
 
-  for (int brick = slot; brick < nbrick; brick += a.split) {
-    int bid = brick;
-    const int bw_ = bid % a.nbw; bid /= a.nbw;
-    const int bh_ = bid % a.nbh; bid /= a.nbh;
-    const int bd_ = bid % a.nbd; const int b = bid / a.nbd;
+  // a workgroup owns a CONTIGUOUS run of bricks (w fastest): the brick coordinates advance by increment-and-carry (no divisions
+  // in the loop) and consecutive bricks re-read each other's halo rows from L2
+  const int chunk = (nbrick + a.split - 1) / a.split;
+  const int brick0 = slot * chunk, brick1 = brick0 + chunk < nbrick ? brick0 + chunk : nbrick;
+  int bw_, bh_, bd_, b;
+  {
+    int bid = brick0;
+    bw_ = bid % a.nbw; bid /= a.nbw;
+    bh_ = bid % a.nbh; bid /= a.nbh;
+    bd_ = bid % a.nbd; b = bid / a.nbd;
+    bw_ -= 1;                                            // (pre-decrement: the loop increments first)
+  }
+  const int nbw_ = a.nbw, nbh_ = a.nbh, nbd_ = a.nbd;
+  for (int brick = brick0; brick < brick1; ++brick) {
+    if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
     // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
     const int i0d = (q0d + a.mind[grp]) * GS_ + upd, i0h = (q0h + a.minh[grp]) * GS_ + uph, i0w = (q0w + a.minw[grp]) * GS_ + upw;
