@@ -92,6 +92,12 @@ struct MaskView {
     if (!m) return true;
     return m[((b * fd + (d >> bs)) * fh + (h >> bs)) * fw + (w >> bs)] != 0;
   }
+  // byte of the patch that holds (d,h,w), or of patch 0 when !inrange: an UNCONDITIONAL load, so a staging plan can issue the
+  // lookups of all its rows back to back and wait once (the branchy form serialises one global round trip per row)
+  __device__ __forceinline__ uint8_t peek(int b, int d, int h, int w, bool inrange) const {
+    const int i = inrange ? ((b * fd + (d >> bs)) * fh + (h >> bs)) * fw + (w >> bs) : 0;
+    return m[i];
+  }
 };
 
 #define AM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

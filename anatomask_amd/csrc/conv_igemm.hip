@@ -199,18 +199,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // ---- per-thread staging plan for this unit's source brick: byte offset of this thread's chunk in each of its rows ----
     unsigned soff[NIT];
     const int mW = a.mdiv_w[un], mHW = a.mdiv_hw[un], EHW = EH * EW;
+    uint8_t mb[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      soff[it] = OOB;
+    for (int it = 0; it < NIT; ++it) {                   // branch-free: offsets + (block-sparse input) all patch-mask bytes in flight at once
       const int e = (tid + it * 256) >> 2;
-      if (e < nvox) {
-        const int ez = (e * mHW) >> 20, rem = e - ez * EHW;       // runtime extents: reciprocal multiply instead of
-        const int ey = (rem * mW) >> 20, ex = rem - ey * EW;       // ~35-instruction integer divisions
-        const int id = (i0d + ez) * a.GS + upd, ih = (i0h + ey) * a.GS + uph, iw = (i0w + ex) * a.GS + upw;
-        if (id >= 0 && id < a.Di && ih >= 0 && ih < a.Hi && iw >= 0 && iw < a.Wi && a.in_mask.active(b, id, ih, iw))
-          soff[it] = (unsigned)(((((id - dbase) * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T));
-      }
+      const int ez = (e * mHW) >> 20, rem = e - ez * EHW;         // runtime extents: reciprocal multiply instead of
+      const int ey = (rem * mW) >> 20, ex = rem - ey * EW;         // ~35-instruction integer divisions
+      const int id = (i0d + ez) * a.GS + upd, ih = (i0h + ey) * a.GS + uph, iw = (i0w + ex) * a.GS + upw;
+      const bool ok = e < nvox && (unsigned)id < (unsigned)a.Di && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+      soff[it] = ok ? (unsigned)(((((id - dbase) * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T)) : OOB;
+      mb[it] = a.in_mask.m ? a.in_mask.peek(b, id, ih, iw, ok) : (uint8_t)1;
     }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (!mb[it]) soff[it] = OOB;
     int bb[VS];                                          // LDS byte offset of this lane's voxel-row chunk, tap shift excluded
 #pragma unroll
     for (int j = 0; j < VS; ++j) {
