@@ -430,3 +430,19 @@ def test_config1_stunet_small_plain_spark_step():
     o = tr.step(x.to(DEV), epoch=0, mask1=mask)
     assert abs(o["loss"].item() - float(loss_o)) < 2e-4 * abs(float(loss_o))
     assert abs(o["grad_norm"].item() - gn_o) < 5e-2 * gn_o
+
+
+def test_two_ranks_on_one_gpu_stay_in_sync():
+    """world_size 2 with the REAL trainer (overlapped per-group exchange, side stream joins) -- both ranks on the one GPU a box has,
+    over gloo with device tensors (RCCL refuses two ranks per device).  Different init per rank, different data per rank: after
+    3 steps the students and the EMA teachers must be bit-identical across the ranks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", os.path.join(root, "tools", "ddp_two_ranks_one_gpu.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("weights identical across ranks: True; teacher identical: True") == 2, r.stdout[-2000:]
