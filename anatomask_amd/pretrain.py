@@ -7,7 +7,9 @@ lifted from in-script literals into flags (SURVEY.md 5 "Config").
     python -m torch.distributed.run --nproc-per-node 8 -m anatomask_amd.pretrain ...
 
 Data: any iterator yielding nnU-Net style batches {'data': float32 (B,1,H,W,D)} works (that is all the step consumes,
-P/pretrain_AntoMask.py:390-392); built in are `--data DIR` (preprocessed .npy volumes (1,H,W,D), random crops) and synthetic.
+P/pretrain_AntoMask.py:390-392).  `--data DIR`: an nnU-Net v2 preprocessed folder (<case>.npy|.npz + <case>.pkl) goes through
+`anatomask_amd.data` (foreground oversampling 0.33, mirroring, as the reference's loader); a folder of bare .npy volumes gets
+random crops; without --data the batches are synthetic.
 """
 import argparse
 import glob
@@ -21,6 +23,7 @@ import torch
 import torch.distributed as dist
 
 from . import checkpoint
+from .data import PatchLoader3D, PreprocessedDataset
 from .modules import STUNET_CONFIGS, build_spark, ema_decay_for_epoch, linear_warmup_cosine_lrs
 from .trainer import AnatoMaskTrainer
 
@@ -76,11 +79,17 @@ def main(argv=None):
     lrs = linear_warmup_cosine_lrs(a.epochs, a.lr, a.warmup, 1e-6)                    # :359
     start = checkpoint.load_checkpoint(a.resume, trainer) if a.resume else 0
     files = sorted(glob.glob(os.path.join(a.data, "*.npy"))) if a.data else None
+    nnunet_feed = None
+    if a.data and glob.glob(os.path.join(a.data, "*.pkl")):          # nnU-Net v2 preprocessed folder
+        nnunet_feed = PatchLoader3D(PreprocessedDataset(a.data), a.batch_size, a.input_size, 0.33, seed=1000 + rank)
     epoch_loss, ema_loss = [], None
     for i in range(start, a.epochs):
         trainer.set_epoch(i); trainer.lr = lrs[i]                                     # :383-386, :452
-        it = (npy_crop_batches(files, a.batch_size, a.input_size, a.iters_per_epoch, 1000 * i + rank) if files
-              else synthetic_batches(a.batch_size, a.input_size, a.iters_per_epoch, 1000 * i + rank))
+        if nnunet_feed is not None:
+            it = (next(nnunet_feed) for _ in range(a.iters_per_epoch))
+        else:
+            it = (npy_crop_batches(files, a.batch_size, a.input_size, a.iters_per_epoch, 1000 * i + rank) if files
+                  else synthetic_batches(a.batch_size, a.input_size, a.iters_per_epoch, 1000 * i + rank))
         t0, acc = time.time(), torch.zeros(1, device=dev)
         for batch in it:
             out = trainer.step(batch["data"].to(dev, non_blocking=True), epoch=i)
