@@ -17,30 +17,35 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, ablate: bool = False) -> str:
+    """ablate=True: the tools-only variant libanatomask_hip_ablate.so (-DAM_ABLATE: timing-ablation switches read from the
+    environment, results wrong on purpose); the product library never contains them."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    sfx = "_ablate" if ablate else ""
+    out = OUT.replace(".so", sfx + ".so")
+    flags = FLAGS + (["-DAM_ABLATE"] if ablate else [])
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "anatomask_hip.h")]
     objs = []
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
+        obj = os.path.join(CSRC, s.replace(".hip", sfx + ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+            cmd = [hipcc, *flags, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    if force or procs or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs]
+    if force or procs or _stale(out, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, ablate="--ablate" in sys.argv))

@@ -27,6 +27,8 @@
 // BatchNorm (scale/shift), a skip tensor and an activation, applies the output patch mask, writes 8 consecutive channels
 // (16 bytes) per lane and (optionally) leaves per-workgroup per-channel partial sums (sum, sum of squares) for the norm
 // that follows -- no extra pass over y.
+#include <mutex>
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/anatomask_hip.h"
 
@@ -53,8 +55,18 @@ struct ConvArgs {
   int brick_in_patch;         // block-sparse output and the q-brick lies inside one patch: one mask lookup decides the whole brick
   int hreuse;                 // taps ordered in h-runs of 3 (see build_plan): the HR kernel variant shares fragment rows across a run
   int nt_store;               // non-temporal output stores (outputs far larger than the 256 MB Infinity Cache)
-  int dbg;                    // AM_CV_DBG ablation bits (timing experiments only): 1 no stores, 2 no source loads, 4 no weight loads
+#ifdef AM_ABLATE
+  int dbg;                    // tools-only build (-DAM_ABLATE): AM_CV_DBG ablation bits, 1 no stores, 2 no source loads, 4 no weight loads
+#endif
 };
+
+// Ablation switches exist only in the tools build (anatomask_amd.build --ablate -> libanatomask_hip_ablate.so); in the product
+// library AM_DBG() is the constant false and no environment variable is ever read.
+#ifdef AM_ABLATE
+#define AM_DBG(a_, bit_) (((a_).dbg & (bit_)) != 0)
+#else
+#define AM_DBG(a_, bit_) false
+#endif
 
 constexpr int ROWB = 64;      // channel-slab bytes staged per voxel / per weight row (unpadded, XOR-swizzled)
 constexpr int LROWB = 80;     // LDS row stride of the source brick (16 B pad; B-fragment address = lane const + scalar tap offset)
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
     const int tt_ = __builtin_amdgcn_readfirstlane((GI) * TG + (tid + it * 256) / (NT * 4));                \
     const int wi_ = AM_TAP(tt_) >> 20;                                                                      \
-    WR[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tt_ < nt && (OK) && !(a.dbg & 4)) ? wsrc[it] : OOB, wi_ * wtapB + (KCW) * (int)sizeof(T), 0)); \
+    WR[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tt_ < nt && (OK) && !AM_DBG(a, 4)) ? wsrc[it] : OOB, wi_ * wtapB + (KCW) * (int)sizeof(T), 0)); \
   }
 #define AM_WSTORE(WR, BUF)                                                                                 \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it)                                                        \
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // issue the loads of the source brick's channel slab KCS into stg (only a partial last slab, Cin % KC != 0, has !cok lanes)
 #define AM_SLOAD(KCS, OK)                                                                                  \
   {                                                                                                        \
-    const bool cok_ = (KCS) + cchunk < a.Cin && (OK) && !(a.dbg & 2);                                       \
+    const bool cok_ = (KCS) + cchunk < a.Cin && (OK) && !AM_DBG(a, 2);                                       \
     _Pragma("unroll") for (int it = 0; it < NIT; ++it)                                                      \
       stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, cok_ ? soff[it] : OOB, (KCS) * (int)sizeof(T), 0)); \
   }
@@ -283,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (more) { if (!(a.dbg & 32)) { AM_WSTORE(wr, buf ^ 1); } if (!(a.dbg & 16)) __syncthreads(); }
+        if (more) { if (!AM_DBG(a, 32)) { AM_WSTORE(wr, buf ^ 1); } if (!AM_DBG(a, 16)) __syncthreads(); }
       }
     }
   }
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int h = 0; h < NH; ++h) {
       f32x4 o0 = acc[2 * h][j] + bia[2 * h], o1 = acc[2 * h + 1][j] + bia[2 * h + 1];
       T* dst = dstv + h * 32;
-      const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout && !(a.dbg & 1);     // Cout % 8 == 0 (C % 8 == 0 contract)
+      const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout && !AM_DBG(a, 1);     // Cout % 8 == 0 (C % 8 == 0 contract)
       if (fused) {
         const T* rs = resg ? resg + (dst - yg) : nullptr;
         o0 = ep(o0, 2 * h, rs, act && wr); o1 = ep(o1, 2 * h + 1, rs ? rs + 4 : nullptr, act && wr);
@@ -458,11 +470,9 @@ template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
   auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS, HR>;
-  static size_t attr_lds = 48 * 1024;             // raise the dynamic-LDS cap only when a launch needs it
-  if (P.lds > attr_lds) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)P.lds) == hipSuccess) attr_lds = P.lds;
-    (void)hipGetLastError();
-  }
+  static std::once_flag lds_cap;                  // per instantiation, thread-safe: lift the 48 KB dynamic-LDS default to the CU's 160 KB
+  std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  if (P.lds > 160 * 1024) return -3;
   dim3 grid(a.B * a.nbd * a.nbh * a.nbw, (a.Cout + 16 * NS - 1) / (16 * NS), a.nclass);
   AM_LAUNCH(kern, grid, dim3(256), P.lds, st, a);
   AM_CHECK_LAUNCH();
@@ -484,7 +494,10 @@ int dispatch_nit(Plan& P, int shape, hipStream_t st) {
   if (shape == 1) {                              // 4x4x16: every 16-lane fragment is 16 consecutive voxels (conflict-free reads)
     if (n <= 4) return launch<T, 4, 4, 16, NS, 4>(P, st);
     if (n <= 7) return launch<T, 4, 4, 16, NS, 7>(P, st);
-    if (n <= 11) return (P.a.hreuse && !getenv("AM_CV_NOHR")) ? launch<T, 4, 4, 16, NS, 11, 3, true>(P, st) : launch<T, 4, 4, 16, NS, 11>(P, st);
+#ifdef AM_ABLATE
+    if (n <= 11 && getenv("AM_CV_NOHR")) return launch<T, 4, 4, 16, NS, 11>(P, st);
+#endif
+    if (n <= 11) return P.a.hreuse ? launch<T, 4, 4, 16, NS, 11, 3, true>(P, st) : launch<T, 4, 4, 16, NS, 11>(P, st);
     return -3;
   }
   if (n <= 4) return launch<T, 4, 8, 8, NS, 4>(P, st);          // narrow grids (W < 16)
@@ -571,9 +584,11 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
     const int qblock = out_mask ? ((1 << out_bshift) / a.OS) : 0;
     a.brick_in_patch = qblock > 0 && qblock % P.bd == 0 && qblock % P.bh == 0 && qblock % P.bw == 0;
   }
+#ifdef AM_ABLATE
   { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
   // outputs far larger than the 256 MB Infinity Cache bypass it (measured +2.5 % on the 1 GB decoder tensors: the halo re-reads keep L2)
-  a.nt_store = ((size_t)B * Do * Ho * Wo * Cout * 2 >= ((size_t)384 << 20) && !accumulate) || (a.dbg & 8);
+  a.nt_store = ((size_t)B * Do * Ho * Wo * Cout * 2 >= ((size_t)384 << 20) && !accumulate) || AM_DBG(a, 8);
   hipStream_t st = (hipStream_t)stream;
   return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, shape, st) : dispatch<float>(P, shape, st);
 }

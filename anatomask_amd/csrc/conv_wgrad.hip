@@ -14,6 +14,7 @@
 // taps is issued before the first MFMA, so LDS latency is paid once per k-step, not once per tap.
 // Partial sums leave the workgroup as f32 atomics into the packed [tap][cy][cx] gradient
 // (64-byte runs per 16 lanes; order-dependent in the last bits, like any split-K atomic reduce).
+#include <mutex>
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/anatomask_hip.h"
@@ -35,8 +36,15 @@ struct WgArgs {
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
   int split;                  // brick-walk slots per (tile, group)
-  int dbg;                    // AM_WG_DBG ablation bits (timing experiments only): 1 no flush, 2 no contraction, 4 no global loads
+#ifdef AM_ABLATE
+  int dbg;                    // tools-only build (-DAM_ABLATE): AM_WG_DBG ablation bits, 1 no flush, 2 no contraction
+#endif
 };
+#ifdef AM_ABLATE
+#define AM_DBG(a_, bit_) (((a_).dbg & (bit_)) != 0)
+#else
+#define AM_DBG(a_, bit_) false
+#endif
 
 
 __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
@@ -218,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 
     // ---- contract over the brick's voxels ----
 #pragma unroll 1
-    for (int ks = wk; ks < ((a.dbg & 2) ? 0 : MV / KSTEP); ks += KS) {
+    for (int ks = wk; ks < (AM_DBG(a, 2) ? 0 : MV / KSTEP); ks += KS) {
       if constexpr (sizeof(T) == 2) {
         const int q = (lane >> 2) & 3, p = lane & 3;
         // contraction index k = 8g + j of the MFMA  <->  voxel ks*32 + (j < 4 ? 4g + j : 16 + 4g + j - 4): any bijection
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int cx = cx0 + 16 * wx + r16;
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
-    if (cx < a.Cx && !(a.dbg & 1)) {
+    if (cx < a.Cx && !AM_DBG(a, 1)) {
       const int widx = a.taps[tb + t] >> 12;
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -308,11 +316,8 @@ int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
   const size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
   if (lds > 160 * 1024) return -3;
   if (maxvox * (KT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
-  static size_t attr_lds = 48 * 1024;
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) attr_lds = lds;
-    (void)hipGetLastError();
-  }
+  static std::once_flag lds_cap;                  // per instantiation, thread-safe
+  std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   a.split = split;
   dim3 grid(((split + 7) / 8) * 8 * a.ngroup, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a);
@@ -334,7 +339,9 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   a.x_mask = MaskView{x_mask, fd, fh, fw, x_bshift};
   a.y_mask = MaskView{y_mask, fd, fh, fw, y_bshift};
   const int k = ksize;
+#ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WG_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
+#endif
   const bool bf = dtype == AM_DT_BF16;
   // units: taps that share the dY operand AND one dense X sub-brick
   //   conv stride 1: one unit per d-tap (9 taps, no d-halo);  ConvT: the 8 output parities (8 taps each);

@@ -15,8 +15,6 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
-import os
-
 import torch
 
 from . import ops
@@ -279,7 +277,7 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
 # for an event recorded when dy exists; the main stream waits for the side stream before a parameter group is declared final
 # (all-reduce hook) and at the end of backward.  record_stream keeps the caching allocator from recycling x / dy early.
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
-_USE_SIDE = not os.environ.get("AM_NO_SIDE_STREAM")
+_USE_SIDE = True      # tools/step_ab.py flips this attribute for same-process A/B timing; no environment switch exists
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":

@@ -307,11 +307,13 @@ def patch_loss_fwd(inp: torch.Tensor, rec: torch.Tensor, mask: MaskInfo, normali
     B, D, H, W = inp.shape
     L = mask.fd * mask.fh * mask.fw
     l2m = torch.empty(B, L, device=inp.device, dtype=torch.float32)
-    pm = torch.empty(B, L, device=inp.device, dtype=torch.float32)
-    pr = torch.empty(B, L, device=inp.device, dtype=torch.float32)
+    # want_loss=False (teacher pass): pmean/prstd stay NULL, which is also the kernel's cue to skip the visible patches entirely
+    # (their l2 is 0 by definition and their rec voxels may never have been written, engine.forward(needed_patches=...))
+    pm = torch.empty(B, L, device=inp.device, dtype=torch.float32) if want_loss else None
+    pr = torch.empty(B, L, device=inp.device, dtype=torch.float32) if want_loss else None
     info = torch.empty(2, device=inp.device, dtype=torch.float32) if want_loss else None
     hip.lib().patch_loss_fwd(inp.data_ptr(), rec.data_ptr(), mask.t.data_ptr(), B, D, H, W, int(normalized), l2m.data_ptr(),
-                             pm.data_ptr(), pr.data_ptr(), _p(info), _stream())
+                             _p(pm), _p(pr), _p(info), _stream())
     return l2m, pm, pr, info
 
 
@@ -334,9 +336,9 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
     hip.lib().sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream())
 
 
-def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, ema_decay, gnorm_out):
+def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, ema_decay, gnorm_out, grad_scale: float = 1.0):
     hip.lib().adamw_ema(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(ema), n, lr, betas[0], betas[1], eps, wd, step,
-                        _p(sumsq_t), max_norm, ema_decay, _p(gnorm_out), _stream())
+                        _p(sumsq_t), max_norm, ema_decay, grad_scale, _p(gnorm_out), _stream())
 
 
 def ema(ema_t: torch.Tensor, p: torch.Tensor, decay: float):

@@ -147,7 +147,9 @@ int am_mask_sampler(const float* loss, const float* keys, int B, int L, int len_
 int am_sumsq(const float* g, long n, double* out, void* stream);
 int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema /* may be NULL */, long n, double lr, double beta1,
                  double beta2, double eps, double weight_decay, int step, const double* sumsq /* NULL: no clipping */,
-                 double max_norm, double ema_decay, float* gnorm_out, void* stream);
+                 double max_norm, double ema_decay, double grad_scale /* g is multiplied by it before the norm and the update: 1/world
+                 when g holds the all-reduced SUM (DDP's gradient mean, P/pretrain_AnatoMask_DDP.py:239-240), else 1 */,
+                 float* gnorm_out, void* stream);
 int am_ema(float* ema, const float* p, long n, double decay, void* stream);
 
 #ifdef __cplusplus

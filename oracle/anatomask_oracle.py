@@ -24,6 +24,7 @@ behaviour, pinned by the same fixtures at its call sites
 from __future__ import annotations
 
 import math
+import re
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -151,6 +152,64 @@ def closed_form_state(cfg: Config, salt: float = 0.0) -> Params:
     return out
 
 
+def seeded_state(cfg: Config, seed: int = 0) -> Params:
+    """File-free, WELL-CONDITIONED weights both the reference and the build can evaluate: `np.random.RandomState(seed)` draws
+    (legacy MT19937: stable across numpy versions) scaled as the reference's initialisers scale them (SURVEY.md §8
+    'Initialisation facts'):
+      encoder / densify_projs Conv3d: nn.Conv3d default = kaiming_uniform(a=sqrt 5) -> U(+-1/sqrt(fan_in)), bias likewise;
+      decoder Conv3d (incl. proj): trunc_normal(std .02), bias 0                       (P/decoder3D.py:70-73);
+      ConvTranspose3d: kaiming_normal(fan_out, relu) -> N(0, 2/(shape[0]*k^3))         (P/decoder3D.py:74-77);
+      mask_tokens: trunc_normal(0, .02, +-.02)                                         (P/AnatoMask.py:41-42).
+    Norm affines, biases the reference starts at 0 and the BN running statistics get SMALL random offsets (gamma 1 +- 0.1,
+    beta / bias +- 0.05, running_mean +- 0.1, running_var 1 +- 0.2) so that every parameter's role is exercised; a freshly
+    initialised gamma = 1 / beta = 0 would hide a wrong handling of them.  One stream, registration order."""
+    rs = np.random.RandomState(seed)
+    out: Params = {}
+    for k, shp in param_shapes(cfg).items():
+        n = int(np.prod(shp)) if len(shp) else 1
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros((), dtype=torch.int64)
+            continue
+        if k.endswith("running_var"):
+            v = 1.0 + 0.2 * rs.uniform(-1, 1, n)
+        elif k.endswith("running_mean"):
+            v = 0.1 * rs.uniform(-1, 1, n)
+        elif len(shp) == 1 and k.endswith("weight"):           # norm gammas
+            v = 1.0 + 0.1 * rs.uniform(-1, 1, n)
+        elif k.startswith("mask_tokens"):
+            v = np.clip(0.02 * rs.standard_normal(n), -0.02, 0.02)
+        elif len(shp) == 1:                                     # biases / norm betas
+            wk = k[:-4] + "weight"
+            if re.search(r"\.conv[123]\.bias$", k) or k.startswith("densify_projs"):     # nn.Conv3d default bias init
+                v = rs.uniform(-1, 1, n) / math.sqrt(int(np.prod(param_shapes(cfg)[wk][1:])))
+            else:
+                v = 0.05 * rs.uniform(-1, 1, n)
+        elif "up_sample" in k:
+            v = rs.standard_normal(n) * math.sqrt(2.0 / (shp[0] * int(np.prod(shp[2:]))))
+        elif k.startswith("dense_decoder"):
+            v = np.clip(0.02 * rs.standard_normal(n), -2.0, 2.0)
+        else:                                                   # encoder convs, densify_projs
+            v = rs.uniform(-1, 1, n) / math.sqrt(int(np.prod(shp[1:])))
+        out[k] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shp).copy())
+    return out
+
+
+def smooth_volume(B: int, size: Sequence[int], seed: int = 0, noise: float = 0.05) -> torch.Tensor:
+    """A learnable synthetic CT-like volume (low-frequency field + a little noise), fp32 (B,1,*size): masked patches are
+    predictable from their visible neighbours, so a working training step drives the loss well below 1 (overfit tests)."""
+    rs = np.random.RandomState(seed)
+    d, h, w = (np.arange(s, dtype=np.float64) for s in size)
+    out = np.zeros((B, 1, *size), dtype=np.float64)
+    for b in range(B):
+        f = rs.uniform(0.03, 0.12, size=(4, 3)); ph = rs.uniform(0, 2 * np.pi, size=(4, 3)); am = rs.uniform(0.5, 1.0, size=4)
+        for j in range(4):
+            out[b, 0] += am[j] * (np.sin(2 * np.pi * f[j, 0] * d + ph[j, 0])[:, None, None]
+                                  * np.sin(2 * np.pi * f[j, 1] * h + ph[j, 1])[None, :, None]
+                                  * np.sin(2 * np.pi * f[j, 2] * w + ph[j, 2])[None, None, :])
+    out += noise * rs.standard_normal(out.shape)
+    return torch.from_numpy(out.astype(np.float32))
+
+
 def synthetic_volume(B: int, size: Sequence[int], seed: int = 1234) -> torch.Tensor:
     """x ~ N(0,1) fp32 (B,1,*size) from a seeded CPU generator."""
     g = torch.Generator().manual_seed(seed)
@@ -204,12 +263,54 @@ def generate_mask_from_keys(cfg: Config, loss_pred: torch.Tensor, keys: torch.Te
 
 
 # ----------------------------------------------------------------------------
+# bf16-STORAGE emulation (tolerance derivation only; identity unless `with storage("bf16")`)
+# ----------------------------------------------------------------------------
+# The HIP path may keep activations, activation gradients and the MFMA weight copies in bf16 (fp32 accumulation, fp32
+# statistics, fp32 master weights).  Under `with storage("bf16"):` the functions below round to bf16 at exactly the points
+# where that path stores a C > 1 tensor (forward value AND the gradient flowing back through the same point), so that the
+# tests can state: "HIP-bf16 is no further from the fp32 reference than an ideal bf16-storage evaluation of the SAME graph".
+_STORAGE = [None]
+
+
+class storage:
+    def __init__(self, kind: Optional[str]):
+        assert kind in (None, "bf16")
+        self.kind = kind
+
+    def __enter__(self):
+        self.prev, _STORAGE[0] = _STORAGE[0], self.kind
+
+    def __exit__(self, *a):
+        _STORAGE[0] = self.prev
+
+
+class _RoundBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+def _q(t):
+    """storage point of a C > 1 activation (identity in the default fp32 mode)."""
+    return _RoundBF16.apply(t) if _STORAGE[0] == "bf16" else t
+
+
+def _qw(w, x):
+    """MFMA weight copy (bf16 in bf16 mode); Cin == 1 stem convs run on the fp32 VALU path with fp32 weights."""
+    return _RoundBF16.apply(w) if (_STORAGE[0] == "bf16" and x.shape[1] > 1) else w
+
+
+# ----------------------------------------------------------------------------
 # encoder  (a7, a8, a9)
 # ----------------------------------------------------------------------------
 def sparse_conv3d(x, w, b, stride: int, active_b1fff):
     """P/encoder3D.py:12-15: dense Conv3d, then multiply by the up-sampled mask."""
     pad = w.shape[-1] // 2
-    y = F.conv3d(x, w, b, stride=stride, padding=pad)
+    y = _q(F.conv3d(x, _qw(w, x), b, stride=stride, padding=pad))
     return y * upsample_mask(active_b1fff, y.shape[2:]).to(y.dtype)
 
 
@@ -230,12 +331,12 @@ def basic_res_block(p: Params, prefix: str, x, stride: int, active, has_sc: bool
     """P/STUNet_head.py:96-103 with every conv/norm in its Sparse* form
     (P/encoder3D.py:301-329; converted InstanceNorm3d keeps eps=1e-5)."""
     y = sparse_conv3d(x, p[f"{prefix}.conv1.weight"], p[f"{prefix}.conv1.bias"], stride, active)
-    y = F.leaky_relu(sparse_instance_norm(y, p[f"{prefix}.norm1.weight"], p[f"{prefix}.norm1.bias"], 1e-5, active), 0.01)
+    y = _q(F.leaky_relu(sparse_instance_norm(y, p[f"{prefix}.norm1.weight"], p[f"{prefix}.norm1.bias"], 1e-5, active), 0.01))
     y = sparse_conv3d(y, p[f"{prefix}.conv2.weight"], p[f"{prefix}.conv2.bias"], 1, active)
     y = sparse_instance_norm(y, p[f"{prefix}.norm2.weight"], p[f"{prefix}.norm2.bias"], 1e-5, active)
     if has_sc:
         x = sparse_conv3d(x, p[f"{prefix}.conv3.weight"], p[f"{prefix}.conv3.bias"], stride, active)
-    return F.leaky_relu(y + x, 0.01)
+    return _q(F.leaky_relu(y + x, 0.01))
 
 
 def encoder_forward(cfg: Config, p: Params, masked_inp, active) -> List[torch.Tensor]:
@@ -284,10 +385,10 @@ def densify(cfg: Config, p: Params, feats: List[torch.Tensor], active) -> List[t
     for i, f in enumerate(fe):
         if i < n_dec:
             f = sparse_instance_norm(f, p[f"densify_norms.{i}.weight"], p[f"densify_norms.{i}.bias"], 1e-6, active)
-            f = torch.where(upsample_mask(cur, f.shape[2:]), f, p[f"mask_tokens.{i}"].expand_as(f))
+            f = _q(torch.where(upsample_mask(cur, f.shape[2:]), f, p[f"mask_tokens.{i}"].expand_as(f)))
             if f"densify_projs.{i}.weight" in p:
                 w = p[f"densify_projs.{i}.weight"]
-                f = F.conv3d(f, w, p[f"densify_projs.{i}.bias"], padding=w.shape[-1] // 2)
+                f = _q(F.conv3d(f, _qw(w, f), p[f"densify_projs.{i}.bias"], padding=w.shape[-1] // 2))
             to_dec.append(f)
         cur = cur.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
     return to_dec
@@ -298,14 +399,14 @@ def decoder_forward(cfg: Config, p: Params, to_dec: List[torch.Tensor], train: b
     conv3-BN-ReLU6-conv3-BN; finally 1x1 proj."""
     x = 0
     for i in range(len(cfg.dec_chs) - 1):
-        x = x + to_dec[i]
+        x = _q(x + to_dec[i]) if i else x + to_dec[i]
         q = f"{DEC}.{i}"
-        x = F.conv_transpose3d(x, p[f"{q}.up_sample.weight"], p[f"{q}.up_sample.bias"], stride=2, padding=1)
-        x = F.conv3d(x, p[f"{q}.conv.0.weight"], None, padding=1)
-        x = F.relu6(batch_norm3d(p, f"{q}.conv.1", x, train, new_buffers))
-        x = F.conv3d(x, p[f"{q}.conv.3.weight"], None, padding=1)
+        x = _q(F.conv_transpose3d(x, _qw(p[f"{q}.up_sample.weight"], x), p[f"{q}.up_sample.bias"], stride=2, padding=1))
+        x = _q(F.conv3d(x, _qw(p[f"{q}.conv.0.weight"], x), None, padding=1))
+        x = _q(F.relu6(batch_norm3d(p, f"{q}.conv.1", x, train, new_buffers)))
+        x = _q(F.conv3d(x, _qw(p[f"{q}.conv.3.weight"], x), None, padding=1))
         x = batch_norm3d(p, f"{q}.conv.4", x, train, new_buffers)
-    return F.conv3d(x, p["dense_decoder.proj.weight"], p["dense_decoder.proj.bias"])
+    return F.conv3d(_q(x), p["dense_decoder.proj.weight"], p["dense_decoder.proj.bias"])
 
 
 # ----------------------------------------------------------------------------
@@ -467,7 +568,7 @@ def student_loss_and_grads(cfg: Config, weights: Params, inp, mask, train: bool 
 
 
 def train_step(st: StepState, inp, mask1, sampler_keys, epoch: int, total_epoch: int, lr: float,
-               ema_decay: float, clip: float = 12.0, wd: float = 1e-5):
+               ema_decay: float, clip: float = 12.0, wd: float = 1e-5, eps: float = 1e-8):
     """One AnatoMask step, P/pretrain_AntoMask.py:418-441 (fp32 branch), with the
     random draws (mask1, sampler keys) supplied by the caller (teacher-forced)."""
     cfg = st.cfg
@@ -481,6 +582,6 @@ def train_step(st: StepState, inp, mask1, sampler_keys, epoch: int, total_epoch:
     live = {k: g for k, g in grads.items() if g is not None}
     gnorm = clip_grad_norm(live, clip)                                      # :437
     st.step += 1
-    adamw_step(st.student, live, st.opt, st.step, lr, wd)                   # :438
+    adamw_step(st.student, live, st.opt, st.step, lr, wd, eps=eps)          # :438
     ema_update(st.teacher, st.student, ema_decay)                           # :440
     return {"loss": float(loss), "grad_norm": float(gnorm), "mask": mask, "recon_loss": recon, "rec_loss": rec_loss}

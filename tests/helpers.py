@@ -19,7 +19,32 @@ def tiny_cfg(f):
 
 
 def np_volume(B, size, seed):
-    return torch.from_numpy(np.random.RandomState(int(seed)).standard_normal((B, 1, *size)).astype(np.float32))
+    """the fixtures' input generator (CT-like learnable volume, legacy MT19937 stream): same call as make_fixtures.py"""
+    return O.smooth_volume(B, size, int(seed))
+
+
+def fixture_weights(cfg, f):
+    """the fixtures' weights: reference-initialiser-scaled RandomState draws (oracle.seeded_state), seed stored in the fixture"""
+    return O.seeded_state(cfg, int(f["weight_seed"]))
+
+
+def grad_errors(grads, f, n=2048):
+    """per-tensor (relative L2 error, cosine) of `grads` against the reference's gradient samples in fixture `f`
+    (`gradsample::<name>`: <= n evenly spaced elements of every gradient tensor).  Tensors whose reference gradient is
+    analytically zero (norm < 1e-7: conv biases that feed a norm) are reported with cos = None."""
+    out = {}
+    for k in f:
+        if not k.startswith("gradsample::"):
+            continue
+        name = k[12:]
+        w = f[k].astype(np.float64)
+        g = sample(grads[name], n).astype(np.float64)
+        nw = np.linalg.norm(w)
+        if nw < 1e-7:
+            out[name] = (float(np.linalg.norm(g)), None)
+            continue
+        out[name] = (float(np.linalg.norm(g - w) / nw), float((g * w).sum() / (np.linalg.norm(g) * nw + 1e-300)))
+    return out
 
 
 def sample(t, n=96):

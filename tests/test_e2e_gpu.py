@@ -1,17 +1,22 @@
 """GPU: the whole HIP path (engine + module API + fused trainer) against the reference-generated fixtures
-(tests/golden/*.npz) and the CPU oracle.  Tolerances:
+(tests/golden/*.npz: reference-initialiser weights, CT-like volumes) and the CPU oracle.  Tolerances (floors measured by
+tests/calibrate_tolerances.py, stated next to the constants in tests/test_oracle_golden.py):
   fp32 forward quantities (stage maps, rec, per-patch l2, loss): <= 2e-4 relative (fixture-vs-HIP), fp32 floor ~2e-5
-  fp32 gradients end-to-end: <= 5e-2 per tensor (LeakyReLU/ReLU6 gate flips; the reference itself sits 4e-4..2e-2 from fp64)
-  N-step weights: same metrics/bounds as tests/test_oracle_golden.py (Adam amplifies the gate-flip noise)
-  bf16 storage: loss within 2e-2 relative, rec within 5e-2 of its max, N-step loss trajectory within 2e-2
+  fp32 gradients end-to-end, EVERY parameter tensor vs the reference's gradient: relative L2 <= 1.5e-2 (median over tensors
+      <= 6e-3), cosine >= 0.9998 -- the reference's own fp32-vs-fp64 floor is 6e-3 / 2.6e-3 / 0.99998
+  one optimizer step: update error median <= 1e-3, <= 0.3 % sign-flipped elements; N steps: statistical (chaotic in the reference too)
+  bf16 storage: loss within 2e-3; per-tensor gradient error bounded by what an IDEAL bf16-storage evaluation of the same graph
+      (oracle.storage("bf16")) shows against the same reference gradient, times a stated factor
+  learning: 120 steps on one fixed batch follow the reference's loss curve and end below 0.1 (fp32 and bf16)
 """
 import numpy as np
 import pytest
 import torch
 
 from oracle import anatomask_oracle as O
-from tests.helpers import assert_checks, load, np_volume, rel_err, sample, tiny_cfg
-from tests.test_oracle_golden import GRAD_RTOL, _zero_grad_bias, delta_metrics, mismatch_fraction
+from tests.helpers import assert_checks, fixture_weights, grad_errors, load, np_volume, rel_err, sample, tiny_cfg
+from tests.test_oracle_golden import (GRAD_COS_MIN, GRAD_RTOL, GRAD_RTOL_MEDIAN, NSTEP_UPDATE_MEDIAN, NSTEP_WEIGHT_MAX, NSTEP_WEIGHT_MEDIAN,
+                                      STEP1_FLIPPED, STEP1_UPDATE_MEDIAN, _zero_grad_bias, delta_metrics, mismatch_fraction)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -40,7 +45,7 @@ def feats_ncdhw(f, mask, cfg):
 def test_forward_matches_reference_fixture(fwd):
     from anatomask_amd import engine, ops
     cfg = tiny_cfg(fwd)
-    W = O.closed_form_state(cfg)
+    W = fixture_weights(cfg, fwd)
     x = np_volume(int(fwd["B"]), cfg.input_size, fwd["x_seed"])
     mask = torch.from_numpy(fwd["fwd_mask"])
     m = make_model(cfg, W).train()
@@ -71,7 +76,7 @@ def test_forward_matches_reference_fixture(fwd):
 def test_module_api_loss_and_grads(fwd):
     """Reference calling convention: inp,rec = model(x, active_b1ff=mask); loss,_ = model.forward_loss(...); loss.backward()."""
     cfg = tiny_cfg(fwd)
-    W = O.closed_form_state(cfg)
+    W = fixture_weights(cfg, fwd)
     x = np_volume(int(fwd["B"]), cfg.input_size, fwd["x_seed"]).to(DEV)
     mask = torch.from_numpy(fwd["fwd_mask"]).to(DEV)
     m = make_model(cfg, W).train()
@@ -96,14 +101,21 @@ def test_module_api_loss_and_grads(fwd):
             scale = np.abs(fwd[k]).max()
             if scale > 1e-6:
                 assert np.abs(grads[k[6:]].cpu().numpy() - fwd[k]).max() < GRAD_RTOL * scale, k
-        if k.startswith("gradsample::"):
-            assert rel_err(sample(grads[k[12:]], 128), fwd[k]) < GRAD_RTOL, k
+    errs = grad_errors(grads, fwd)                       # every live tensor vs the reference's gradient
+    assert len(errs) == 102
+    live = {k: v for k, v in errs.items() if v[1] is not None}
+    worst = max(live.items(), key=lambda kv: kv[1][0])
+    print("HIP fp32 gradient vs reference: median rel %.2e  max %.2e (%s)  min cos %.6f"
+          % (np.median([v[0] for v in live.values()]), worst[1][0], worst[0], min(v[1] for v in live.values())))
+    for k, (e, c) in live.items():
+        assert e < GRAD_RTOL and c > GRAD_COS_MIN, (k, e, c)
+    assert np.median([v[0] for v in live.values()]) < GRAD_RTOL_MEDIAN
 
 
 def test_gradients_vs_oracle_same_box(fwd):
     """Same check against the CPU oracle evaluated here (cosine + norm per tensor)."""
     cfg = tiny_cfg(fwd)
-    W = O.closed_form_state(cfg)
+    W = O.seeded_state(cfg, 3)
     x = np_volume(2, cfg.input_size, 77)
     mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(5))
     loss_o, _, g_o, _ = O.student_loss_and_grads(cfg, W, x, mask)
@@ -117,14 +129,13 @@ def test_gradients_vs_oracle_same_box(fwd):
             continue
         a, b = p.grad.cpu().double().flatten(), g_o[k].double().flatten()
         cos = float((a * b).sum() / (a.norm() * b.norm()))
-        big = a.numel() >= 256          # tiny tensors (biases, norm affines) are cancelling sums over all voxels: noisier
-        assert cos > (0.995 if big else 0.97) and abs(float(a.norm() / b.norm()) - 1) < (GRAD_RTOL if big else 0.12), (k, cos, float(a.norm()), float(b.norm()))
+        assert cos > GRAD_COS_MIN and float((a - b).norm() / b.norm()) < GRAD_RTOL, (k, cos, float(a.norm()), float(b.norm()))
 
 
 def _run_trainer(dtype, r, f, teacher_force_student_mask=False):
     from anatomask_amd.trainer import AnatoMaskTrainer
     cfg = tiny_cfg(f)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, f)
     m = make_model(cfg, W0, dtype)
     ep, tot = (int(v) for v in r["epoch"])
     tr = AnatoMaskTrainer(m, lr=float(r["lr"]), ema_decay=float(r["ema_decay"]), total_epochs=tot + 1, distributed=False)
@@ -161,9 +172,10 @@ def test_trainer_n_steps_fp32_matches_reference():
         mfs.append((mismatch_fraction(snap[0][k] - W0[k], r["step1delta::" + k]) * n_el, n_el))
         mfe.append((mismatch_fraction(snap[1][k] - W0[k], r["step1ema::" + k]) * n_el, n_el))
         assert c > 0.7, ("step1", k, e, c)
-    assert np.median(errs) < 5e-3, np.median(errs)
+    print("HIP fp32 first update vs reference: median rel %.2e, flipped %.2e" % (np.median(errs), sum(a for a, _ in mfs) / sum(b for _, b in mfs)))
+    assert np.median(errs) < STEP1_UPDATE_MEDIAN, np.median(errs)
     for mm in (mfs, mfe):
-        assert sum(a for a, _ in mm) / sum(b for _, b in mm) <= 0.01
+        assert sum(a for a, _ in mm) / sum(b for _, b in mm) <= STEP1_FLIPPED
     fsd = {k: v.cpu() for k, v in m.state_dict().items()}
     esd = {k: v.cpu() for k, v in tr.teacher.ema.state_dict().items()}
     errs, werrs = [], []
@@ -179,23 +191,106 @@ def test_trainer_n_steps_fp32_matches_reference():
         errs.append(e)
         werrs.append(float((fsd[k] - W0[k]).norm()) * e / (float(W0[k].norm()) + 1e-30))
         if W0[k].numel() >= 64:
-            assert e < 0.6 and c > 0.8, ("final", k, e, c)
-            assert e2 < 0.6 and c2 > 0.8, ("ema", k, e2, c2)
+            assert e < 0.9 and c > 0.5, ("final", k, e, c)
+            assert e2 < 0.9 and c2 > 0.5, ("ema", k, e2, c2)
     print("HIP fp32 vs reference, update L2 error after N steps: median %.3f max %.3f; weight-level median %.2e max %.2e"
           % (np.median(errs), max(errs), np.median(werrs), max(werrs)))
-    assert np.median(errs) < 0.15 and np.median(werrs) < 2e-2 and max(werrs) < 0.2
+    assert np.median(errs) < NSTEP_UPDATE_MEDIAN and np.median(werrs) < NSTEP_WEIGHT_MEDIAN and max(werrs) < NSTEP_WEIGHT_MAX
+
+
+def _emulated_bf16_errors(cfg, W, x, mask, fwd):
+    """per-tensor (rel, cos) of an IDEAL bf16-storage evaluation of the reference graph (CPU oracle under storage("bf16"):
+    fp32 arithmetic, every C > 1 activation / gradient / MFMA weight copy rounded to bf16 where the HIP path stores it)
+    against the reference's fp32 gradient."""
+    with O.storage("bf16"):
+        loss, _, g, _ = O.student_loss_and_grads(cfg, W, x, mask)
+    return float(loss), grad_errors({k: v for k, v in g.items() if v is not None}, fwd)
+
+
+def test_bf16_gradients_no_worse_than_ideal_bf16_storage(fwd):
+    """bf16 STORAGE (the benchmarked precision), one student forward + backward on the reference fixture.
+    bf16 rounding (2^-9 relative) flips ~1000x more LeakyReLU(0.01)/ReLU6 gates than fp32 rounding does, so NO bf16-storage
+    evaluation of this graph reproduces the fp32 gradient closely: the ideal emulation sits at a median relative L2 error of
+    ~0.27 per tensor (cos 0.75..0.97), against 2.3e-2 / cos 0.999 when the activations are smooth.  The assertion is therefore
+    relative to that emulation, tensor by tensor: the HIP path must not be further from the reference than BF16_FACTOR x the
+    ideal bf16-storage evaluation (+ a small absolute slack for tensors the emulation happens to hit well) -- a wrong tap,
+    a missing term or a wrong scale in any backward kernel fails it (errors >= 1, cos <= 0.5 on the affected tensors)."""
+    BF16_FACTOR, SLACK = 1.6, 0.08
+    cfg = tiny_cfg(fwd)
+    W = fixture_weights(cfg, fwd)
+    x = np_volume(int(fwd["B"]), cfg.input_size, fwd["x_seed"])
+    mask = torch.from_numpy(fwd["fwd_mask"])
+    loss_e, emu = _emulated_bf16_errors(cfg, W, x, mask, fwd)
+    m = make_model(cfg, W, torch.bfloat16).train()
+    inp, rec = m(x.to(DEV), active_b1ff=mask.to(DEV))
+    loss, _ = m.forward_loss(inp, rec, mask.to(DEV))
+    loss.backward()
+    ref_loss = float(fwd["fwd_loss"])
+    assert abs(loss.item() - ref_loss) < 2e-3 * ref_loss, (loss.item(), ref_loss, loss_e)
+    errs = grad_errors({k: p.grad for k, p in m.named_parameters() if p.grad is not None}, fwd)
+    live = [k for k, v in errs.items() if v[1] is not None]
+    med_h, med_e = np.median([errs[k][0] for k in live]), np.median([emu[k][0] for k in live])
+    print("bf16 gradient vs reference: HIP median rel %.3f (min cos %.3f) | ideal bf16-storage emulation median rel %.3f (min cos %.3f)"
+          % (med_h, min(errs[k][1] for k in live), med_e, min(emu[k][1] for k in live)))
+    assert med_h < BF16_FACTOR * med_e, (med_h, med_e)
+    for k in live:
+        assert errs[k][0] < BF16_FACTOR * emu[k][0] + SLACK, (k, errs[k], emu[k])
+        assert errs[k][1] > min(emu[k][1] - 0.15, 0.9), (k, errs[k], emu[k])
+    gh = float(torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None]).norm())
+    assert abs(gh - float(np.linalg.norm(fwd["grad_norms"][fwd["grad_norms"] > 0]))) < 0.1 * gh
 
 
 def test_trainer_n_steps_bf16_tracks_reference():
+    """N teacher-forced steps in bf16 storage: loss trajectory within 2e-3 of the reference at every step, grad-norm within 15 %,
+    and the N-step weight update no further from the reference's than twice the fp32 N-step bound (itself the reference's
+    fp32-vs-fp64 chaos floor, tests/test_oracle_golden.py)."""
     r, f = load("train_tiny.npz"), load("forward_tiny.npz")
     cfg, W0, m, tr, out, _ = _run_trainer(torch.bfloat16, r, f, teacher_force_student_mask=True)
     for s, o in enumerate(out):
         assert np.array_equal(o["mask"].numpy().astype(bool).reshape(r["mask"][s].shape), r["mask"][s])
-        assert abs(o["loss"].item() - r["losses"][s]) < 2e-2 * abs(r["losses"][s]), (s, o["loss"].item(), r["losses"][s])
-        # bf16 rounding (2^-8) flips far more LeakyReLU/ReLU6 gates than fp32's 1e-5 does: on this ill-conditioned
-        # synthetic problem the gradient is only reproducible near the output layers (DESIGN.md "Parity tolerances")
-        assert 0.4 < o["grad_norm"].item() / r["grad_norms"][s] < 2.5, (s, o["grad_norm"].item(), r["grad_norms"][s])
-    assert all(torch.isfinite(v).all() for v in m.state_dict().values())
+        assert abs(o["loss"].item() - r["losses"][s]) < 2e-3 * abs(r["losses"][s]), (s, o["loss"].item(), r["losses"][s])
+        assert abs(o["grad_norm"].item() / r["grad_norms"][s] - 1) < 0.15, (s, o["grad_norm"].item(), r["grad_norms"][s])
+    fsd = {k: v.float().cpu() for k, v in m.state_dict().items()}
+    assert all(torch.isfinite(v).all() for v in fsd.values())
+    errs, werrs = [], []
+    for k in [str(n) for n in r["names"]]:
+        if "finaldelta::" + k not in r or _zero_grad_bias(k) or np.linalg.norm(r["finaldelta::" + k]) < 1e-9:
+            continue
+        e, c = delta_metrics(fsd[k] - W0[k], r["finaldelta::" + k])
+        errs.append(e)
+        werrs.append(float((fsd[k] - W0[k]).norm()) * e / (float(W0[k].norm()) + 1e-30))
+    print("HIP bf16 vs reference, update L2 error after N steps: median %.3f max %.3f; weight-level median %.2e max %.2e"
+          % (np.median(errs), max(errs), np.median(werrs), max(werrs)))
+    assert np.median(errs) < 2 * NSTEP_UPDATE_MEDIAN and np.median(werrs) < 2 * NSTEP_WEIGHT_MEDIAN and max(werrs) < 2 * NSTEP_WEIGHT_MAX
+
+
+@pytest.mark.parametrize("dtype,track,final", [(torch.float32, 2e-3, 0.1), (torch.bfloat16, 2e-2, 0.12)])
+def test_overfit_one_batch_follows_reference_curve(dtype, track, final):
+    """Does the step LEARN?  120 full AnatoMask steps (teacher, sampler, student, backward, clip, AdamW, EMA) on one fixed CT-like
+    batch, the random draws teacher-forced from the reference's run of the same thing (tests/golden/overfit_tiny.npz: loss
+    1.005 -> 0.044).  The first 5 steps must follow the reference's loss curve within `track` (relative); after that the
+    sampler's hard-patch set flips with 1e-7 differences and the trajectories decorrelate (the CPU oracle itself is 1e-2..4e-2
+    off the reference from step 7 on), so the curve is bounded instead: every 10-step mean within 25 % of the reference's, and
+    the last 10 steps average below `final`."""
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    ov, f = load("overfit_tiny.npz"), load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    m = make_model(cfg, fixture_weights(cfg, f), dtype)
+    ep, tot = (int(v) for v in ov["epoch"])
+    tr = AnatoMaskTrainer(m, lr=float(ov["lr"]), ema_decay=float(ov["ema_decay"]), total_epochs=tot + 1, distributed=False)
+    x = np_volume(int(f["B"]), cfg.input_size, ov["x_seed"]).to(DEV)
+    losses = []
+    for s in range(int(ov["N"])):
+        o = tr.step(x, epoch=ep, mask1=torch.from_numpy(ov["mask1"][s]), keys=torch.from_numpy(ov["keys"][s]))
+        losses.append(o["loss"])
+    losses = torch.cat(losses).cpu().numpy()
+    ref = ov["losses"]
+    assert np.isfinite(losses).all()
+    assert np.abs(losses[:5] / ref[:5] - 1).max() < track, (losses[:5], ref[:5])
+    blocks = losses.reshape(-1, 10).mean(1) / ref.reshape(-1, 10).mean(1)
+    print("overfit", dtype, "loss[::10]", np.round(losses[::10], 4), "block ratio to reference", np.round(blocks, 3))
+    assert np.abs(blocks - 1).max() < 0.25, blocks
+    assert losses[-10:].mean() < final, losses[-10:]
 
 
 def test_reference_style_driver_loop(fwd):
@@ -205,7 +300,7 @@ def test_reference_style_driver_loop(fwd):
     from anatomask_amd.trainer import AnatoMaskTrainer
     r = load("train_tiny.npz")
     cfg = tiny_cfg(fwd)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, load("forward_tiny.npz"))
     ep, tot = (int(v) for v in r["epoch"])
     x = np_volume(int(fwd["B"]), cfg.input_size, r["x_seeds"][0]).to(DEV)
     mask1 = torch.from_numpy(r["mask1"][0]).to(DEV)
@@ -252,7 +347,7 @@ def test_depth2_blocks_identity_shortcut_vs_oracle():
     (P/STUNet_head.py:99-103).  Forward + gradients against the CPU oracle on the same box."""
     from anatomask_amd import modules as M
     cfg = O.Config([8, 16, 32, 64, 128, 128], [2, 2, 2, 2, 2, 2], 128, (32, 32, 48), 0.6)
-    W = O.closed_form_state(cfg, salt=0.3)
+    W = O.seeded_state(cfg, 11)
     assert len(W) == 131 + 5 * 8                       # 8 more entries per extra block
     x = np_volume(2, cfg.input_size, 91)
     mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(9))
@@ -280,7 +375,7 @@ def test_depth2_blocks_identity_shortcut_vs_oracle():
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         dev_ = abs(float(a.norm() / b.norm()) - 1)
         big = a.numel() >= 256
-        assert cos > (0.99 if big else 0.95) and dev_ < (2 * GRAD_RTOL if big else 0.15), (k, cos, float(a.norm()), float(b.norm()))
+        assert cos > GRAD_COS_MIN and dev_ < GRAD_RTOL, (k, cos, float(a.norm()), float(b.norm()))
         if big:
             n_big += 1
             n_tight += dev_ < GRAD_RTOL
@@ -295,7 +390,7 @@ def test_trainer_distributed_path_single_rank_nccl():
     from anatomask_amd.trainer import AnatoMaskTrainer
     r, f = load("train_tiny.npz"), load("forward_tiny.npz")
     cfg = tiny_cfg(f)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, load("forward_tiny.npz"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
@@ -320,7 +415,7 @@ def test_checkpoint_roundtrip_and_finetune_handoff(tmp_path):
     from anatomask_amd.trainer import AnatoMaskTrainer
     r, f = load("train_tiny.npz"), load("forward_tiny.npz")
     cfg = tiny_cfg(f)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, load("forward_tiny.npz"))
     x = np_volume(int(f["B"]), cfg.input_size, 5).to(DEV)
 
     def fresh():
@@ -350,7 +445,7 @@ def test_recompute_mode_matches_plain_backward():
     """P/GC.py policy (checkpoint per encoder stage / decoder block): same loss, same gradients, BN buffers updated once."""
     from anatomask_amd import modules as M
     cfg = O.Config([8, 16, 32, 64, 128, 128], [2, 1, 2, 1, 1, 1], 128, (32, 32, 48), 0.6)
-    W = O.closed_form_state(cfg, salt=0.7)
+    W = O.seeded_state(cfg, 12)
     x = np_volume(2, cfg.input_size, 3).to(DEV)
     mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(4)).to(DEV)
     res = []
@@ -378,7 +473,7 @@ def test_plain_spark_step_vs_oracle():
     from anatomask_amd.trainer import AnatoMaskTrainer
     f = load("forward_tiny.npz")
     cfg = tiny_cfg(f)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, load("forward_tiny.npz"))
     x = np_volume(2, cfg.input_size, 41)
     mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(8))
     loss_o, _, grads, _ = O.student_loss_and_grads(cfg, {k: v.clone() for k, v in W0.items()}, x, mask)
@@ -395,7 +490,7 @@ def test_forward_return_feat_and_vis():
     """SparK.forward(return_feat=True) / (vis=True) outputs (P/AnatoMask.py:172-185) vs the oracle's densify / unpatchify."""
     f = load("forward_tiny.npz")
     cfg = tiny_cfg(f)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, load("forward_tiny.npz"))
     x = np_volume(2, cfg.input_size, 43)
     mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(9))
     m = make_model(cfg, W0).eval()
@@ -421,7 +516,7 @@ def test_config1_stunet_small_plain_spark_step():
     one fused HIP step vs the CPU oracle step on the same volumes, fp32."""
     from anatomask_amd.trainer import AnatoMaskTrainer
     cfg = O.Config([16, 32, 64, 128, 256, 256], [1] * 6, 256, (48, 48, 48), 0.6)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, load("forward_tiny.npz"))
     x = np_volume(2, cfg.input_size, 51)
     mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(10))
     loss_o, _, grads, _ = O.student_loss_and_grads(cfg, {k: v.clone() for k, v in W0.items()}, x, mask)

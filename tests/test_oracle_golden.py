@@ -6,16 +6,24 @@ import pytest
 import torch
 
 from oracle import anatomask_oracle as O
-from tests.helpers import assert_checks, load, np_volume, rel_err, sample, tiny_cfg
+from tests.helpers import assert_checks, fixture_weights, grad_errors, load, np_volume, rel_err, sample, tiny_cfg
 
 torch.set_num_threads(8)
 
-# End-to-end fp32 gradients are only reproducible to ~1e-2: a 1e-5 activation difference flips a few
-# LeakyReLU/ReLU6 gates and every flip is an O(1) change of that element's gradient.  Measured here:
-# the reference's own fp32 gradients sit 4e-4..2e-2 (relative L2, per tensor) from an fp64 evaluation
-# of the same graph (DESIGN.md "Parity tolerances").  Tight kernel-level parity is asserted per op in
-# tests/test_ops_gpu.py; this end-to-end bound is the noise floor times a small factor.
-GRAD_RTOL = 5e-2
+# End-to-end gradient tolerances (per parameter tensor, relative L2 over <= 2048 sampled elements, against the REFERENCE's
+# gradient in tests/golden/forward_tiny.npz).  Floors measured with tests/calibrate_tolerances.py on these fixtures
+# (reference-initialiser weights, CT-like input):
+#   * the oracle runs the same torch-CPU fp32 ops as the reference:            median 8e-5, max 2e-4  -> ORACLE bound 1e-3;
+#   * the reference's own fp32 gradient vs an fp64 evaluation of the same graph: median 2.6e-3, max 6.1e-3, min cos 0.99998.
+#     That second number is what ANY other fp32 implementation (different summation order) can achieve: a 1e-6 activation
+#     difference flips a few LeakyReLU(0.01) / ReLU6 gates and every flip is an O(1) change of that element's gradient (with
+#     smooth activations the same comparison gives 2.5e-6) -> HIP-fp32 bound: max 1.5e-2, median 6e-3, cos >= 0.9998.
+#   * an ideal bf16-STORAGE evaluation of the graph (oracle.storage("bf16")) vs fp64: median 0.27, worst-tensor cos 0.75:
+#     the HIP-bf16 bound is stated relative to that emulation (tests/test_e2e_gpu.py).
+ORACLE_GRAD_RTOL = 1e-3
+GRAD_RTOL = 1.5e-2          # HIP fp32, per tensor (max);  GRAD_RTOL_MEDIAN over tensors below
+GRAD_RTOL_MEDIAN = 6e-3
+GRAD_COS_MIN = 0.9998
 
 
 @pytest.fixture(scope="module")
@@ -26,7 +34,7 @@ def fwd():
 @pytest.fixture(scope="module")
 def setup(fwd):
     cfg = tiny_cfg(fwd)
-    W = O.closed_form_state(cfg)
+    W = fixture_weights(cfg, fwd)
     x = np_volume(int(fwd["B"]), cfg.input_size, fwd["x_seed"])
     np.testing.assert_allclose(sample(x), fwd["x_sample"], rtol=0, atol=0)
     return cfg, W, x, torch.from_numpy(fwd["fwd_mask"])
@@ -61,15 +69,18 @@ def test_forward_loss_and_grads(fwd, setup):
         if gn < 1e-6:
             assert float(g.norm()) < 1e-5, k
             continue
-        assert abs(float(g.norm()) - gn) < GRAD_RTOL * gn, (k, float(g.norm()), gn)
+        assert abs(float(g.norm()) - gn) < ORACLE_GRAD_RTOL * gn, (k, float(g.norm()), gn)
     for k in fwd:
         if k.startswith("grad::"):
             name = k[6:]
             scale = np.abs(fwd[k]).max()
             if scale > 1e-6:
-                assert np.abs(grads[name].numpy() - fwd[k]).max() < GRAD_RTOL * scale, name
-        if k.startswith("gradsample::"):
-            assert rel_err(sample(grads[k[12:]], 128), fwd[k]) < GRAD_RTOL, k
+                assert np.abs(grads[name].numpy() - fwd[k]).max() < ORACLE_GRAD_RTOL * scale, name
+    errs = grad_errors(grads, fwd)
+    assert len(errs) == 102                                     # every live parameter tensor (107 - 5 dead)
+    for name, (e, c) in errs.items():
+        if c is not None:
+            assert e < ORACLE_GRAD_RTOL and c > 1 - 1e-6, (name, e, c)
     for k in fwd:
         if k.startswith("bn1::"):
             np.testing.assert_allclose(newbuf[k[5:]].numpy(), fwd[k], rtol=1e-5, atol=1e-6)
@@ -138,14 +149,25 @@ def mismatch_fraction(got_delta, want_sample, n=1024):
     return float((np.abs(g - w) > 0.1 * np.abs(w).max()).mean())
 
 
+# N-step bounds (shared with the HIP tests).  The step is CHAOTIC at this horizon in the reference itself: the same reference code
+# evaluated in fp64 instead of fp32 gives, after 6 steps at lr 1e-3, a per-tensor update (weights - initial weights) that differs
+# by 0.23 (median over tensors, relative L2; max 0.40), although loss and grad-norm agree to 1.4e-4 / 1.6e-2 at every step and
+# the first step's update agrees to 3e-5 (median) with 2e-4 of the sampled elements sign-flipped.  Mechanism: Adam's first
+# updates are lr*sign(g) per element, elements whose gradient is float noise flip, and tiny-sample norms (the coarsest maps hold
+# a few dozen voxels) amplify.  So: strict after ONE step, statistical after N.
+STEP1_UPDATE_MEDIAN = 1e-3       # median over tensors of the relative L2 error of the first update (measured 3e-5 .. 5e-5)
+STEP1_FLIPPED = 3e-3             # fraction of sampled elements whose first update is off by > 10 % of the largest update (measured 2e-4 .. 7e-4)
+NSTEP_UPDATE_MEDIAN = 0.45       # median over tensors, relative L2 error of the N-step update (reference fp32-vs-fp64: 0.23 .. 0.27)
+NSTEP_WEIGHT_MEDIAN, NSTEP_WEIGHT_MAX = 4e-2, 0.6   # the same error relative to each tensor's own norm (measured 1.7e-2 / 0.34)
+
+
 def test_n_step_run_matches_reference():
-    """Teacher-forced N-step AnatoMask run vs the reference (P/pretrain_AntoMask.py:418-441).
-    Strict after ONE step (pins clip/AdamW/EMA arithmetic: update L2 error <= 2e-2, measured fp32
-    floor 1e-3); trajectory-level after N=6 steps (fp32-vs-fp64 floor of the update is 8e-2)."""
+    """Teacher-forced N-step AnatoMask run vs the reference (P/pretrain_AntoMask.py:418-441): sampler masks bit-exact at every
+    step, loss 2e-4, grad-norm 5e-2; strict after ONE step (pins clip/AdamW/EMA arithmetic); statistical after N=6."""
     r = load("train_tiny.npz")
     f = load("forward_tiny.npz")
     cfg = tiny_cfg(f)
-    W0 = O.closed_form_state(cfg)
+    W0 = fixture_weights(cfg, f)
     st = O.StepState(cfg, W0)
     N, lr = int(r["N"]), float(r["lr"])
     ep, tot = (int(v) for v in r["epoch"])
@@ -171,9 +193,9 @@ def test_n_step_run_matches_reference():
                 mfs.append((mismatch_fraction(st.student[k] - W0[k], r["step1delta::" + k]) * n_el, n_el))
                 mfe.append((mismatch_fraction(st.teacher[k] - W0[k], r["step1ema::" + k]) * n_el, n_el))
                 assert c > 0.7, ("step1", k, e, c)
-            assert np.median(errs) < 5e-3, np.median(errs)
-            for m in (mfs, mfe):                      # sign-flipped elements over the whole model: <= 1%
-                assert sum(a for a, _ in m) / sum(b for _, b in m) <= 0.01
+            assert np.median(errs) < STEP1_UPDATE_MEDIAN, np.median(errs)
+            for m in (mfs, mfe):                      # sign-flipped elements over the whole model
+                assert sum(a for a, _ in m) / sum(b for _, b in m) <= STEP1_FLIPPED
     errs, werrs = [], []
     for k in names:
         if "final::" + k in r:                       # integer buffers
@@ -187,9 +209,40 @@ def test_n_step_run_matches_reference():
         errs.append(e)
         werrs.append(float((st.student[k] - W0[k]).norm()) * e / (float(W0[k].norm()) + 1e-30))
         if W0[k].numel() >= 64:
-            assert e < 0.6 and c > 0.8, ("final", k, e, c)
-            assert e2 < 0.6 and c2 > 0.8, ("ema", k, e2, c2)
+            assert e < 0.9 and c > 0.5, ("final", k, e, c)
+            assert e2 < 0.9 and c2 > 0.5, ("ema", k, e2, c2)
     print("update L2 error after N steps: median %.3f max %.3f; weight-level error: median %.2e max %.2e"
           % (np.median(errs), max(errs), np.median(werrs), max(werrs)))
-    assert np.median(errs) < 0.15            # fp32-vs-fp64 floor measured at 0.08
-    assert np.median(werrs) < 2e-2 and max(werrs) < 0.2   # relative to each tensor's own norm
+    assert np.median(errs) < NSTEP_UPDATE_MEDIAN
+    assert np.median(werrs) < NSTEP_WEIGHT_MEDIAN and max(werrs) < NSTEP_WEIGHT_MAX   # relative to each tensor's own norm
+
+
+def test_overfit_curve_first_steps_match_reference():
+    """tests/golden/overfit_tiny.npz (120 reference steps on one fixed CT-like batch, loss 1.005 -> 0.044): the oracle follows
+    the reference's curve (first 25 steps here; the GPU tests run all 120): to 1e-3 over the first 5 steps, then -- the hard-patch
+    set of the sampler flips with 1e-7 differences of the teacher's loss and the trajectories decorrelate -- to 6 %."""
+    ov, f = load("overfit_tiny.npz"), load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    st = O.StepState(cfg, fixture_weights(cfg, f))
+    ep, tot = (int(v) for v in ov["epoch"])
+    x = np_volume(int(f["B"]), cfg.input_size, ov["x_seed"])
+    assert ov["losses"][-10:].mean() < 0.06 and ov["losses"][0] > 1.0          # the reference itself learns on this batch
+    for s in range(25):
+        o = O.train_step(st, x, torch.from_numpy(ov["mask1"][s]), torch.from_numpy(ov["keys"][s]), ep, tot, float(ov["lr"]),
+                         float(ov["ema_decay"]))
+        assert abs(o["loss"] / ov["losses"][s] - 1) < (1e-3 if s < 5 else 6e-2), (s, o["loss"], ov["losses"][s])
+
+
+def test_bf16_storage_emulation_is_identity_in_fp32_mode_and_close_in_bf16(fwd, setup):
+    """oracle.storage("bf16") (tolerance derivation for the bf16 HIP tests): off by default (the pinned fp32 results above are
+    unaffected), and under it the loss moves by < 1e-3 while gradients degrade to the documented bf16-storage floor."""
+    cfg, W, x, mask = setup
+    l0, _, g0, _ = O.student_loss_and_grads(cfg, W, x, mask)
+    with O.storage("bf16"):
+        l1, _, g1, _ = O.student_loss_and_grads(cfg, W, x, mask)
+    l2, _, g2, _ = O.student_loss_and_grads(cfg, W, x, mask)
+    assert float(l0) == float(l2) and all(torch.equal(g0[k], g2[k]) for k in g0 if g0[k] is not None)
+    assert abs(float(l1) - float(l0)) < 1e-3 * float(l0)
+    e = grad_errors({k: v for k, v in g1.items() if v is not None}, fwd)
+    med = np.median([v[0] for v in e.values() if v[1] is not None])
+    assert 0.02 < med < 0.6, med

@@ -1,5 +1,7 @@
-"""Interleaved A/B of environment knobs on the full step in ONE process (robust to noisy neighbours on the GPU):
-usage: python tools/step_ab.py KNOB=v1,v2,... [batch]   e.g. AM_WG_TARGET=1024,768,512"""
+"""Interleaved A/B of a knob on the full step in ONE process (robust to noisy neighbours on the GPU):
+usage: python tools/step_ab.py KNOB=v1,v2,... [batch]
+  KNOB = engine.<attr> flips a module attribute of anatomask_amd.engine (e.g. engine._USE_SIDE=1,0);
+  any other KNOB is set as an environment variable (only the -DAM_ABLATE tools build reads any)."""
 import os
 import sys
 import time
@@ -24,7 +26,11 @@ for _ in range(3):
 res = {v: [] for v in vals}
 for rep in range(4):
     for v in vals:
-        os.environ[knob] = v
+        if knob.startswith("engine."):
+            from anatomask_amd import engine
+            setattr(engine, knob[7:], type(getattr(engine, knob[7:]))(int(v)))
+        else:
+            os.environ[knob] = v
         tr.step(x, epoch=500)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
