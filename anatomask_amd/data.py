@@ -106,3 +106,61 @@ class PatchLoader3D:
         if self.pin and torch.cuda.is_available():
             d = d.pin_memory()
         return {"data": d, "seg": torch.from_numpy(np.ascontiguousarray(seg_all)), "properties": props, "keys": sel}
+
+
+class DeviceFeed:
+    """Host -> device hand-off of the batches (the reference's `inp.to(device, non_blocking=True)` on pinned batches,
+    P/pretrain_AntoMask.py:343-345,390-392), double-buffered: batch k+1 is copied on a dedicated HIP stream into the other
+    device slot while step k computes; `next(feed)` returns the device tensor of batch k after making the compute stream wait
+    for its copy event.  Un-pinned host batches are first copied into a persistent pinned staging buffer of the slot."""
+
+    def __init__(self, batches, device, key: str = "data", depth: int = 2):
+        self.it, self.dev, self.key, self.depth = iter(batches), device, key, depth
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.dbuf, self.pin, self.ready = [None] * depth, [None] * depth, [None] * depth
+        self.k = 0
+        self._start(0)
+
+    def _start(self, slot: int, after=None) -> bool:
+        try:
+            b = next(self.it)
+        except StopIteration:
+            self.ready[slot] = None
+            return False
+        h = b[self.key] if isinstance(b, dict) else b
+        if self.dbuf[slot] is None or self.dbuf[slot].shape != h.shape:
+            self.dbuf[slot] = torch.empty(h.shape, dtype=h.dtype, device=self.dev)
+        if not h.is_pinned():
+            if self.ready[slot] is not None:
+                self.ready[slot].synchronize()             # the previous copy out of this staging buffer has finished
+            if self.pin[slot] is None or self.pin[slot].shape != h.shape:
+                self.pin[slot] = torch.empty(h.shape, dtype=h.dtype).pin_memory()
+            self.pin[slot].copy_(h)
+            h = self.pin[slot]
+        with torch.cuda.stream(self.copy_stream):
+            if after is not None:
+                self.copy_stream.wait_event(after)         # the step that last read this device slot has been enqueued before `after`
+            self.dbuf[slot].copy_(h, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self.ready[slot] = ev
+        self._host_keepalive = h
+        return True
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> torch.Tensor:
+        slot = self.k % self.depth
+        if self.ready[slot] is None:
+            raise StopIteration
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.ready[slot])
+        out = self.dbuf[slot]
+        # start the next copy into the other slot: it may only overwrite that slot once every kernel enqueued so far (the steps
+        # that read it) has run -> an event recorded on the compute stream now
+        done = torch.cuda.Event()
+        done.record(cur)
+        self.k += 1
+        self._start(self.k % self.depth, after=done)
+        return out

@@ -41,9 +41,12 @@ class AnatoMaskTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self._works = []
-        if self.distributed:                      # DDP start-up broadcast (P/pretrain_AnatoMask_DDP.py:239-240)
+        if self.distributed:                      # DDP start-up broadcast of parameters AND buffers (P/pretrain_AnatoMask_DDP.py:239-240)
             dist.broadcast(model._flat, 0, group=process_group)
+            dist.broadcast(model._bflat, 0, group=process_group)
             self.teacher.ema._flat.copy_(model._flat)
+            self.teacher.ema._bflat.copy_(model._bflat)
+            model.weights_changed(); self.teacher.ema.weights_changed()   # packed MFMA copies made before the broadcast are stale
         self._build_ranges()
 
     def _build_ranges(self):
@@ -73,8 +76,12 @@ class AnatoMaskTrainer:
             return
         for w in self._works:
             w.wait()
-        self._works.clear()
-        self.model._gflat[:self.model._live_end].mul_(1.0 / self.world)
+        self._works.clear()                        # the buffer now holds the SUM over ranks; 1/world is folded into am_adamw_ema
+
+    @property
+    def grad_scale(self) -> float:
+        """what the flat gradient buffer must be multiplied by to be DDP's mean gradient (folded into am_adamw_ema)."""
+        return 1.0 / self.world
 
     # ------------------------------------------------------------------ one step
     @torch.no_grad()
@@ -126,7 +133,8 @@ class AnatoMaskTrainer:
         decay = self.teacher.decay if ema_decay is None else ema_decay
         ops.sumsq(m._gflat[:n], self.sumsq)
         ops.adamw_ema(m._flat, m._gflat, self.m, self.v, t._flat if self.self_distill else None, n, self.lr if lr is None else lr,
-                      self.betas, self.eps, self.wd, self.step_count, self.sumsq, self.clip, decay, self.gnorm)
+                      self.betas, self.eps, self.wd, self.step_count, self.sumsq, self.clip, decay, self.gnorm,
+                      grad_scale=self.grad_scale)
         if not self.self_distill:
             m.weights_changed()
             return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": None, "rec_loss": l2m}

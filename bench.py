@@ -2,12 +2,23 @@
 """Benchmark of the AnatoMask pretraining step on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+  N > 1 without a launcher: this process (which has not touched the GPU) starts
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same flags>
+  as a child, one rank per GPU, RCCL gradient all-reduce; under a launcher (RANK/WORLD_SIZE set) it is a rank.
 
 Workload (BASELINE.json configs[1]/[2]): STUNet-B AnatoMask, 128^3 patch, mask_ratio 0.6, bf16 storage /
 bf16 MFMA with fp32 accumulation, fp32 master weights + AdamW + EMA; one "step" = the full iteration of
 P/pretrain_AntoMask.py:418-441 (teacher fwd, sampler, student fwd, loss, bwd, clip, AdamW, EMA) on a batch
 of B synthetic N(0,1) volumes already resident in HBM.  value = volumes/s over all ranks (weak scaling).
+
+Extra fields of the JSON line (besides the driver's contract):
+  step_ms_median / step_ms_min      per-step durations from HIP events recorded after every step of the timed window
+  value_with_h2d                    the same K steps fed from pinned host memory through the double-buffered copy stream
+                                    (anatomask_amd.data.DeviceFeed; the reference's `inp.to(device, non_blocking=True)`): NOT `value`
+  exchange (N > 1)                  RCCL rank count, gradient bytes per step, step time with the exchange disabled, exposed ms
+  roofline                          dominant kernel (profiles/): isolated launch AND the same launch timed inside the step
+  encoder_fwd_hbm                   north-star figure: student sparse-encoder forward vs the 8 TB/s HBM peak
+  cpu_baseline                      the CPU oracle taking one B=1 step on the host cores (rank 0, N = 1 only)
 """
 import argparse
 import json
@@ -40,25 +51,58 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def dominant_kernel_roofline(B, dev):
-    """The dominant kernel of the step (profiles/: conv_igemm bf16 4x8x8 brick, 64 output channels) on its largest
-    instance: decoder level-3 conv 64->64 at 128^3 (P/decoder3D.py:20).  Bound: MFMA (AI ~ 1700 flop/B)."""
+def dominant_kernel_roofline(B, dev, tr, x):
+    """The dominant kernel of the step (profiles/: conv_igemm bf16, 4x4x16 brick, 64 output channels) on its largest
+    instance: decoder level-3 conv 64->64 at 128^3 (P/decoder3D.py:20).  Bound: MFMA (AI ~ 1700 flop/B).
+    `launch_ms`: the launch alone (20 back-to-back launches, HIP events); `launch_ms_in_step`: the SAME launch timed by HIP
+    events where it sits inside the training step (student decoder block 3, first conv), median over 3 steps."""
     from anatomask_amd import ops
     C = 64
-    x = torch.randn(B, 128, 128, 128, C, device=dev).to(torch.bfloat16)
+    xx = torch.randn(B, 128, 128, 128, C, device=dev).to(torch.bfloat16)
     w = (torch.randn(C, C, 3, 3, 3, device=dev) * 0.02)
     wp = ops.pack_weight(w, torch.bfloat16, False, False)
-    y = torch.empty_like(x)
-    t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (128, 128, 128), 3, 1, out=y))
+    y = torch.empty_like(xx)
+    t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, xx, wp, None, (128, 128, 128), 3, 1, out=y))
+    del xx, y
     flops = 2.0 * B * 128 ** 3 * C * C * 27
+    # the same launch inside the step: wrap ops.conv3d for three steps (events only, no synchronisation inside the step)
+    evs, orig = [], ops.conv3d
+
+    def timed_conv3d(mode, x_, w_packed, bias, out_spatial, ksize, stride, *a, **k):
+        hit = (mode == ops.CONV_FWD and ksize == 3 and stride == 1 and tuple(x_.shape[1:]) == (128, 128, 128, C)
+               and w_packed.logical == (C, C) and not k.get("ep_scale") is not None and k.get("want_partials"))
+        if not hit:
+            return orig(mode, x_, w_packed, bias, out_spatial, ksize, stride, *a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig(mode, x_, w_packed, bias, out_spatial, ksize, stride, *a, **k)
+        e1.record()
+        evs.append((e0, e1))
+        return r
+    in_step = None
+    if tr is not None:
+        from anatomask_amd import engine
+        ops.conv3d = timed_conv3d
+        try:
+            for _ in range(3):
+                tr.step(x, epoch=500)
+            torch.cuda.synchronize()
+        finally:
+            ops.conv3d = orig
+        if evs:
+            ds = sorted(a.elapsed_time(b) for a, b in evs)
+            in_step = ds[len(ds) // 2]
+        del engine
     achieved = flops / t / 1e12
     # HBM bytes per launch from the PMC counters of the SAME launch shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc_traffic.md, measured at B=2 -> linear in B
     traffic = (605.5e6 + 536.9e6) * B / 2
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4,11> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4,11,3,true> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
             "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, scaled from B=2)",
-            "algorithmic_bytes": (2 * 128 ** 3 * C * 2 * B) + 27 * C * C * 2, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops}
+            "algorithmic_bytes": (2 * 128 ** 3 * C * 2 * B) + 27 * C * C * 2, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops,
+            "launch_ms_in_step": None if in_step is None else round(in_step, 4),
+            "frac_in_step": None if in_step is None else round(flops / (in_step * 1e-3) / MFMA_BF16_PEAK, 4)}
 
 
 def encoder_forward_hbm(model, x, dev):
@@ -100,6 +144,45 @@ def cpu_baseline(state_dict_cpu, spec_kw):
             "sample": f"1 full step, B=1, STUNet-B 128^3 fp32, torch-CPU oracle, {dt:.1f} s, loss {o['loss']:.4f}"}
 
 
+def timed_window(step, steps, world, dist, dev):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (wall clock, MAX over ranks), with a HIP event
+    after every step for the per-step distribution."""
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    out = None
+    for i in range(steps):
+        out = step()
+        evs[i + 1].record()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    return dt, per, out
+
+
+def dry_run_launch(a):
+    """`--dry-run-launch` (CPU, gloo): proves the self-launch plumbing without a GPU -- every rank joins the group, the ranks
+    all-reduce their rank numbers and rank 0 prints one JSON line (tests/test_launch.py)."""
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": a.gpus, "world": world, "rank_sum": t.item(), "backend": "gloo"}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,21 +197,31 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true")
+    ap.add_argument("--dry-run-launch", action="store_true", help="CPU/gloo check of the N-rank self-launch (no GPU work)")
     a = ap.parse_args()
+
+    from anatomask_amd import launch
+    if a.gpus > 1 and not launch.launched():
+        # no launcher around us: become one.  Nothing in this process has touched the GPU (importing torch does not).
+        sys.exit(launch.self_launch(a.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if a.dry_run_launch:
+        return dry_run_launch(a)
 
     import torch.distributed as dist
     from anatomask_amd import modules as M
+    from anatomask_amd.data import DeviceFeed
     from anatomask_amd.trainer import AnatoMaskTrainer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
 
     kw = M.STUNET_CONFIGS[a.size]
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -143,20 +236,7 @@ def main():
 
     for _ in range(a.warmup):
         out = tr.step(x, epoch=500)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = tr.step(x, epoch=500)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt, per, out = timed_window(lambda: tr.step(x, epoch=500), a.steps, world, dist, dev)
     loss = out["loss"].item()
     assert loss == loss and abs(loss) < 1e6, f"non-finite loss {loss}"   # the reference's finite-loss guard (:443-446)
 
@@ -168,10 +248,35 @@ def main():
                "config": {"workload": f"STUNet-{a.size} AnatoMask step, {a.patch}^3 patch, mask_ratio {a.mask_ratio}, {a.dtype} storage/MFMA + fp32 master",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                           "step": "teacher fwd + sampler + student fwd + loss + bwd + clip + AdamW + EMA"},
-               "final_loss": round(loss, 5)}
-        if not a.no_roofline and a.size == "B" and a.patch == 128:
-            res["roofline"] = dominant_kernel_roofline(a.batch, dev)
-            res["encoder_fwd_hbm"] = encoder_forward_hbm(model, x, dev)
+               "final_loss": round(loss, 5), "step_ms_median": round(per[len(per) // 2], 3), "step_ms_min": round(per[0], 3)}
+
+    # ---- the same steps fed from pinned host memory through the copy stream (reported beside `value`, never as `value`)
+    if not a.no_h2d:
+        host = x.cpu().pin_memory()
+        feed = DeviceFeed(({"data": host} for _ in range(a.steps + 4)), dev)
+        for _ in range(2):
+            tr.step(next(feed), epoch=500)
+        dth, _, _ = timed_window(lambda: tr.step(next(feed), epoch=500), a.steps, world, dist, dev)
+        if rank == 0:
+            res["value_with_h2d"] = round(a.batch * world * a.steps / dth, 4)
+            res["h2d"] = {"bytes_per_step": host.numel() * 4, "how": "pinned host batch -> double-buffered device slots on a copy stream, overlapped with the previous step"}
+        del feed, host
+
+    # ---- exposed communication: the same window with the gradient exchange switched off (N > 1)
+    if world > 1:
+        tr.distributed = False
+        for _ in range(2):
+            tr.step(x, epoch=500)
+        dtn, _, _ = timed_window(lambda: tr.step(x, epoch=500), a.steps, world, dist, dev)
+        tr.distributed = True
+        if rank == 0:
+            res["exchange"] = {"backend": "rccl", "ranks": world, "gradient_bytes_per_step": int(model._live_end) * 4,
+                               "buckets": len(tr._ranges), "ms_per_step_without_exchange": round(dtn / a.steps * 1e3, 3),
+                               "exposed_ms": round((dt - dtn) / a.steps * 1e3, 3)}
+
+    if rank == 0 and not a.no_roofline and a.size == "B" and a.patch == 128 and a.dtype == "bf16":
+        res["roofline"] = dominant_kernel_roofline(a.batch, dev, tr if world == 1 else None, x)
+        res["encoder_fwd_hbm"] = encoder_forward_hbm(model, x, dev)
     if world > 1:
         dist.barrier()
     if rank == 0:

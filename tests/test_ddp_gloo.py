@@ -55,8 +55,10 @@ def _worker(rank, world, port, q):
         for tag in ["decoder", "densify"] + [f"stage{s}" for s in reversed(range(5))]:
             tr._after_group(tag)
         tr._finish_exchange()
+        # the buffer holds the SUM over ranks; DDP's 1/world is a factor of the fused optimizer kernel (am_adamw_ema grad_scale)
         want = sum(range(1, world + 1)) / world
-        assert torch.allclose(m._gflat[:m._live_end], torch.full((m._live_end,), want))
+        assert AnatoMaskTrainer.grad_scale.fget(tr) == 1.0 / world
+        assert torch.allclose(m._gflat[:m._live_end] * AnatoMaskTrainer.grad_scale.fget(tr), torch.full((m._live_end,), want))
         assert torch.all(m._gflat[m._live_end:] == 123.0)
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001

@@ -1,0 +1,34 @@
+"""CPU: `bench.py --gpus N` launches itself (no torchrun around it): the parent spawns N ranks through
+`python -m torch.distributed.run`, the ranks form a process group (gloo here, RCCL on the GPU box), and rank 0's JSON line
+comes back on stdout.  Ref: P/pretrain_AnatoMask_DDP.py:192-240 expects an external torchrun; the driver runs `python bench.py`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(180)
+def test_bench_self_launch_two_ranks_gloo():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-launch"], capture_output=True,
+                       text=True, timeout=170, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # ONE line, from rank 0
+    out = json.loads(lines[0])
+    assert out == {"dry_run": True, "n_gpus": 2, "world": 2, "rank_sum": 1.0, "backend": "gloo"}
+
+
+def test_launch_command_and_noop_under_a_launcher(monkeypatch):
+    from anatomask_amd import launch
+    cmd = launch.launch_command(4, "bench.py", ["--gpus", "4", "--steps", "3"], port=12345)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "4", "--steps", "3"]
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert not launch.launched()
+    monkeypatch.setenv("WORLD_SIZE", "4"); monkeypatch.setenv("RANK", "1")
+    assert launch.launched()                               # under torchrun bench.py is a rank, never a launcher
