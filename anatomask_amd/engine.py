@@ -214,19 +214,12 @@ def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, 
     return o, {"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2}
 
 
-def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
-            tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False, recompute: bool = False,
-            want_to_dec0: bool = False, needed_patches: Optional[MaskInfo] = None):
-    """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps).
-    recompute=True is the P/GC.py policy (torch.utils.checkpoint per encoder stage :324 and per decoder block :68): the tape
-    keeps only stage / block INPUTS; backward re-runs that stage's forward before differentiating it."""
-    counts = _counts(mask, range(5))
-    if tape is not None:
-        tape.counts = counts
-        tape.recompute = recompute
+def encoder_forward(spec: Spec, W, pk: PackCache, inp: torch.Tensor, mask: MaskInfo, counts, tape: Optional[Tape] = None,
+                    recompute: bool = False) -> List[torch.Tensor]:
+    """STUNet.forward(hierarchical=True) under SparseEncoder (P/STUNet_head.py:67-76, P/encoder3D.py:366-367): the 5 stage
+    output maps, channels-last, block-sparse (only voxels of active patches are defined)."""
     feats = []
     x = None
-    # ------------------------------------------------------------------ sparse encoder
     for s in range(spec.n_stage):
         sp = spec.stage_spatial(s)
         if tape is not None and recompute:
@@ -236,9 +229,11 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
             if tape is not None and not recompute:
                 tape.enc.append(rec_)
         feats.append(x)
-    if encoder_only:
-        return feats
-    # ------------------------------------------------------------------ densify (level 4 is dead: P/decoder3D.py:57-60)
+    return feats
+
+
+def densify_forward(spec: Spec, W, pk: PackCache, feats, mask: MaskInfo, counts, tape: Optional[Tape] = None) -> List[torch.Tensor]:
+    """P/AnatoMask.py:158-168: norm -> mask-token fill -> projection per level, coarse -> fine (level 4 is dead: P/decoder3D.py:57-60)."""
     n_dec = len(spec.dec_chs) - 1
     to_dec = []
     for i in range(n_dec):
@@ -254,11 +249,19 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
         to_dec.append(pr)
         if tape is not None:
             tape.dens.append({"i": i, "f": f, "st": st, "d": d, "k": W[pw].shape[-1] if pw in W else 0})
-    # ------------------------------------------------------------------ dense decoder
+    return to_dec
+
+
+def decoder_forward(spec: Spec, W, pk: PackCache, to_dec, train: bool, tape: Optional[Tape] = None, recompute: bool = False,
+                    needed_patches: Optional[MaskInfo] = None, fuse_eval: Optional[bool] = None) -> torch.Tensor:
+    """LightDecoder.forward (P/decoder3D.py:55-63): x = 0; per block x += to_dec[i]; UNetBlock; 1x1 proj -> rec fp32 [B,D,H,W]."""
+    n_dec = len(spec.dec_chs) - 1
+    if fuse_eval is None:
+        fuse_eval = tape is None
     x = to_dec[0]
     for i in range(n_dec):
         nxt = to_dec[i + 1] if i + 1 < n_dec else None
-        o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=tape is None,
+        o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=fuse_eval,
                              out_skip=needed_patches if (i == n_dec - 1 and tape is None and not train) else None)
         if tape is not None:
             tape.dec.append({"q": rec_["q"], "xin": x, "nxt": nxt} if recompute else rec_)
@@ -266,6 +269,24 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
     rec = ops.proj_fwd(x, W["dense_decoder.proj.weight"].view(-1), W["dense_decoder.proj.bias"])
     if tape is not None:
         tape.last = x
+    return rec
+
+
+def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
+            tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False, recompute: bool = False,
+            want_to_dec0: bool = False, needed_patches: Optional[MaskInfo] = None):
+    """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps).
+    recompute=True is the P/GC.py policy (torch.utils.checkpoint per encoder stage :324 and per decoder block :68): the tape
+    keeps only stage / block INPUTS; backward re-runs that stage's forward before differentiating it."""
+    counts = _counts(mask, range(5))
+    if tape is not None:
+        tape.counts = counts
+        tape.recompute = recompute
+    feats = encoder_forward(spec, W, pk, inp, mask, counts, tape, recompute)
+    if encoder_only:
+        return feats
+    to_dec = densify_forward(spec, W, pk, feats, mask, counts, tape)
+    rec = decoder_forward(spec, W, pk, to_dec, train, tape, recompute, needed_patches)
     if want_to_dec0:                         # coarsest densified map, channels-last (SparK.forward(return_feat=True), P/AnatoMask.py:172-173)
         return rec, to_dec[0]
     return (rec, feats) if want_feats else rec
@@ -314,11 +335,9 @@ def _wgrad_into(G, name, mode, x, dy, k, stride, transposed=False, **masks):
     _on_side(x.device, (x, dy), run)
 
 
-def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo,
-             tape: Tape, drec: torch.Tensor, after_group=None):
-    """Accumulates parameter gradients into G (fp32, torch layout).  `after_group(tag)` is called when
-    all gradients of a parameter group ('decoder', 'densify', 'stage{s}') are final (DDP overlap hook)."""
-    counts = tape.counts
+def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Tensor) -> List[Optional[torch.Tensor]]:
+    """backward of decoder_forward: accumulates the decoder's parameter gradients into G, returns dproj[i] = gradient wrt
+    to_dec[i].  (densify_projs[i].bias for i >= 1 -- the per-channel sum of dproj[i] -- is folded into the ConvT-dgrad epilogue.)"""
     n_dec = len(spec.dec_chs) - 1
     # ---- projection
     g = ops.proj_bwd(tape.last, drec, W["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.weight"].view(-1),
@@ -344,17 +363,19 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
         ptu.reduce(sum_accum=G[f"{q}.up_sample.bias"])           # ConvT bias gradient = per-channel sum of du
         _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
         si = tuple(t["xin"].shape[1:4])
-        need_sum = i > 0 and tape.dens[i]["k"]                     # densify_projs[i].bias gradient = sum of this tensor
+        need_sum = i > 0 and f"densify_projs.{i}.bias" in G        # densify_projs[i].bias gradient = sum of this tensor
         g = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2, want_partials=bool(need_sum))
         if need_sum:
             g, ptg = g
             ptg.reduce(sum_accum=G[f"densify_projs.{i}.bias"])
         _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
     dproj[0] = g
-    if after_group:
-        _join_side(drec.device)
-        after_group("decoder")
-    # ---- densify: grads wrt the encoder feature maps (active voxels only)
+    return dproj
+
+
+def densify_backward(spec: Spec, W, G, pk: PackCache, mask: MaskInfo, tape: Tape, dproj) -> List[Optional[torch.Tensor]]:
+    """backward of densify_forward: returns dfeat[s] = gradient wrt the stage-s encoder map (active voxels only; None for s = 0)."""
+    n_dec = len(spec.dec_chs) - 1
     dfeat: List[Optional[torch.Tensor]] = [None] * spec.n_stage
     for i in range(n_dec):
         t = tape.dens[i]
@@ -370,10 +391,13 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
         dfeat[4 - i] = ops.norm_backward(dd, None, t["f"], t["st"], W[f"densify_norms.{i}.weight"], ACT_NONE, mask, i,
                                          G[f"densify_norms.{i}.weight"], G[f"densify_norms.{i}.bias"],
                                          dtoken=G[f"mask_tokens.{i}"].view(-1), fill=True)
-    if after_group:
-        _join_side(drec.device)
-        after_group("densify")
-    # ---- encoder, deep -> shallow.  gstage[s] = gradient wrt the stage-s output map (active voxels only)
+    return dfeat
+
+
+def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: MaskInfo, tape: Tape, dfeat, after_group=None):
+    """backward of encoder_forward, deep -> shallow.  dfeat[s] = gradient wrt the stage-s output map (active voxels only), or
+    None (the stage-0 map feeds only stage 1 on the SparK path: its densify branch is dead)."""
+    counts = tape.counts
     gstage: List[Optional[torch.Tensor]] = list(dfeat)
     by_stage: Dict[int, List[dict]] = {}
     for t in tape.enc:
@@ -387,7 +411,8 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
                 recs.append(r_)
             by_stage[s] = recs
         gout = gstage[s]
-        assert gout is not None
+        if gout is None:                          # (stand-alone SparseEncoder.forward: the caller used only some of the maps)
+            gout = torch.zeros_like(by_stage[s][-1]["out"])
         for t in reversed(by_stage[s]):
             p = t["p"]
             y2, a1, y1, out, x = t["y2"], t["a1"], t["y1"], t["out"], t["x"]
@@ -426,6 +451,21 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
                                 in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
                 gout = ops.add(gx, dpre, out=gx)
         if after_group:
-            _join_side(drec.device)
+            _join_side(inp.device)
             after_group(f"stage{s}")
-    _join_side(drec.device)
+    _join_side(inp.device)
+
+
+def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo,
+             tape: Tape, drec: torch.Tensor, after_group=None):
+    """Accumulates parameter gradients into G (fp32, torch layout).  `after_group(tag)` is called when
+    all gradients of a parameter group ('decoder', 'densify', 'stage{s}') are final (DDP overlap hook)."""
+    dproj = decoder_backward(spec, W, G, pk, tape, drec)
+    if after_group:
+        _join_side(drec.device)
+        after_group("decoder")
+    dfeat = densify_backward(spec, W, G, pk, mask, tape, dproj)
+    if after_group:
+        _join_side(drec.device)
+        after_group("densify")
+    encoder_backward(spec, W, G, pk, inp, mask, tape, dfeat, after_group)

@@ -33,6 +33,103 @@ def _trunc_normal_(t, std=.02, a=-2., b=2.):
     return nn.init.trunc_normal_(t, mean=0., std=std, a=a, b=b)
 
 
+# The reference's side channel (P/encoder3D.py:5, set by SparK.forward at P/AnatoMask.py:143, read by every Sparse* layer):
+# the patch mask (B,1,f,f,f) bool the sparse encoder works under.  Kept with the same name and the same protocol so that code
+# calling `model.sparse_encoder(masked)` / `sp_cnn(x, hierarchical=True)` directly (as the reference's users do) keeps working:
+# set `modules._cur_active = mask` first.  None = everything active (dense).
+_cur_active: Optional[torch.Tensor] = None
+
+
+def _to_channels_last(t_ncdhw: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    return t_ncdhw.permute(0, 2, 3, 4, 1).to(dtype).contiguous()
+
+
+class _Standalone:
+    """Engine context (weights dict, packed-weight cache, gradient dict) of a module used OUTSIDE a SparK (stand-alone
+    SparseEncoder / STUNet / LightDecoder): plain views of the module's own torch-layout fp32 parameters."""
+
+    def __init__(self, module: nn.Module, prefix: str, dtype: torch.dtype):
+        self.module, self.prefix, self.dtype = module, prefix, dtype
+        self.pack = engine.PackCache(dtype)
+        self.ptrs = None
+
+    def weights(self) -> Dict[str, torch.Tensor]:
+        W = {self.prefix + n: p.data for n, p in self.module.named_parameters()}
+        W.update({self.prefix + n: b for n, b in self.module.named_buffers()})
+        ptrs = tuple(v.data_ptr() for v in W.values())
+        if ptrs != self.ptrs:
+            self.pack = engine.PackCache(self.dtype)
+            self.ptrs = ptrs
+        else:
+            self.pack.invalidate()                    # the fp32 masters may have been stepped by an optimizer since the last call
+        return W
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return {self.prefix + n: torch.zeros_like(p.data, dtype=torch.float32) for n, p in self.module.named_parameters()}
+
+
+class _EncoderFn(torch.autograd.Function):
+    """feats = SparseEncoder(x | _cur_active): the 5 stage maps (NCDHW fp32 views, exact zeros at inactive voxels)."""
+
+    @staticmethod
+    def forward(ctx, enc: "SparseEncoder", x_b1, mask_info, *params):
+        spec, W, pk, G = enc._engine_ctx()
+        need_grad = any(ctx.needs_input_grad[3:])
+        tape = engine.Tape() if need_grad else None
+        counts = engine._counts(mask_info, range(5))
+        if tape is not None:
+            tape.counts = counts
+        feats = engine.encoder_forward(spec, W, pk, x_b1, mask_info, counts, tape)
+        ctx.enc, ctx.tape, ctx.inp, ctx.mask = enc, tape, x_b1, mask_info
+        outs = []
+        for s, f in enumerate(feats):                   # dense view of the block-sparse map: zeros where the reference has zeros
+            ident = ops.NormStats(f.shape[-1], f.device)
+            ident.scale.fill_(1.0); ident.shift.zero_()
+            zero = torch.zeros(f.shape[-1], device=f.device)
+            d = ops.norm_apply(f, ident, ops.ACT_NONE, mask_info, 4 - s, fill=zero)
+            outs.append(d.permute(0, 4, 1, 2, 3).float())
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        enc = ctx.enc
+        if ctx.tape is None:
+            raise RuntimeError("backward through a no-grad SparseEncoder forward")
+        spec, W, pk, G = enc._engine_ctx(want_grads=True)
+        dt = pk.dtype
+        dfeat = [None if g is None else _to_channels_last(g, dt) for g in gouts]
+        engine.encoder_backward(spec, W, G, pk, ctx.inp, ctx.mask, ctx.tape, dfeat)
+        ctx.tape = None
+        return (None, None, None, *[G.get(n) for n in enc._param_names()])
+
+
+class _DecoderFn(torch.autograd.Function):
+    """rec = LightDecoder(to_dec): P/decoder3D.py:55-63 on the engine; differentiable wrt the decoder parameters AND to_dec[i]."""
+
+    @staticmethod
+    def forward(ctx, dec: "LightDecoder", n_in: int, *args):
+        to_dec_ncdhw, params = args[:n_in], args[n_in:]
+        spec, W, pk, G = dec._engine_ctx()
+        need_grad = any(ctx.needs_input_grad[2:])
+        tape = engine.Tape() if need_grad else None
+        to_dec = [_to_channels_last(t, pk.dtype) for t in to_dec_ncdhw]
+        rec = engine.decoder_forward(spec, W, pk, to_dec, dec.training, tape, fuse_eval=False if need_grad else None)
+        ctx.dec, ctx.tape, ctx.n_in = dec, tape, n_in
+        return rec.unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, drec):
+        dec = ctx.dec
+        if ctx.tape is None:
+            raise RuntimeError("backward through a no-grad LightDecoder forward")
+        spec, W, pk, G = dec._engine_ctx(want_grads=True)
+        dproj = engine.decoder_backward(spec, W, G, pk, ctx.tape, drec[:, 0].float().contiguous())
+        engine._join_side(drec.device)
+        ctx.tape = None
+        gin = [g.permute(0, 4, 1, 2, 3).float() for g in dproj]
+        return (None, None, *gin, *[G.get(n) for n in dec._param_names()])
+
+
 # --------------------------------------------------------------------------- backbone
 class BasicResBlock(nn.Module):
     """conv3-IN-LReLU-conv3-IN (+1x1 shortcut) -add-LReLU, P/STUNet_head.py:78-103 (parameters only)."""
@@ -90,9 +187,41 @@ class STUNet(nn.Module):
     def get_feature_map_channels(self):
         return self.dims[:5]
 
+    compute_dtype = torch.float32
+
+    def _engine_ctx(self, want_grads=False):
+        owner = self.__dict__.get("_owner")
+        owner = owner() if owner is not None else None
+        size = tuple(self.__dict__["_input_size"])
+        if owner is not None:                          # inside a SparK: its flat fp32 masters and packed MFMA copies
+            owner._ensure_flat()
+            spec = Spec(self.dims, self.depth, owner.spec.width, size)
+            G = {n: torch.zeros_like(owner._W[n]) for n in self._param_names()} if want_grads else None
+            return spec, owner._W, owner._pack, G
+        sa = self.__dict__.setdefault("_sa", _Standalone(self, "sparse_encoder.sp_cnn.", self.compute_dtype))
+        sa.dtype = self.compute_dtype
+        return Spec(self.dims, self.depth, 16 * 8, size), sa.weights(), sa.pack, (sa.grads() if want_grads else None)
+
+    def _param_names(self):
+        return ["sparse_encoder.sp_cnn." + n for n, _ in self.named_parameters()]
+
     def forward(self, x, hierarchical=False):
-        raise RuntimeError("STUNet is driven through SparseEncoder/SparK on the HIP engine (masked pretraining path); "
-                           "the dense supervised forward is out of scope of this package")
+        """P/STUNet_head.py:67-76 under the Sparse* layers of P/encoder3D.py: x (B,1,H,W,D) is the MASKED input, the patch mask
+        comes from the side channel `modules._cur_active` (None: dense).  Returns the 5 stage maps (hierarchical) or the last."""
+        if x.device.type != "cuda":
+            raise RuntimeError("STUNet runs on the HIP engine: move the model and the input to a cuda (ROCm) device first")
+        B = x.shape[0]
+        size = tuple(x.shape[2:])
+        self.__dict__["_input_size"] = size
+        act = _cur_active
+        if act is None:
+            act = torch.ones(B, 1, *(v // 16 for v in size), dtype=torch.bool, device=x.device)
+        if any(v % 16 for v in size) or tuple(act.shape) != (B, 1, *(v // 16 for v in size)):
+            raise RuntimeError(f"input {tuple(x.shape)} does not match the patch mask {tuple(act.shape)} (16^3 patches)")
+        mi = ops.MaskInfo.from_bool(act, x.device)
+        params = [p for _, p in self.named_parameters()]
+        feats = _EncoderFn.apply(self, x[:, 0].float().contiguous(), mi, *params)
+        return list(feats) if hierarchical else feats[-1]
 
 
 class SparseEncoder(nn.Module):
@@ -109,7 +238,8 @@ class SparseEncoder(nn.Module):
         return m
 
     def forward(self, x):
-        raise RuntimeError("call SparK.forward / SparK.encode: the encoder runs inside the fused HIP forward")
+        """P/encoder3D.py:366-367: `self.sp_cnn(x, hierarchical=True)` -> the 5 feature maps (fine -> coarse)."""
+        return self.sp_cnn(x, hierarchical=True)
 
 
 # --------------------------------------------------------------------------- decoder
@@ -157,8 +287,36 @@ class LightDecoder(nn.Module):
                 nn.init.constant_(m.bias, 0)
                 nn.init.constant_(m.weight, 1.0)
 
+    compute_dtype = torch.float32
+
+    def _engine_ctx(self, want_grads=False):
+        owner = self.__dict__.get("_owner")
+        owner = owner() if owner is not None else None
+        chans = [self.width // 2 ** i for i in range(len(self.dec) + 1)]
+        if owner is not None:
+            owner._ensure_flat()
+            G = {n: torch.zeros_like(owner._W[n]) for n in self._param_names()} if want_grads else None
+            return owner.spec, owner._W, owner._pack, G
+        sa = self.__dict__.setdefault("_sa", _Standalone(self, "dense_decoder.", self.compute_dtype))
+        sa.dtype = self.compute_dtype
+        spec = Spec([8, 16, 32, 64, 128, 128], [1] * 6, self.width, (16, 16, 16))
+        assert spec.dec_chs == chans
+        return spec, sa.weights(), sa.pack, (sa.grads() if want_grads else None)
+
+    def _param_names(self):
+        return ["dense_decoder." + n for n, _ in self.named_parameters()]
+
     def forward(self, to_dec):
-        raise RuntimeError("LightDecoder runs inside SparK.forward on the HIP engine")
+        """P/decoder3D.py:55-63.  to_dec: list of (B,C_i,D_i,H_i,W_i) maps, coarse -> fine (entries past the 4 blocks are ignored,
+        as in the reference; None entries are not supported).  Returns (B,1,D,H,W) fp32."""
+        n = len(self.dec)
+        use = list(to_dec[:n])
+        if len(use) < n or any(t is None for t in use):
+            raise NotImplementedError("LightDecoder.forward needs one map per UNetBlock (the SparK path always provides them)")
+        if use[0].device.type != "cuda":
+            raise RuntimeError("LightDecoder runs on the HIP engine: move the model and the inputs to a cuda (ROCm) device first")
+        params = [p for _, p in self.named_parameters()]
+        return _DecoderFn.apply(self, n, *use, *params)
 
 
 class SparseInstanceNorm(nn.Module):
@@ -256,6 +414,8 @@ class SparK(nn.Module):
         cnn = sparse_encoder.sp_cnn
         self.spec = Spec(cnn.dims, cnn.depth, dense_decoder.width, tuple(input_size))
         self.compute_dtype = compute_dtype
+        import weakref                       # sub-modules called on their own (model.sparse_encoder(x), model.dense_decoder(to_dec))
+        cnn.__dict__["_owner"] = dense_decoder.__dict__["_owner"] = weakref.ref(self)   # run on THIS model's flat buffers
         self._flat: Optional[torch.Tensor] = None
         self._after_group = None
         n_dec = len(self.spec.dec_chs) - 1
@@ -354,6 +514,8 @@ class SparK(nn.Module):
     def forward(self, inp_bchwd: torch.Tensor, active_b1ff=None, vis=False, return_feat=False):
         if active_b1ff is None:
             active_b1ff = self.mask(inp_bchwd.shape[0], inp_bchwd.device)
+        global _cur_active
+        _cur_active = active_b1ff                                  # P/AnatoMask.py:143 (kept for code that reads the side channel)
         rec_bchwd = self.reconstruct(inp_bchwd, active_b1ff)
         inp, rec = self.patchify(inp_bchwd), self.patchify(rec_bchwd)
         if return_feat:                                            # P/AnatoMask.py:172-173: to_dec[0].flatten(2).permute(0, 2, 1)
@@ -433,6 +595,10 @@ class SparK(nn.Module):
             b_new.data = b_old.data.clone()
         self._flat = flat
         self.__dict__.update(saved)
+        import weakref                       # the copy's sub-modules belong to the copy
+        new.sparse_encoder.sp_cnn.__dict__["_owner"] = new.dense_decoder.__dict__["_owner"] = weakref.ref(new)
+        for mod in (new.sparse_encoder.sp_cnn, new.dense_decoder):
+            mod.__dict__.pop("_sa", None)
         return new
 
 

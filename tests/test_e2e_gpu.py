@@ -241,10 +241,21 @@ def test_bf16_gradients_no_worse_than_ideal_bf16_storage(fwd):
     assert abs(gh - float(np.linalg.norm(fwd["grad_norms"][fwd["grad_norms"] > 0]))) < 0.1 * gh
 
 
+def _nstep_update_errors(state, W0, r):
+    errs, werrs = [], []
+    for k in [str(n) for n in r["names"]]:
+        if "finaldelta::" + k not in r or _zero_grad_bias(k) or np.linalg.norm(r["finaldelta::" + k]) < 1e-9:
+            continue
+        e, _ = delta_metrics(state[k] - W0[k], r["finaldelta::" + k])
+        errs.append(e)
+        werrs.append(float((state[k] - W0[k]).norm()) * e / (float(W0[k].norm()) + 1e-30))
+    return np.median(errs), max(errs), np.median(werrs), max(werrs)
+
+
 def test_trainer_n_steps_bf16_tracks_reference():
-    """N teacher-forced steps in bf16 storage: loss trajectory within 2e-3 of the reference at every step, grad-norm within 15 %,
-    and the N-step weight update no further from the reference's than twice the fp32 N-step bound (itself the reference's
-    fp32-vs-fp64 chaos floor, tests/test_oracle_golden.py)."""
+    """N teacher-forced steps in bf16 storage vs the reference's fp32 run: loss within 2e-3 at every step, grad-norm within 15 %,
+    and the N-step weight update no further from the reference's than 1.3x (median) / 1.5x (max) what the IDEAL bf16-storage
+    evaluation of the same N steps (CPU oracle under storage("bf16"), run here) shows -- measured: HIP 0.66 / ideal 0.70 median."""
     r, f = load("train_tiny.npz"), load("forward_tiny.npz")
     cfg, W0, m, tr, out, _ = _run_trainer(torch.bfloat16, r, f, teacher_force_student_mask=True)
     for s, o in enumerate(out):
@@ -253,16 +264,17 @@ def test_trainer_n_steps_bf16_tracks_reference():
         assert abs(o["grad_norm"].item() / r["grad_norms"][s] - 1) < 0.15, (s, o["grad_norm"].item(), r["grad_norms"][s])
     fsd = {k: v.float().cpu() for k, v in m.state_dict().items()}
     assert all(torch.isfinite(v).all() for v in fsd.values())
-    errs, werrs = [], []
-    for k in [str(n) for n in r["names"]]:
-        if "finaldelta::" + k not in r or _zero_grad_bias(k) or np.linalg.norm(r["finaldelta::" + k]) < 1e-9:
-            continue
-        e, c = delta_metrics(fsd[k] - W0[k], r["finaldelta::" + k])
-        errs.append(e)
-        werrs.append(float((fsd[k] - W0[k]).norm()) * e / (float(W0[k].norm()) + 1e-30))
-    print("HIP bf16 vs reference, update L2 error after N steps: median %.3f max %.3f; weight-level median %.2e max %.2e"
-          % (np.median(errs), max(errs), np.median(werrs), max(werrs)))
-    assert np.median(errs) < 2 * NSTEP_UPDATE_MEDIAN and np.median(werrs) < 2 * NSTEP_WEIGHT_MEDIAN and max(werrs) < 2 * NSTEP_WEIGHT_MAX
+    ep, tot = (int(v) for v in r["epoch"])
+    st = O.StepState(cfg, W0)
+    with O.storage("bf16"):
+        for s in range(int(r["N"])):
+            keys = torch.from_numpy(1.0 - r["mask"][s].reshape(r["keys"][s].shape).astype(np.float32))
+            O.train_step(st, np_volume(int(f["B"]), cfg.input_size, r["x_seeds"][s]), torch.from_numpy(r["mask1"][s]), keys, ep, tot,
+                         float(r["lr"]), float(r["ema_decay"]))
+    h, e = _nstep_update_errors(fsd, W0, r), _nstep_update_errors(st.student, W0, r)
+    print("bf16 N-step update error vs reference (median, max, weight-level median, max): HIP %.3f %.3f %.2e %.2e | ideal bf16-storage %.3f %.3f %.2e %.2e"
+          % (*h, *e))
+    assert h[0] < 1.3 * e[0] and h[1] < 1.5 * e[1] and h[2] < 1.3 * e[2] and h[3] < 1.5 * e[3], (h, e)
 
 
 @pytest.mark.parametrize("dtype,track,final", [(torch.float32, 2e-3, 0.1), (torch.bfloat16, 2e-2, 0.12)])
@@ -376,7 +388,8 @@ def test_depth2_blocks_identity_shortcut_vs_oracle():
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         dev_ = abs(float(a.norm() / b.norm()) - 1)
         big = a.numel() >= 256
-        assert cos > GRAD_COS_MIN and dev_ < GRAD_RTOL, (k, cos, float(a.norm()), float(b.norm()))
+        # 12 residual blocks: the reference's own fp32-vs-fp64 floor on this net is cos 0.99987, norm 7.7e-3, rel 1.6e-2
+        assert cos > 0.999 and dev_ < 2 * GRAD_RTOL, (k, cos, float(a.norm()), float(b.norm()))
         if big:
             n_big += 1
             n_tight += dev_ < GRAD_RTOL
@@ -542,3 +555,107 @@ def test_two_ranks_on_one_gpu_stay_in_sync():
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("weights identical across ranks: True; teacher identical: True") == 2, r.stdout[-2000:]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# L2 / L3 boundary: the sub-modules called on their own, as the reference's users call them
+# ------------------------------------------------------------------------------------------------------------------------
+def test_sparse_encoder_forward_matches_reference_fixture(fwd):
+    """`model.sparse_encoder(masked)` with the side channel `_cur_active` set first -- exactly how tests/golden/make_fixtures.py
+    drives the REFERENCE's SparseEncoder (P/encoder3D.py:5,366-367, P/STUNet_head.py:67-76) -- against the enc{i} fixtures;
+    plus autograd through the stand-alone encoder against the CPU oracle."""
+    from anatomask_amd import modules as M
+    cfg = tiny_cfg(fwd)
+    W = fixture_weights(cfg, fwd)
+    x = np_volume(int(fwd["B"]), cfg.input_size, fwd["x_seed"])
+    mask = torch.from_numpy(fwd["fwd_mask"])
+    act = O.upsample_mask(mask, x.shape[2:])
+    m = make_model(cfg, W).train()
+    M._cur_active = mask.to(DEV)
+    masked = (x * act.float()).to(DEV)
+    feats = m.sparse_encoder(masked)
+    assert isinstance(feats, list) and len(feats) == 5
+    for i, f in enumerate(feats):
+        assert tuple(f.shape) == (x.shape[0], cfg.dims[i], *(v >> i for v in cfg.input_size)) and f.dtype == torch.float32
+        fc = f.detach().cpu()
+        assert_checks(fc, fwd[f"enc{i}_checks"], 2e-4, f"enc{i}")
+        assert rel_err(sample(fc), fwd[f"enc{i}_sample"]) < 2e-4
+        assert float(fc[~O.upsample_mask(mask, fc.shape[2:]).expand_as(fc)].abs().max()) == 0.0      # exact zeros where the reference has zeros
+    last = m.sparse_encoder.sp_cnn(masked, hierarchical=False)                # P/STUNet_head.py:75-76
+    assert torch.equal(last, feats[-1])
+    # gradients of a loss on the five maps, wrt every encoder parameter
+    wts = [1.0, 0.5, 2.0, 1.5, 3.0]
+    loss = sum(w_ * (f ** 2).mean() for w_, f in zip(wts, feats))
+    loss.backward()
+    keys = [k for k in O.trainable_keys(cfg) if k.startswith(O.ENC)]
+    leaves = {k: W[k].clone().requires_grad_(True) for k in keys}
+    p = dict(W); p.update(leaves)
+    fo = O.encoder_forward(cfg, p, x * act.float(), mask)
+    lo = sum(w_ * (f ** 2).mean() for w_, f in zip(wts, fo))
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 2e-4 * abs(lo.item())
+    got = dict(m.named_parameters())
+    for k in keys:
+        a, b = got[k].grad.detach().cpu().double().flatten(), leaves[k].grad.double().flatten()
+        if float(b.norm()) < 1e-9:
+            continue
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.9995 and float((a - b).norm() / b.norm()) < 3e-2, (k, cos, float(a.norm()), float(b.norm()))
+    assert all(q.grad is None for k, q in got.items() if not k.startswith(O.ENC))      # nothing outside the encoder was touched
+    M._cur_active = None
+
+
+def test_light_decoder_forward_and_grads_vs_oracle(fwd):
+    """`model.dense_decoder(to_dec)` (P/decoder3D.py:55-63) on the engine: output, BN buffer update, gradients wrt the decoder
+    parameters and wrt every to_dec[i], against the CPU oracle; a 5th list entry is ignored as in the reference."""
+    cfg = tiny_cfg(fwd)
+    W = fixture_weights(cfg, fwd)
+    m = make_model(cfg, W).train()
+    B = 2
+    rs = np.random.RandomState(3)
+    sizes = [tuple(v // 16 * 2 ** i for v in cfg.input_size) for i in range(5)]
+    to_dec_cpu = [torch.from_numpy(rs.standard_normal((B, cfg.dec_chs[i] if i < 4 else 8, *sizes[i])).astype(np.float32)) for i in range(5)]
+    to_dec = [t.to(DEV).requires_grad_(True) for t in to_dec_cpu]
+    rec = m.dense_decoder(to_dec)
+    assert tuple(rec.shape) == (B, 1, *cfg.input_size)
+    (rec ** 2).mean().backward()
+    keys = [k for k in O.trainable_keys(cfg) if k.startswith("dense_decoder")]
+    leaves = {k: W[k].clone().requires_grad_(True) for k in keys}
+    p = dict(W); p.update(leaves)
+    tin = [t.clone().requires_grad_(True) for t in to_dec_cpu[:4]]
+    nb = {}
+    ro = O.decoder_forward(cfg, p, tin, True, nb)
+    (ro ** 2).mean().backward()
+    assert rel_err(rec.detach().cpu().numpy(), ro.detach().numpy()) < 2e-4
+    for k, v in nb.items():
+        np.testing.assert_allclose(m.state_dict()[k].cpu().numpy(), v.numpy(), rtol=1e-4, atol=1e-6)
+    got = dict(m.named_parameters())
+    for k in keys:
+        a, b = got[k].grad.detach().cpu().double().flatten(), leaves[k].grad.double().flatten()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos > 0.9995 and float((a - b).norm() / b.norm()) < 3e-2, (k, cos)
+    for i in range(4):
+        a, b = to_dec[i].grad.cpu().double().flatten(), tin[i].grad.double().flatten()
+        assert float((a - b).norm() / b.norm()) < 1e-2, i
+    assert to_dec[4].grad is None
+
+
+def test_standalone_encoder_outside_spark_matches(fwd):
+    """STUNet + SparseEncoder constructed on their own (no SparK around them): same maps as inside the model."""
+    from anatomask_amd import modules as M
+    cfg = tiny_cfg(fwd)
+    W = fixture_weights(cfg, fwd)
+    x = np_volume(2, cfg.input_size, 7)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(2))
+    masked = (x * O.upsample_mask(mask, x.shape[2:]).float()).to(DEV)
+    m = make_model(cfg, W).eval()
+    head = M.STUNet(1, 1, depth=cfg.depth, dims=cfg.dims)
+    enc = M.SparseEncoder(head, input_size=cfg.input_size, sbn=False)
+    enc.load_state_dict({k[len("sparse_encoder."):]: v for k, v in W.items() if k.startswith("sparse_encoder.")})
+    enc = enc.to(DEV)
+    M._cur_active = mask.to(DEV)
+    with torch.no_grad():
+        a, b = m.sparse_encoder(masked), enc(masked)
+    M._cur_active = None
+    for fa, fb in zip(a, b):
+        assert torch.equal(fa, fb)
