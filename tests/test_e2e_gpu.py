@@ -597,7 +597,7 @@ def test_sparse_encoder_forward_matches_reference_fixture(fwd):
     got = dict(m.named_parameters())
     for k in keys:
         a, b = got[k].grad.detach().cpu().double().flatten(), leaves[k].grad.double().flatten()
-        if float(b.norm()) < 1e-9:
+        if float(b.norm()) < 1e-9 or _zero_grad_bias(k):      # conv biases that feed a norm: analytically zero, float noise
             continue
         cos = float((a * b).sum() / (a.norm() * b.norm()))
         assert cos > 0.9995 and float((a - b).norm() / b.norm()) < 3e-2, (k, cos, float(a.norm()), float(b.norm()))
