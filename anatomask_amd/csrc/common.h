@@ -49,9 +49,12 @@ template <> __device__ __forceinline__ u32x4 f_to_chunk<float>(const float* f) {
   u32x4 c; c[0] = __float_as_uint(f[0]); c[1] = __float_as_uint(f[1]); c[2] = __float_as_uint(f[2]); c[3] = __float_as_uint(f[3]); return c;
 }
 template <> __device__ __forceinline__ u32x4 f_to_chunk<bf16_t>(const float* f) {
+  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN -- the same values as f2bf() at 1/10 of its instruction count
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bfx2_;
   u32x4 c;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) c[i] = (uint32_t)f2bf(f[2 * i]) | ((uint32_t)f2bf(f[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) c[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2_{f[2 * i], f[2 * i + 1]}), bfx2_));
   return c;
 }
 

@@ -349,6 +349,344 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
   }
 }
 
+
+// ================================================================== block-sparse tensors: ACTIVE-PATCH ROW WALK
+// A block-sparse tensor [B][D][H][W][C] with patch edge P = 1 << bs voxels is a set of "patch rows": P consecutive voxels along
+// W = P*C contiguous elements (for STUNet-B exactly 1 KB at every level: 16 x 32 ch ... 1 x 512 ch, bf16).  The kernels below
+// walk ONLY the rows of active patches, taken from the compacted active-patch list (am_mask_compact: one int32 per active
+// patch, b << 24 | pd << 16 | ph << 8 | pw): no per-voxel mask lookup, no integer divisions, no loop iterations spent on the
+// 60 % of the volume that is masked, and every thread keeps UNR independent 16-byte loads in flight.
+// Thread t of a workgroup owns chunk (t % rowchunks) of row lane (t / rowchunks); its channel chunk is t % cpv (rowchunks is a
+// multiple of cpv), the same thread -> channel map as the linear kernels, so the reduction epilogues are shared.
+struct RowGeo {
+  int B, D, H, W, C, bs;
+  int rowchunks;             // 16-byte chunks per patch row = P * C / EPC  (<= 256)
+  int rpp;                   // rows per pass = blockDim.x / rowchunks
+  int rpw;                   // rows per workgroup (multiple of rpp)
+  long total_rows;           // n_active * P * P
+  const int* plist;
+};
+constexpr int UNR = 4;
+
+template <typename T> struct RowWalk {
+  int cl, vx, r0, cpv; bool live;
+  long row, row_end; int rpp;
+  __device__ __forceinline__ RowWalk(const RowGeo& g) {
+    cpv = g.C / TT<T>::EPC;
+    const int c = threadIdx.x % g.rowchunks;
+    r0 = threadIdx.x / g.rowchunks; cl = c % cpv; vx = c / cpv; rpp = g.rpp; live = r0 < g.rpp;
+    row = (long)blockIdx.x * g.rpw + r0;
+    row_end = min((long)(blockIdx.x + 1) * g.rpw, g.total_rows);
+  }
+  // voxel index of this thread's chunk in patch row `rw`
+  __device__ __forceinline__ long voxel(const RowGeo& g, long rw) const {
+    const int P = 1 << g.bs;
+    const int a = (int)(rw >> (2 * g.bs)), r = (int)(rw & (P * P - 1));
+    const int pk = g.plist[a];
+    const int b = (pk >> 24) & 255, pd = (pk >> 16) & 255, ph = (pk >> 8) & 255, pw = pk & 255;
+    return (((long)b * g.D + pd * P + (r >> g.bs)) * g.H + ph * P + (r & (P - 1))) * g.W + pw * P + vx;
+  }
+};
+
+// MODE: 0 plain, 1 + residual tensor, 2 + Cin=1 stem shortcut.  Straight-line body (compile-time activation / mode, tail rows
+// clamped to the last row -- a pure map may store a row twice), the patch-list entries of the NEXT batch are fetched while the
+// current batch is in flight (the row -> address chain otherwise adds an L2 round trip in front of every batch of loads).
+template <typename T, int ACT, int MODE>
+__global__ __launch_bounds__(256) void norm_apply_rows_kernel(const T* __restrict__ x, RowGeo g, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const T* __restrict__ res,
+                                                              const float* __restrict__ stem_x, const float* __restrict__ stem_w,
+                                                              const float* __restrict__ stem_b, T* __restrict__ y) {
+  constexpr int EPC = TT<T>::EPC;
+  RowWalk<T> wk(g);
+  float sc[EPC], sh[EPC], sw[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) {
+    sc[i] = scale[wk.cl * EPC + i]; sh[i] = shift[wk.cl * EPC + i]; sw[i] = 0.f;
+    if (MODE == 2) { sw[i] = stem_w[wk.cl * EPC + i]; sh[i] += stem_b[wk.cl * EPC + i]; }
+  }
+  const int P = 1 << g.bs, pm = P * P - 1, sh2 = 2 * g.bs;
+  const long last = wk.row_end - 1;
+  if (wk.row > last) return;
+  int pk[UNR];
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) { const long r = min(wk.row + (long)u * wk.rpp, last); pk[u] = g.plist[r >> sh2]; }
+  for (long rw = wk.row; rw <= last; rw += (long)UNR * wk.rpp) {
+    size_t off[UNR]; long vox[UNR]; u32x4 xv[UNR], rv[UNR]; float sx[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const long r = min(rw + (long)u * wk.rpp, last);
+      const int q = (int)(r & pm);
+      const int b = (pk[u] >> 24) & 255, pd = (pk[u] >> 16) & 255, ph = (pk[u] >> 8) & 255, pw = pk[u] & 255;
+      vox[u] = (((long)b * g.D + pd * P + (q >> g.bs)) * g.H + ph * P + (q & (P - 1))) * g.W + pw * P + wk.vx;
+      off[u] = (size_t)vox[u] * g.C + wk.cl * EPC;
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      xv[u] = *(const u32x4*)(x + off[u]);
+      if (MODE == 1) rv[u] = *(const u32x4*)(res + off[u]);
+      if (MODE == 2) sx[u] = stem_x[vox[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {                                   // next batch's patch-list entries (clamped: always a valid index)
+      const long r = min(rw + (long)(UNR + u) * wk.rpp, last);
+      pk[u] = g.plist[r >> sh2];
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      float f[EPC], o[EPC];
+      chunk_to_f<T>(xv[u], f);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) o[i] = f[i] * sc[i] + sh[i];
+      if (MODE == 1) {
+        float r[EPC];
+        chunk_to_f<T>(rv[u], r);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) o[i] += r[i];
+      }
+      if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) o[i] += sw[i] * sx[u];
+      }
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) o[i] = act_fwd(o[i], ACT);
+      *(u32x4*)(y + off[u]) = f_to_chunk<T>(o);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chan_stats_rows_kernel(const T* __restrict__ x, RowGeo g, double* __restrict__ sums) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 2 * 8];
+  RowWalk<T> wk(g);
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) s1[i] = s2[i] = 0.f;
+  if (wk.live)
+    for (long rw = wk.row; rw < wk.row_end; rw += (long)UNR * wk.rpp) {
+      long v[UNR]; u32x4 xv[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) { const long r = rw + (long)u * wk.rpp; v[u] = r < wk.row_end ? wk.voxel(g, r) : -1; }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) if (v[u] >= 0) xv[u] = *(const u32x4*)(x + (size_t)v[u] * g.C + wk.cl * EPC);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (v[u] < 0) continue;
+        float f[EPC];
+        chunk_to_f<T>(xv[u], f);
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+      }
+    }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { red[(threadIdx.x * 2) * 8 + i] = s1[i]; red[(threadIdx.x * 2 + 1) * 8 + i] = s2[i]; }
+  __syncthreads();
+  const int nlane = blockDim.x / wk.cpv;
+  if (threadIdx.x < wk.cpv) {
+    double a1[EPC], a2[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) a1[i] = a2[i] = 0.0;
+    for (int vl = 0; vl < nlane; ++vl) {
+      const int t = vl * wk.cpv + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { a1[i] += red[(t * 2) * 8 + i]; a2[i] += red[(t * 2 + 1) * 8 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+      const int c = threadIdx.x * EPC + i;
+      double* sr = sums + (size_t)(blockIdx.x % NREP) * g.C * 2;
+      atomicAdd(&sr[c * 2], a1[i]); atomicAdd(&sr[c * 2 + 1], a2[i]);
+    }
+  }
+}
+
+// backward reduce over the active rows (no fill: the densify norms, whose inactive voxels carry the token gradient, keep the
+// linear kernel)
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_rows_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                                   const T* __restrict__ x, RowGeo g, const float* __restrict__ mean,
+                                                                   const float* __restrict__ rstd, int act, double* __restrict__ bsum,
+                                                                   const float* __restrict__ psc, const float* __restrict__ psh) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 2 * 8];
+  RowWalk<T> wk(g);
+  float s1[EPC], s2[EPC], mu[EPC], rs[EPC], qs[EPC], qh[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { s1[i] = s2[i] = 0.f; mu[i] = rs[i] = qs[i] = qh[i] = 0.f; }
+  if (wk.live) {
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+      mu[i] = mean[wk.cl * EPC + i]; rs[i] = rstd[wk.cl * EPC + i];
+      if (!out && act != AM_ACT_NONE) { qs[i] = psc[wk.cl * EPC + i]; qh[i] = psh[wk.cl * EPC + i]; }
+    }
+    for (long rw = wk.row; rw < wk.row_end; rw += (long)UNR * wk.rpp) {
+      long v[UNR]; u32x4 dv[UNR], xv[UNR], ov[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) { const long r = rw + (long)u * wk.rpp; v[u] = r < wk.row_end ? wk.voxel(g, r) : -1; }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (v[u] < 0) continue;
+        const size_t off = (size_t)v[u] * g.C + wk.cl * EPC;
+        dv[u] = *(const u32x4*)(dout + off); xv[u] = *(const u32x4*)(x + off);
+        if (out && act != AM_ACT_NONE) ov[u] = *(const u32x4*)(out + off);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (v[u] < 0) continue;
+        float d[EPC], f[EPC];
+        chunk_to_f<T>(dv[u], d); chunk_to_f<T>(xv[u], f);
+        if (act != AM_ACT_NONE) {
+          if (out) {
+            float o[EPC];
+            chunk_to_f<T>(ov[u], o);
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+          } else {
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) { s1[i] += d[i]; s2[i] += d[i] * (f[i] - mu[i]) * rs[i]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { red[(threadIdx.x * 2) * 8 + i] = s1[i]; red[(threadIdx.x * 2 + 1) * 8 + i] = s2[i]; }
+  __syncthreads();
+  const int nlane = blockDim.x / wk.cpv;
+  if (threadIdx.x < wk.cpv) {
+    double a1[EPC], a2[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) a1[i] = a2[i] = 0.0;
+    for (int vl = 0; vl < nlane; ++vl) {
+      const int t = vl * wk.cpv + threadIdx.x;
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) { a1[i] += red[(t * 2) * 8 + i]; a2[i] += red[(t * 2 + 1) * 8 + i]; }
+    }
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) {
+      const int c = threadIdx.x * EPC + i;
+      double* br = bsum + (size_t)(blockIdx.x % NREP) * g.C * 3;
+      atomicAdd(&br[c * 3], a1[i]); atomicAdd(&br[c * 3 + 1], a2[i]);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                                  const T* __restrict__ x, RowGeo g, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, const float* __restrict__ k0,
+                                                                  const float* __restrict__ k1, const float* __restrict__ k2, int act,
+                                                                  T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum,
+                                                                  int dxrep, const float* __restrict__ psc, const float* __restrict__ psh) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 8];
+  RowWalk<T> wk(g);
+  float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC], sx[EPC], qs[EPC], qh[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) {
+    const int c = wk.cl * EPC + i;
+    sx[i] = 0.f; qs[i] = qh[i] = 0.f;
+    if (wk.live) {
+      mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c];
+      if (!out && act != AM_ACT_NONE) { qs[i] = psc[c]; qh[i] = psh[c]; }
+    }
+  }
+  if (wk.live)
+    for (long rw = wk.row; rw < wk.row_end; rw += (long)UNR * wk.rpp) {
+      long v[UNR]; u32x4 dv[UNR], xv[UNR], ov[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) { const long r = rw + (long)u * wk.rpp; v[u] = r < wk.row_end ? wk.voxel(g, r) : -1; }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (v[u] < 0) continue;
+        const size_t off = (size_t)v[u] * g.C + wk.cl * EPC;
+        dv[u] = *(const u32x4*)(dout + off); xv[u] = *(const u32x4*)(x + off);
+        if (out && act != AM_ACT_NONE) ov[u] = *(const u32x4*)(out + off);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (v[u] < 0) continue;
+        const size_t off = (size_t)v[u] * g.C + wk.cl * EPC;
+        float d[EPC], f[EPC];
+        chunk_to_f<T>(dv[u], d); chunk_to_f<T>(xv[u], f);
+        if (act != AM_ACT_NONE) {
+          if (out) {
+            float o[EPC];
+            chunk_to_f<T>(ov[u], o);
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+          } else {
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+          }
+        }
+        if (dres) *(u32x4*)(dres + off) = f_to_chunk<T>(d);
+        float r[EPC];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) r[i] = c0[i] * d[i] - c1[i] - c2[i] * (f[i] - mu[i]) * rs[i];
+        const u32x4 pk = f_to_chunk<T>(r);
+        *(u32x4*)(dx + off) = pk;
+        if (dxsum) {
+          float q[EPC];
+          chunk_to_f<T>(pk, q);
+#pragma unroll
+          for (int i = 0; i < EPC; ++i) sx[i] += q[i];
+        }
+      }
+    }
+  if (dxsum) {
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) red[threadIdx.x * 8 + i] = sx[i];
+    __syncthreads();
+    const int nlane = blockDim.x / wk.cpv;
+    if (threadIdx.x < wk.cpv) {
+      float a1[EPC];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) a1[i] = 0.f;
+      for (int vl = 0; vl < nlane; ++vl)
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], a1[i]);
+    }
+  }
+}
+
+// active-patch list of a patch mask: list[i] = b << 24 | pd << 16 | ph << 8 | pw of the i-th active patch in memory order (ONE
+// workgroup: ordered block scan over B*fd*fh*fw <= a few thousand bytes), count[0] = number of active patches.
+__global__ __launch_bounds__(256) void mask_compact_kernel(const uint8_t* __restrict__ mask, int B, int fd, int fh, int fw,
+                                                           int* __restrict__ list, int* __restrict__ count) {
+  __shared__ int wsum[4];
+  __shared__ int base;
+  const int n = B * fd * fh * fw;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int i = i0 + threadIdx.x;
+    const int a = (i < n && mask[i]) ? 1 : 0;
+    const unsigned long long bal = __ballot(a);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[wv] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wv; ++w) off += wsum[w];
+    if (a) {
+      int q = i;
+      const int pw = q % fw; q /= fw;
+      const int ph = q % fh; q /= fh;
+      const int pd = q % fd; const int b = q / fd;
+      list[off + pre] = (b << 24) | (pd << 16) | (ph << 8) | pw;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) count[0] = base;
+}
+
 // ------------------------------------------------------------------ generic per-channel sum (bias grads)
 template <typename T>
 __global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, Geo g, float* __restrict__ out) {
@@ -791,6 +1129,72 @@ __global__ __launch_bounds__(256) void partials_reduce2_kernel(const float* __re
   }
 }
 
+
+// Statistics plumbing of one norm in ONE launch: per-workgroup conv partials [rows][C][2] -> per-channel sums (double atomics
+// into a zeroed workspace) -> the LAST workgroup to finish (ticket counter) folds them into mean / rstd / scale / shift
+// (+ BatchNorm running statistics and num_batches_tracked), then re-zeroes the workspace for the next user.  Replaces
+// memset + partials_reduce + norm_finalize (3 launches, ~20 us of an encoder level that computes for 100 us).
+// Cross-workgroup visibility: the sums are only ever touched by device-scope atomics (performed at the memory side), the ticket
+// increment follows a __threadfence(), and the finalizing workgroup reads the sums back with atomics as well.
+__global__ __launch_bounds__(256) void partials_finalize_kernel(const float* __restrict__ part, int rows, int C, int rows_per_block,
+                                                                double* __restrict__ ws, const double* count_ptr, double count_host,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                                float* mean, float* rstd, float* scale, float* shift, float* run_mean,
+                                                                float* run_var, float momentum, long* nbt, float* sum_accum) {
+  __shared__ double sh1[256], sh2[256];
+  __shared__ unsigned ticket_s;
+  const int t = threadIdx.x;
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  const float2* __restrict__ p2 = (const float2*)part;
+  double* sums = ws;                                           // [C][2]
+  unsigned* ticket = (unsigned*)(ws + 2 * (size_t)C);
+  if (C <= 256) {
+    const int rstep = 256 / C;
+    double s1 = 0.0, s2 = 0.0;
+    if (t < rstep * C) {
+      const int c = t % C;
+      for (int r = r0 + t / C; r < r1; r += rstep) { const float2 v = p2[(size_t)r * C + c]; s1 += v.x; s2 += v.y; }
+    }
+    sh1[t] = s1; sh2[t] = s2;
+    __syncthreads();
+    if (t < C) {
+      for (int k = 1; k < rstep; ++k) { s1 += sh1[k * C + t]; s2 += sh2[k * C + t]; }
+      atomicAdd(&sums[2 * t], s1); atomicAdd(&sums[2 * t + 1], s2);
+    }
+  } else {
+    for (int c = t; c < C; c += 256) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int r = r0; r < r1; ++r) { const float2 v = p2[(size_t)r * C + c]; s1 += v.x; s2 += v.y; }
+      atomicAdd(&sums[2 * c], s1); atomicAdd(&sums[2 * c + 1], s2);
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (t == 0) ticket_s = atomicAdd(ticket, 1u);
+  __syncthreads();
+  if (ticket_s != gridDim.x - 1) return;
+  // ---- last workgroup: finalize
+  const double n = count_ptr ? count_ptr[0] : count_host;
+  for (int c = t; c < C; c += 256) {
+    const double q1 = __longlong_as_double(atomicExch((unsigned long long*)&sums[2 * c], 0ull));       // read + re-zero at the memory side
+    const double q2 = __longlong_as_double(atomicExch((unsigned long long*)&sums[2 * c + 1], 0ull));
+    if (sum_accum) sum_accum[c] += (float)q1;
+    if (!gamma) continue;
+    const double m = q1 / n;
+    double var = q2 / n - m * m;
+    if (var < 0) var = 0;
+    const float rs = (float)(1.0 / sqrt(var + (double)eps));
+    mean[c] = (float)m; rstd[c] = rs;
+    const float scv = gamma[c] * rs;
+    scale[c] = scv; shift[c] = beta[c] - (float)m * scv;
+    if (run_mean) {
+      run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+      run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * (n / (n - 1.0)));
+    }
+  }
+  if (t == 0) { atomicExch(ticket, 0u); if (nbt) nbt[0] += 1; }
+}
+
 // voxels per workgroup: whole passes (256/(C/EPC) voxels each), ~2048 workgroups per launch (<= 1024 for reductions)
 inline int pick_vpw(long nvox, int C, int dtype, bool reduction) {
   const int epc = dtype == AM_DT_BF16 ? 8 : 4;
@@ -821,6 +1225,32 @@ inline bool geo_ok(int B, int D, int H, int W) {
   return n * (unsigned long long)m < 0xffffffffull;
 }
 
+
+// row-walk geometry of a block-sparse tensor, or false when the tensor does not qualify (rows wider than one workgroup, >255 patches
+// per axis): the caller then uses the linear kernel
+inline bool mkrows(RowGeo& r, int dtype, bool reduction, int B, int D, int H, int W, int C, int bs, const int* plist, int n_active) {
+  if (!plist || n_active <= 0 || bs < 0 || bs > 6) return false;
+  const int epc = dtype == AM_DT_BF16 ? 8 : 4;
+  const int P = 1 << bs;
+  const long rc = (long)P * C / epc;
+  if (rc > 256 || rc < 1 || (D >> bs) > 255 || (H >> bs) > 255 || (W >> bs) > 255 || B > 255) return false;
+  if (D % P || H % P || W % P) return false;
+  r.B = B; r.D = D; r.H = H; r.W = W; r.C = C; r.bs = bs; r.plist = plist;
+  r.rowchunks = (int)rc; r.rpp = 256 / r.rowchunks;
+  r.total_rows = (long)n_active * P * P;
+  // rows per workgroup: >= UNR passes, ~32 KB of the tensor, but keep >= ~1024 workgroups on big tensors / >= 1 pass on tiny ones
+  const long target = reduction ? 1024 : 2048;
+  long rpw = (r.total_rows + target - 1) / target;
+  const long unit = (long)UNR * r.rpp;
+  rpw = (rpw + unit - 1) / unit * unit;
+  if (rpw < unit) rpw = unit;
+  if (rpw > 64 * unit) rpw = 64 * unit;
+  r.rpw = (int)rpw;
+  return true;
+}
+inline int rows_blocks(const RowGeo& r) { return (int)((r.total_rows + r.rpw - 1) / r.rpw); }
+inline int rows_threads(const RowGeo& r) { return r.rpp * r.rowchunks; }
+
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == AM_DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
@@ -829,12 +1259,19 @@ inline bool geo_ok(int B, int D, int H, int W) {
 extern "C" {
 
 int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
-                  int fw, double* sums, void* stream) {
+                  int fw, double* sums, const int32_t* active_list, int n_active, void* stream) {
   CHK_C(C);
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * NREP, st);
+  RowGeo rg;
+  if (mask && mkrows(rg, dtype, true, B, D, H, W, C, bshift, active_list, n_active)) {
+    DISPATCH_T(dtype, AM_LAUNCH(chan_stats_rows_kernel<float>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const float*)x, rg, sums),
+               AM_LAUNCH(chan_stats_rows_kernel<bf16_t>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const bf16_t*)x, rg, sums));
+    AM_CHECK_LAUNCH();
+    return 0;
+  }
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype, AM_LAUNCH(chan_stats_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, sums),
              AM_LAUNCH(chan_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, sums));
@@ -844,6 +1281,13 @@ int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, c
 
 int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out, void* stream) {
   AM_LAUNCH(mask_count_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, n, voxels_per_patch, out);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_mask_compact(const uint8_t* mask, int B, int fd, int fh, int fw, int32_t* list, int32_t* count, void* stream) {
+  if (B > 255 || fd > 255 || fh > 255 || fw > 255) return -1;
+  AM_LAUNCH(mask_compact_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mask, B, fd, fh, fw, list, count);
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -867,11 +1311,30 @@ int am_norm_fold_running(int C, const float* gamma, const float* beta, const flo
 
 int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                   int fw, const float* scale, const float* shift, int act, const void* res, const float* stem_x,
-                  const float* stem_w, const float* stem_b, const float* fill, void* y, void* stream) {
+                  const float* stem_w, const float* stem_b, const float* fill, void* y, const int32_t* active_list, int n_active,
+                  void* stream) {
   CHK_C(C);
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
+  RowGeo rg;
+  if (mask && !fill && !(res && stem_x) && mkrows(rg, dtype, false, B, D, H, W, C, bshift, active_list, n_active)) {
+    const dim3 gr(rows_blocks(rg)), bl(rows_threads(rg));
+    const int mode = res ? 1 : (stem_x ? 2 : 0);
+#define AM_ROWS_APPLY(TT_, ACT_, MODE_)                                                                                        \
+    AM_LAUNCH((norm_apply_rows_kernel<TT_, ACT_, MODE_>), gr, bl, 0, st, (const TT_*)x, rg, scale, shift, (const TT_*)res, stem_x, stem_w, stem_b, (TT_*)y)
+#define AM_ROWS_APPLY_M(TT_, ACT_)                                                                                             \
+    do { if (mode == 0) AM_ROWS_APPLY(TT_, ACT_, 0); else if (mode == 1) AM_ROWS_APPLY(TT_, ACT_, 1); else AM_ROWS_APPLY(TT_, ACT_, 2); } while (0)
+#define AM_ROWS_APPLY_A(TT_)                                                                                                   \
+    do { if (act == AM_ACT_LRELU) AM_ROWS_APPLY_M(TT_, AM_ACT_LRELU); else if (act == AM_ACT_RELU6) AM_ROWS_APPLY_M(TT_, AM_ACT_RELU6); \
+         else AM_ROWS_APPLY_M(TT_, AM_ACT_NONE); } while (0)
+    DISPATCH_T(dtype, AM_ROWS_APPLY_A(float), AM_ROWS_APPLY_A(bf16_t));
+#undef AM_ROWS_APPLY_A
+#undef AM_ROWS_APPLY_M
+#undef AM_ROWS_APPLY
+    AM_CHECK_LAUNCH();
+    return 0;
+  }
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,
@@ -884,13 +1347,24 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
 
 int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
-                       int fill, double* bsum, const float* pre_scale, const float* pre_shift, void* stream) {
+                       int fill, double* bsum, const float* pre_scale, const float* pre_shift, const int32_t* active_list,
+                       int n_active, void* stream) {
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C * NREP, st);
+  RowGeo rg;
+  if (mask && !fill && mkrows(rg, dtype, true, B, D, H, W, C, bshift, active_list, n_active)) {
+    DISPATCH_T(dtype,
+               AM_LAUNCH(norm_bwd_reduce_rows_kernel<float>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const float*)dout,
+                         (const float*)out, (const float*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift),
+               AM_LAUNCH(norm_bwd_reduce_rows_kernel<bf16_t>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout,
+                         (const bf16_t*)out, (const bf16_t*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift));
+    AM_CHECK_LAUNCH();
+    return 0;
+  }
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
@@ -913,19 +1387,29 @@ int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double cou
 int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, float* dxsum_accum,
-                      float* dxsum_scratch, const float* pre_scale, const float* pre_shift, void* stream) {
+                      float* dxsum_scratch, const float* pre_scale, const float* pre_shift, const int32_t* active_list, int n_active,
+                      void* stream) {
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  const int nb = nblk((long)B * D * H * W, g.vpw);
+  RowGeo rg;
+  const bool rows = mask && mkrows(rg, dtype, false, B, D, H, W, C, bshift, active_list, n_active);
+  const int nb = rows ? rows_blocks(rg) : nblk((long)B * D * H * W, g.vpw);
   // bias-gradient sums: every workgroup adds C floats; on ONE accumulator 2048 workgroups serialise (measured 400 us on an
   // 8 MB tensor), so they go to AM_DXREP replicas that a 1-block kernel folds afterwards
   const bool rep = dxsum_accum && dxsum_scratch;
   float* dxs = rep ? dxsum_scratch : dxsum_accum;
   const int nrep = rep ? AM_DXREP : 1;
   if (rep) hipMemsetAsync(dxsum_scratch, 0, sizeof(float) * AM_DXREP * C, st);
+  if (rows) {
+    DISPATCH_T(dtype,
+               AM_LAUNCH(norm_bwd_apply_rows_kernel<float>, dim3(nb), dim3(rows_threads(rg)), 0, st, (const float*)dout, (const float*)out,
+                         (const float*)x, rg, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift),
+               AM_LAUNCH(norm_bwd_apply_rows_kernel<bf16_t>, dim3(nb), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
+                         (const bf16_t*)x, rg, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift));
+  } else
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
                                 (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift),
@@ -1037,6 +1521,22 @@ int am_partials_reduce(const float* partials, int rows, int C, double* sums, flo
     return 0;
   }
   AM_LAUNCH(partials_reduce_kernel, dim3(C), dim3(256), 0, st, partials, rows, C, sums, sum_accum);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+
+int am_partials_finalize(const float* partials, int rows, int C, double* workspace, const double* count_ptr, double count_host,
+                         const float* gamma, const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                         float* run_mean, float* run_var, float momentum, long* num_batches_tracked, float* sum_accum, void* stream) {
+  if (C <= 0 || C > 4096 || rows <= 0 || !workspace) return -1;
+  if (gamma && (!beta || !mean || !rstd || !scale || !shift)) return -1;
+  const int rstep = C <= 256 ? 256 / C : 1;
+  int nb = rows / (rstep * 16); nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  const int rpb = ((rows + nb - 1) / nb + rstep - 1) / rstep * rstep;
+  nb = (rows + rpb - 1) / rpb;
+  AM_LAUNCH(partials_finalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, partials, rows, C, rpb, workspace, count_ptr, count_host,
+            gamma, beta, eps, mean, rstd, scale, shift, run_mean, run_var, momentum, num_batches_tracked, sum_accum);
   AM_CHECK_LAUNCH();
   return 0;
 }

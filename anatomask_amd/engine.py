@@ -65,8 +65,11 @@ class Tape:
         self.enc_in: List[Optional[torch.Tensor]] = []   # recompute mode: the input map of every encoder stage
 
 
-def _counts(mask: MaskInfo, levels: Sequence[int]) -> Dict[int, torch.Tensor]:
-    """active-voxel counts (device doubles) per block shift."""
+def _counts(mask: MaskInfo, levels: Sequence[int]) -> Dict[int, object]:
+    """active-voxel counts per block shift: host numbers when the number of active patches is known (the trainer's sampler
+    guarantees B * len_keep), else device doubles (one tiny kernel per level, no host synchronisation)."""
+    if mask.n_active is not None:
+        return {bs: float(mask.n_active) * float((1 << bs) ** 3) for bs in levels}
     out = {}
     buf = torch.empty(len(levels), device=mask.t.device, dtype=torch.float64)
     for i, bs in enumerate(levels):
@@ -75,15 +78,21 @@ def _counts(mask: MaskInfo, levels: Sequence[int]) -> Dict[int, torch.Tensor]:
     return out
 
 
+def _set_count(st: NormStats, cnt):
+    if isinstance(cnt, float):
+        st.count_host, st.count_ptr = cnt, None
+    else:
+        st.count_ptr = cnt
+
+
 def _sparse_norm(x, mask, bs, counts, gamma, beta, eps, part=None) -> NormStats:
     """pooled sparse InstanceNorm statistics; `part` = partial sums left by the producing conv's epilogue."""
     st = NormStats(x.shape[-1], x.device)
-    st.count_ptr = counts[bs]
+    _set_count(st, counts[bs])
     if part is not None:
-        part.reduce(sums=st.sums)
-        st.nrep = 1
-    else:
-        ops.chan_stats(x, mask, bs, st)
+        part.finalize(st, gamma, beta, eps)                       # reduce + finalize in one launch
+        return st
+    ops.chan_stats(x, mask, bs, st)
     ops.norm_finalize(st, gamma, beta, eps)
     return st
 
@@ -92,11 +101,14 @@ def _batch_norm(x, W, prefix, train: bool, part=None, update_running: bool = Tru
     st = NormStats(x.shape[-1], x.device)
     if train:
         st.count_host = float(x.numel() // x.shape[-1])
-        if part is not None:
-            part.reduce(sums=st.sums)
-            st.nrep = 1
-        else:
-            ops.chan_stats(x, None, 0, st)
+        if part is not None:                                      # reduce + finalize (+ running stats, num_batches_tracked) in one launch
+            if update_running:
+                part.finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"], W[f"{prefix}.running_var"],
+                              0.1, W[f"{prefix}.num_batches_tracked"])
+            else:
+                part.finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5)
+            return st
+        ops.chan_stats(x, None, 0, st)
         if update_running:
             ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"],
                               W[f"{prefix}.running_var"], 0.1)
@@ -360,14 +372,14 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
         dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
                                 G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"])
         du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
-        ptu.reduce(sum_accum=G[f"{q}.up_sample.bias"])           # ConvT bias gradient = per-channel sum of du
+        ptu.finalize(None, sum_accum=G[f"{q}.up_sample.bias"])  # ConvT bias gradient = per-channel sum of du
         _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
         si = tuple(t["xin"].shape[1:4])
         need_sum = i > 0 and f"densify_projs.{i}.bias" in G        # densify_projs[i].bias gradient = sum of this tensor
         g = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2, want_partials=bool(need_sum))
         if need_sum:
             g, ptg = g
-            ptg.reduce(sum_accum=G[f"densify_projs.{i}.bias"])
+            ptg.finalize(None, sum_accum=G[f"densify_projs.{i}.bias"])
         _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
     dproj[0] = g
     return dproj

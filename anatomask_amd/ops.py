@@ -30,10 +30,26 @@ def _stream():
 class MaskInfo:
     """uint8 patch mask [B, fd, fh, fw] (1 = active)."""
 
-    def __init__(self, mask_u8: torch.Tensor):
+    def __init__(self, mask_u8: torch.Tensor, n_active: Optional[int] = None):
+        """n_active: number of active patches when the caller knows it (the trainer: B * len_keep); otherwise it is counted on
+        first use (one host synchronisation, as the reference's `nonzero` calls incur in every layer)."""
         assert mask_u8.dtype == torch.uint8 and mask_u8.dim() == 4 and mask_u8.is_contiguous()
         self.t = mask_u8
         self.B, self.fd, self.fh, self.fw = mask_u8.shape
+        self.n_active = n_active
+        self._list: Optional[torch.Tensor] = None
+
+    def active_list(self):
+        """(device int32 list of the active patches, their number) -- built once per mask (am_mask_compact)."""
+        if self._list is None:
+            if max(self.B, self.fd, self.fh, self.fw) > 255:
+                return None, 0
+            if self.n_active is None:
+                self.n_active = int(self.t.count_nonzero().item())
+            buf = torch.empty(self.t.numel() + 1, device=self.t.device, dtype=torch.int32)
+            hip.lib().mask_compact(self.t.data_ptr(), self.B, self.fd, self.fh, self.fw, buf.data_ptr(), buf[-1:].data_ptr(), _stream())
+            self._list = buf
+        return self._list, self.n_active
 
     @staticmethod
     def from_bool(active_b1fff: torch.Tensor, device) -> "MaskInfo":
@@ -45,6 +61,14 @@ def _mk(mask: Optional[MaskInfo]):
     if mask is None:
         return None, 1, 1, 1
     return mask.t.data_ptr(), mask.fd, mask.fh, mask.fw
+
+
+def _al(mask: Optional[MaskInfo]):
+    """(active-patch list pointer, n_active) for the row-walk kernels, or (None, 0)."""
+    if mask is None:
+        return None, 0
+    lst, n = mask.active_list()
+    return (lst.data_ptr(), n) if lst is not None and n > 0 else (None, 0)
 
 
 # ------------------------------------------------------------------ weights
@@ -67,6 +91,32 @@ class ConvPartials:
 
     def reduce(self, sums: Optional[torch.Tensor] = None, sum_accum: Optional[torch.Tensor] = None):
         hip.lib().partials_reduce(self.t.data_ptr(), self.rows, self.C, _p(sums), _p(sum_accum), _stream())
+
+    def finalize(self, st: Optional["NormStats"], gamma=None, beta=None, eps: float = 0.0, run_mean=None, run_var=None,
+                 momentum: float = 0.1, num_batches_tracked=None, sum_accum: Optional[torch.Tensor] = None):
+        """partials -> per-channel sums -> mean / rstd / scale / shift of `st` (+ BN running stats, num_batches_tracked) in ONE
+        launch (am_partials_finalize); st None: only `sum_accum[c] += sum` (bias gradients)."""
+        ws = _stats_workspace(self.t.device, self.C)
+        if st is None:
+            hip.lib().partials_finalize(self.t.data_ptr(), self.rows, self.C, ws.data_ptr(), None, 1.0, None, None, 0.0, None, None, None,
+                                        None, None, None, 0.0, None, _p(sum_accum), _stream())
+            return
+        hip.lib().partials_finalize(self.t.data_ptr(), self.rows, self.C, ws.data_ptr(), _p(st.count_ptr), float(st.count_host),
+                                    gamma.data_ptr(), beta.data_ptr(), eps, st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
+                                    st.shift.data_ptr(), _p(run_mean), _p(run_var), momentum, _p(num_batches_tracked), _p(sum_accum), _stream())
+        st.nrep = 1
+
+
+_WS = {}
+
+
+def _stats_workspace(device, C: int) -> torch.Tensor:
+    """zero-initialised scratch of am_partials_finalize (left zero by every call), one per (device, stream)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < 2 * C + 2:
+        ws = _WS[key] = torch.zeros(2 * max(C, 2048) + 2, device=device, dtype=torch.float64)
+    return ws
 
 
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_dgrad: bool) -> torch.Tensor:
@@ -208,7 +258,7 @@ class NormStats:
 def chan_stats(x: torch.Tensor, mask: Optional[MaskInfo], bshift: int, st: NormStats):
     B, D, H, W, Cc = x.shape
     mp, fd, fh, fw = _mk(mask)
-    hip.lib().chan_stats(_dt(x), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw, st.sums.data_ptr(), _stream())
+    hip.lib().chan_stats(_dt(x), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw, st.sums.data_ptr(), *_al(mask), _stream())
     st.nrep = NREP
 
 
@@ -238,7 +288,7 @@ def norm_apply(x: torch.Tensor, st: NormStats, act: int, mask: Optional[MaskInfo
     mp, fd, fh, fw = _mk(mask)
     sx, sw, sb = stem if stem is not None else (None, None, None)
     hip.lib().norm_apply(_dt(x), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw, st.scale.data_ptr(), st.shift.data_ptr(),
-                         act, _p(res), _p(sx), _p(sw), _p(sb), _p(fill), out.data_ptr(), _stream())
+                         act, _p(res), _p(sx), _p(sw), _p(sb), _p(fill), out.data_ptr(), *_al(mask), _stream())
     return out
 
 
@@ -262,14 +312,15 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
     L = hip.lib()
     s = _stream()
     L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
-                      st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), sc.bsum.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), s)
+                      st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), sc.bsum.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                      *_al(mask), s)
     L.norm_bwd_finalize(sc.bsum.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
                         sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
     if dx is None:
         dx = torch.empty_like(x)
     L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                      st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
-                     dx.data_ptr(), _p(dres), _p(dxsum), sc.dxrep.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), s)
+                     dx.data_ptr(), _p(dres), _p(dxsum), sc.dxrep.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), *_al(mask), s)
     return dx
 
 

@@ -101,11 +101,11 @@ class AnatoMaskTrainer:
             m1 = ops.mask_sampler(torch.zeros(B, L, device=dev), k1, m.len_keep, 0)
         else:
             m1 = mask1.reshape(B, L).to(device=dev, dtype=torch.uint8).contiguous()
-        mi1 = ops.MaskInfo(m1.view(B, *spec.fmap))
+        mi1 = ops.MaskInfo(m1.view(B, *spec.fmap), n_active=B * m.len_keep if mask1 is None else None)
         if self.self_distill:
             # 2. teacher pass + raw per-patch loss (:421-425)
             # (only the masked patches' teacher loss is used: the last decoder conv skips the visible 40 % of the volume)
-            need = ops.MaskInfo((1 - m1).view(B, *spec.fmap)) if spec.input_size[0] // spec.fmap[0] == 16 else None
+            need = ops.MaskInfo((1 - m1).view(B, *spec.fmap), n_active=B * (L - m.len_keep) if mask1 is None else None) if spec.input_size[0] // spec.fmap[0] == 16 else None
             rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False, needed_patches=need)
             recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
             del rec1
@@ -114,7 +114,7 @@ class AnatoMaskTrainer:
             if keys is None:
                 keys = torch.rand(B, L, device=dev, generator=self.gen)
             mk = ops.mask_sampler(recon, keys.to(dev).float().contiguous(), m.len_keep, ll)
-            mi = ops.MaskInfo(mk.view(B, *spec.fmap))
+            mi = ops.MaskInfo(mk.view(B, *spec.fmap), n_active=B * m.len_keep)      # the sampler leaves exactly len_keep visible per sample
         else:                                                     # plain SparK: the random mask IS the student mask
             recon, mk, mi = None, m1, mi1
         # 4. student forward + loss (:429-430)

@@ -113,7 +113,7 @@ def encoder_forward_hbm(model, x, dev):
     L = model.spec.fmap[0] * model.spec.fmap[1] * model.spec.fmap[2]
     k = torch.rand(B, L, device=dev)
     mk = ops.mask_sampler(torch.zeros(B, L, device=dev), k, model.len_keep, 0)
-    mi = ops.MaskInfo(mk.view(B, *model.spec.fmap))
+    mi = ops.MaskInfo(mk.view(B, *model.spec.fmap), n_active=B * model.len_keep)
     xs = x[:, 0].contiguous()
 
     def enc_only():

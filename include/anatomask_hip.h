@@ -93,24 +93,40 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
 /* Pooled sparse InstanceNorm (P/encoder3D.py:138-165: statistics over ALL active voxels of the local
  * batch) and BatchNorm3d (P/decoder3D.py:21-22) share these: stats -> finalize -> apply. */
 int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
-                  int fw, double* sums /* [AM_NREP][C][2] replicated accumulators, zeroed inside */, void* stream);
+                  int fw, double* sums /* [AM_NREP][C][2] replicated accumulators, zeroed inside */,
+                  const int32_t* active_list, int n_active /* see am_mask_compact; NULL / 0: linear walk with per-voxel mask lookups */,
+                  void* stream);
 int am_mask_count(const uint8_t* mask, int n, int voxels_per_patch, double* out, void* stream);
+/* Active-patch list of a patch mask: list[i] = b << 24 | pd << 16 | ph << 8 | pw of the i-th active patch (memory order),
+ * count[0] = their number.  The reference rebuilds `nonzero` index tuples of the UP-SAMPLED mask in every sparse layer call
+ * (P/encoder3D.py:7-10, 30x per forward); here the list is built once per mask and shared by every streaming kernel of the
+ * forward and the backward, which then walk only the rows of active patches (no per-voxel mask lookup). */
+int am_mask_compact(const uint8_t* mask, int B, int fd, int fh, int fw, int32_t* list, int32_t* count, void* stream);
 int am_norm_finalize(const double* sums, int nrep /* AM_NREP after am_chan_stats, 1 after am_partials_reduce */, const double* count_ptr, double count_host, int C, const float* gamma,
                      const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                      float* run_mean /* NULL or BN running stats, updated */, float* run_var, float momentum, void* stream);
+/* The statistics plumbing of one norm in ONE launch: conv partials [rows][C][2] -> per-channel sums -> (last workgroup) mean /
+ * rstd / folded scale+shift, BatchNorm running-stat update and num_batches_tracked += 1 (nn.BatchNorm3d in train mode,
+ * P/decoder3D.py:21-22).  gamma == NULL: only sum_accum[c] += sum (a bias gradient).  workspace: 2*C + 1 doubles that are ZERO on
+ * entry and are left ZERO on exit (allocate once, zero once, share between consecutive calls on one stream). */
+int am_partials_finalize(const float* partials, int rows, int C, double* workspace, const double* count_ptr, double count_host,
+                         const float* gamma, const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
+                         float* run_mean, float* run_var, float momentum, long* num_batches_tracked, float* sum_accum, void* stream);
 int am_norm_fold_running(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
                          float* scale, float* shift, void* stream);   /* eval-mode BN (teacher) */
 /* y = act(x*scale + shift [+ res] [+ stem_w*stem_x + stem_b]); fill != NULL: inactive voxels := mask token
  * (densify, P/AnatoMask.py:158-163).  Fuses norm + LeakyReLU/ReLU6 + residual add (P/STUNet_head.py:96-103). */
 int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                   int fw, const float* scale, const float* shift, int act, const void* res, const float* stem_x,
-                  const float* stem_w, const float* stem_b, const float* fill, void* y, void* stream);
+                  const float* stem_w, const float* stem_b, const float* fill, void* y,
+                  const int32_t* active_list, int n_active, void* stream);
 /* backward: bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout}, dpre = dout*act'(out) */
 int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
                        int fill, double* bsum /* [AM_NREP][C][3], zeroed inside */,
                        const float* pre_scale, const float* pre_shift /* out == NULL with an activation (no residual): the
-                       derivative is taken from the recomputed pre-activation x*pre_scale + pre_shift -- one read less */, void* stream);
+                       derivative is taken from the recomputed pre-activation x*pre_scale + pre_shift -- one read less */,
+                       const int32_t* active_list, int n_active, void* stream);
 int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
                          const float* rstd, float* k0, float* k1, float* k2, float* dgamma_accum, float* dbeta_accum,
                          float* dtoken_accum, float* dbeta2_accum /* bias of a conv added after the norm: same sum */, void* stream);
@@ -119,7 +135,8 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres,
                       float* dxsum_accum /* NULL or += per-channel sum of dx: bias gradient of the conv feeding the norm */,
                       float* dxsum_scratch /* [AM_DXREP][C] workspace when dxsum_accum != NULL (NULL: direct atomics) */,
-                      const float* pre_scale, const float* pre_shift /* as in am_norm_bwd_reduce */, void* stream);
+                      const float* pre_scale, const float* pre_shift /* as in am_norm_bwd_reduce */,
+                      const int32_t* active_list, int n_active, void* stream);
 int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                 int fw, float* out_accum, void* stream);   /* conv bias gradients */
 int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream);   /* x + to_dec[i], P/decoder3D.py:59 */

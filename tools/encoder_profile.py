@@ -16,7 +16,7 @@ model._ensure_flat() if hasattr(model, "_ensure_flat") else None
 x = torch.randn(B, 128, 128, 128, device=dev)
 L = model.spec.fmap[0] * model.spec.fmap[1] * model.spec.fmap[2]
 mk = ops.mask_sampler(torch.zeros(B, L, device=dev), torch.rand(B, L, device=dev), model.len_keep, 0)
-mi = ops.MaskInfo(mk.view(B, *model.spec.fmap))
+mi = ops.MaskInfo(mk.view(B, *model.spec.fmap), n_active=B * model.len_keep)
 
 
 def run():
