@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libanatomask_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_wgrad.hip", "stream_ops.hip", "step_ops.hip"]
+SOURCES = ["conv_igemm.hip", "conv_rw.hip", "conv_wgrad.hip", "stream_ops.hip", "step_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -24,7 +24,7 @@ def build(force: bool = False, verbose: bool = True, ablate: bool = False) -> st
     sfx = "_ablate" if ablate else ""
     out = OUT.replace(".so", sfx + ".so")
     flags = FLAGS + (["-DAM_ABLATE"] if ablate else [])
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "anatomask_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_plan.h"), os.path.join(os.path.dirname(HERE), "include", "anatomask_hip.h")]
     objs = []
     procs = []
     for s in SOURCES:

@@ -1,0 +1,408 @@
+// Resident-weight gather convolution for THIN layers (gfx950, bf16): Cin <= 32 (one 64-byte channel slab per voxel) and
+// taps * Cout small enough that EVERY tap's weights fit in LDS next to the source brick:
+//   STUNet stage 0  conv2 32->32 k3 s1 @128^3 (block-sparse, 16^3 patches)  and its data gradient      (P/STUNet_head.py:86, P/encoder3D.py:12-15)
+//   STUNet stage 1  conv1 32->64 k3 s2 -> 64^3 (block-sparse, 8^3 output patches)                       (P/STUNet_head.py:81)
+// The generic kernel (conv_igemm.hip) gives such a layer one workgroup per brick: a prologue (tap table, staging plan, buffer
+// descriptors), ONE channel slab, and nine 3-tap weight groups that each cost a barrier and a trip to L2 -- ~200 us of weight
+// traffic and ~120 us of fixed costs around 84 us of MFMA work (profiles/r01_encoder_fwd.md).  Here a PERSISTENT workgroup
+//   * loads all taps' weights into LDS once (27 x 32 x 64 B = 54 KB, or 27 x 64 x 64 B = 108 KB),
+//   * walks a contiguous run of ACTIVE bricks taken from the active-patch list (am_mask_compact) -- empty bricks are never
+//     launched, the activity of a brick's 27 neighbour patches is one ballot per brick (fetched two bricks ahead), so the
+//     staging plan of a source row is pure ALU,
+//   * software-pipelines the stages (brick x unit): the next stage's source rows are in flight (registers) while the current
+//     stage's taps issue; per stage there are two barriers and no weight traffic at all,
+//   * keeps the per-channel (sum, sum of squares) of what it stored in registers across its bricks and leaves ONE partials row.
+// Fragment layouts, LDS images, tap plan and epilogue channel order are those of conv_igemm.hip (conv_plan.h).
+#include <mutex>
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "../../include/anatomask_hip.h"
+#include "conv_plan.h"
+
+using namespace amconv;
+
+namespace {
+
+struct RwArgs {
+  const int* plist;      // active-patch list (block-sparse in/out) or nullptr (dense: every brick of the q grid)
+  int nbrick;            // bricks to process in total
+  int pbd, pbh, pbw;     // bricks per patch along d, h, w   (block-sparse)
+  int pq;                // patch edge in q (= output) voxels (block-sparse)
+  int ntaps;
+};
+
+typedef bf16_t T;
+constexpr int EPC = 8;
+constexpr unsigned OOB = 0x80000000u;
+
+template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR>
+__global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) {
+  constexpr int NTH = NW * 64;
+  constexpr int MV = BD * BH * BW;
+  constexpr int VS = MV / (16 * NW);                     // 16-voxel subtiles per wave
+  constexpr int NT = 16 * NS;
+  constexpr int RPI = NTH / 4;                           // source rows staged per iteration
+  static_assert(MV % (16 * NW) == 0, "brick must give each wave whole 16-voxel subtiles");
+  static_assert(!HR || (BH == 4 && BW == 16 && VS == 4), "h-run reuse: a wave owns one 4x16 d-plane");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* ldsW = lds + a.w_lds_off;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int co0 = blockIdx.y * NT;
+  const bool sparse = r.plist != nullptr;
+  const int ibs = a.in_mask.bs, obs = a.out_mask.bs;
+
+  // ---- this workgroup's contiguous run of bricks ----
+  const int chunk = (r.nbrick + gridDim.x - 1) / gridDim.x;
+  const int b0 = blockIdx.x * chunk, b1 = min(b0 + chunk, r.nbrick);
+
+  // ---- all taps' weights -> LDS (once) ----
+  {
+    const int wtapB = a.Coutp * a.Cinp * (int)sizeof(T);
+    const int total = r.ntaps * NT * 4;
+    for (int idx = tid; idx < total; idx += NTH) {
+      const int tap = idx / (NT * 4), rem = idx - tap * (NT * 4), row = rem >> 2, ch = rem & 3;
+      const int widx = (a.taps[tap] >> 12) & 63;
+      const u32x4 v = *(const u32x4*)((const unsigned char*)a.w + (size_t)widx * wtapB + ((co0 + crow(row)) * a.Cinp + ch * EPC) * (int)sizeof(T));
+      *(u32x4*)(ldsW + tap * NT * ROWB + swz(row, ch)) = v;
+    }
+  }
+  // tap table -> one VGPR (lane t = tap t): byte offset of the tap's window inside its unit's brick
+  int tapv;
+  {
+    const int tp = a.taps[lane];
+    const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8, un = (tp >> 18) & 7;
+    tapv = (((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LROWB;
+  }
+  int aoff[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) aoff[i] = swz(i * 16 + r16, g);
+  f32x4 acc[NS][VS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int j = 0; j < VS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1a[NS][4], s2a[NS][4];                          // statistics of the stored values, across all bricks of this workgroup
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s1a[i][q] = s2a[i][q] = 0.f;
+  f32x4 bia[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int co = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
+    bia[i] = (a.bias && co < a.Cout) ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int cchunk = (tid & 3) * EPC;
+  const int sdst = (tid >> 2) * LROWB + (tid & 3) * 16;
+  const size_t plane_elems = (size_t)a.Hi * a.Wi * a.Cin;
+  const bool cok = cchunk < a.Cin;
+  T* __restrict__ yg = (T*)a.y;
+  const int bpp = r.pbd * r.pbh * r.pbw;
+
+  // brick index -> sample, q origin, fmap patch (uniform)
+  auto decode = [&](int bi, int& b, int& q0d, int& q0h, int& q0w, int& pd, int& ph, int& pw) {
+    if (sparse) {
+      const int ai = bi / bpp, s_ = bi - ai * bpp;
+      const int pk = __builtin_amdgcn_readfirstlane(r.plist[ai]);
+      b = (pk >> 24) & 255; pd = (pk >> 16) & 255; ph = (pk >> 8) & 255; pw = pk & 255;
+      const int sd = s_ / (r.pbh * r.pbw), sh = (s_ / r.pbw) % r.pbh, sw = s_ % r.pbw;
+      q0d = pd * r.pq + sd * BD; q0h = ph * r.pq + sh * BH; q0w = pw * r.pq + sw * BW;
+    } else {
+      int t = bi;
+      const int bw_ = t % a.nbw; t /= a.nbw;
+      const int bh_ = t % a.nbh; t /= a.nbh;
+      const int bd_ = t % a.nbd; b = t / a.nbd;
+      q0d = bd_ * BD; q0h = bh_ * BH; q0w = bw_ * BW; pd = ph = pw = 0;
+    }
+  };
+  // mask byte of neighbour patch `lane` (3x3x3 around the brick's patch), 0 outside the patch grid
+  auto nb_byte = [&](int bi) -> int {
+    if (!sparse || bi >= b1) return 0;
+    int b, q0d, q0h, q0w, pd, ph, pw;
+    decode(bi, b, q0d, q0h, q0w, pd, ph, pw);
+    const int nd = pd + lane / 9 - 1, nh = ph + (lane / 3) % 3 - 1, nw = pw + lane % 3 - 1;
+    const bool ok = lane < 27 && (unsigned)nd < (unsigned)a.in_mask.fd && (unsigned)nh < (unsigned)a.in_mask.fh && (unsigned)nw < (unsigned)a.in_mask.fw;
+    return ok ? (int)a.in_mask.m[((b * a.in_mask.fd + nd) * a.in_mask.fh + nh) * a.in_mask.fw + nw] : 0;
+  };
+
+  u32x4 stg[NIT];
+  // staging plan of stage (brick bi, unit un) + issue of its loads into stg.  nbm: activity bits of the 27 neighbour patches.
+  auto plan_and_load = [&](int bi, int un, unsigned long long nbm) {
+    int b, q0d, q0h, q0w, pd, ph, pw;
+    decode(bi, b, q0d, q0h, q0w, pd, ph, pw);
+    const int EH = a.eh[un], EW = a.ew[un], nvox = a.ed[un] * EH * EW, EHW = EH * EW;
+    const int mW = a.mdiv_w[un], mHW = a.mdiv_hw[un];
+    const int upd = (a.upar[un] >> 2) & 1, uph = (a.upar[un] >> 1) & 1, upw = a.upar[un] & 1;
+    const int i0d = q0d + a.mind[un], i0h = q0h + a.minh[un], i0w = q0w + a.minw[un];
+    int dbase = i0d * a.GS + upd; dbase = dbase < 0 ? 0 : (dbase > a.Di ? a.Di : dbase);
+    const size_t left = (size_t)(a.Di - dbase) * plane_elems * sizeof(T);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((const T*)a.x + ((size_t)b * a.Di + dbase) * plane_elems), 0, (int)(left < 0x7fffff00ull ? left : 0x7fffff00ull), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = (tid >> 2) + it * RPI;
+      const int ez = (e * mHW) >> 20, rem = e - ez * EHW;
+      const int ey = (rem * mW) >> 20, ex = rem - ey * EW;
+      const int id = (i0d + ez) * a.GS + upd, ih = (i0h + ey) * a.GS + uph, iw = (i0w + ex) * a.GS + upw;
+      bool ok = cok && e < nvox && (unsigned)id < (unsigned)a.Di && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+      if (sparse) {
+        const int pidx = ((id >> ibs) - pd + 1) * 9 + ((ih >> ibs) - ph + 1) * 3 + ((iw >> ibs) - pw + 1);
+        ok = ok && ((nbm >> (pidx & 31)) & 1ull);
+      }
+      const unsigned off = ok ? (unsigned)(((((id - dbase) * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T)) : OOB;
+      stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+    }
+  };
+
+  if (b0 < b1) {
+    unsigned long long nbm_cur = __ballot(nb_byte(b0) != 0);
+    int mbyte = nb_byte(b0 + 1);                         // in flight: consumed one stage later
+    unsigned long long nbm_next = 0;
+    plan_and_load(b0, 0, nbm_cur);
+    int bi = b0, un = 0;
+    while (bi < b1) {
+      const int tb = a.tap_begin[un], nt = a.tap_begin[un + 1] - tb;
+      const int EH = a.eh[un], EW = a.ew[un], nvox = a.ed[un] * EH * EW;
+      __syncthreads();                                   // the previous stage's fragment reads are done
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+        if ((tid >> 2) + it * RPI < nvox) *(u32x4*)(lds + sdst + it * RPI * LROWB) = stg[it];
+      if (un == 0) {                                     // (the wait above covered the neighbour bytes fetched a stage ago)
+        nbm_next = __ballot(mbyte != 0);
+        mbyte = nb_byte(bi + 2);
+      }
+      __syncthreads();
+      // next stage's source rows fly while this stage's taps issue
+      {
+        int nbi = bi, nun = un + 1;
+        if (nun == a.nunit) { nun = 0; ++nbi; }
+        while (nbi < b1 && a.tap_begin[nun + 1] == a.tap_begin[nun]) { if (++nun == a.nunit) { nun = 0; ++nbi; } }   // (units without taps)
+        if (nbi < b1) plan_and_load(nbi, nun, nbi == bi ? nbm_cur : nbm_next);
+      }
+      int bb[VS];
+#pragma unroll
+      for (int j = 0; j < VS; ++j) {
+        const int v = wave * (MV / NW) + j * 16 + r16;
+        bb[j] = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * LROWB + g * 16;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (HR) {
+        // taps ordered in (d, w) runs of h = -1, 0, +1; subtile j = h-row j of this wave's d-plane: 6 fragment rows serve 3 taps
+        const int ewb = EW * LROWB;
+#pragma unroll
+        for (int tr = 0; tr < 9; ++tr) {
+          const int tob = __builtin_amdgcn_readlane(tapv, tr * 3);
+          u32x4 brow[VS + 2];
+#pragma unroll
+          for (int q = 0; q < VS + 2; ++q) brow[q] = *(const u32x4*)(lds + bb[0] + tob + q * ewb);
+#pragma unroll
+          for (int th = 0; th < 3; ++th) {
+            u32x4 af[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tr * 3 + th) * NT * ROWB + aoff[i]);
+#pragma unroll
+            for (int j = 0; j < VS; ++j)
+#pragma unroll
+              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], brow[j + th], acc[i][j]);
+          }
+        }
+      } else {
+        auto taps = [&](auto NTAP_) {
+          constexpr int NTAP = decltype(NTAP_)::value;
+#pragma unroll
+          for (int tl = 0; tl < NTAP; ++tl) {
+            const int tob = __builtin_amdgcn_readlane(tapv, tb + tl);
+            u32x4 af[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tb + tl) * NT * ROWB + aoff[i]);
+#pragma unroll
+            for (int j = 0; j < VS; ++j) {
+              const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
+#pragma unroll
+              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+            }
+          }
+        };
+        if (nt == 8) taps(std::integral_constant<int, 8>{});
+        else if (nt == 4) taps(std::integral_constant<int, 4>{});
+        else if (nt == 2) taps(std::integral_constant<int, 2>{});
+        else if (nt == 1) taps(std::integral_constant<int, 1>{});
+        else {
+          for (int tl = 0; tl < nt; ++tl) {              // any other count (27-tap single units without h-run layout)
+            const int tob = __builtin_amdgcn_readlane(tapv, tb + tl);
+            u32x4 af[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tb + tl) * NT * ROWB + aoff[i]);
+#pragma unroll
+            for (int j = 0; j < VS; ++j) {
+              const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
+#pragma unroll
+              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- last unit of the brick: epilogue ----
+      int nun = un + 1;
+      while (nun < a.nunit && a.tap_begin[nun + 1] == a.tap_begin[nun]) ++nun;
+      if (nun >= a.nunit) {
+        int b, q0d, q0h, q0w, pd, ph, pw;
+        decode(bi, b, q0d, q0h, q0w, pd, ph, pw);
+#pragma unroll
+        for (int j = 0; j < VS; ++j) {
+          const int v = wave * (MV / NW) + j * 16 + r16;
+          const int od = q0d + v / (BW * BH), oh = q0h + (v / BW) % BH, ow = q0w + v % BW;
+          const bool inr = od < a.Do && oh < a.Ho && ow < a.Wo;
+          const size_t ovox = ((size_t)(b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+          T* dstv = yg + ovox * a.Cout + co0 + g * 8;
+#pragma unroll
+          for (int h = 0; h < NS / 2; ++h) {
+            const f32x4 o0 = acc[2 * h][j] + bia[2 * h], o1 = acc[2 * h + 1][j] + bia[2 * h + 1];
+            const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout;
+            typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
+            typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+            const bfx4 p0 = __builtin_convertvector(o0, bfx4), p1 = __builtin_convertvector(o1, bfx4);
+            if (wr) *(bfx8*)(dstv + h * 32) = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+            const f32x4 q0 = __builtin_convertvector(p0, f32x4), q1 = __builtin_convertvector(p1, f32x4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (wr) { s1a[2 * h][q] += q0[q]; s2a[2 * h][q] += q0[q] * q0[q]; s1a[2 * h + 1][q] += q1[q]; s2a[2 * h + 1][q] += q1[q] * q1[q]; }
+            }
+            acc[2 * h][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[2 * h + 1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+        un = 0; ++bi; nbm_cur = nbm_next;
+        while (bi < b1 && a.tap_begin[un + 1] == a.tap_begin[un]) ++un;
+      } else {
+        un = nun;
+      }
+    }
+  }
+  // ---- ONE partials row per workgroup ----
+  if (a.partials) {
+    __syncthreads();
+    float* red = (float*)lds;                            // [NW waves][16*NS couts][2]
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float s1 = s1a[i][q], s2 = s2a[i][q];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        if (r16 == 0) {
+          const int c = (i >> 1) * 32 + g * 8 + (i & 1) * 4 + q;
+          red[(wave * 16 * NS + c) * 2] = s1; red[(wave * 16 * NS + c) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    if (tid < 16 * NS && co0 + tid < a.Cout) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { s1 += red[(w * 16 * NS + tid) * 2]; s2 += red[(w * 16 * NS + tid) * 2 + 1]; }
+      float* part = a.partials + ((size_t)blockIdx.x * a.Cout + co0 + tid) * 2;
+      part[0] = s1; part[1] = s2;
+    }
+  }
+}
+
+// which shapes qualify, and with what geometry
+struct RwGeo { int nw, bd, bh, bw, nt_tile, nwg, nbrick, pbd, pbh, pbw, pq; bool hr; };
+
+bool rw_geometry(RwGeo& G, int mode, int dtype, int k, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, bool sparse, int out_bshift,
+                 int n_active) {
+  if (dtype != AM_DT_BF16 || k != 3 || Cin > 32 || Cin % 8 || Cout > 64 || Cout % 8) return false;
+  const bool s1 = stride == 1 && (mode == AM_CONV_FWD || mode == AM_CONV_DGRAD);
+  const bool s2 = stride == 2 && mode == AM_CONV_FWD;
+  if (!s1 && !s2) return false;
+  G.nt_tile = Cout <= 32 ? 32 : 64;
+  const int patch = sparse ? (1 << out_bshift) : 0;
+  if (s1) {                                              // 27 taps, one unit: h-run layout, wave = one 4x16 d-plane
+    if (G.nt_tile != 32) return false;                   // 27 x 64 x 64 B of weights + an 8x4x16 brick do not fit; 4 waves measured no gain
+    if (sparse && patch != 16) return false;
+    if (Wo % 16 || Ho % 4 || Do % 8) return false;
+    G.nw = 8; G.bd = 8; G.bh = 4; G.bw = 16; G.hr = true;
+  } else {                                               // 8 parity sub-lattices of the fine grid
+    if (sparse && patch != 8) return false;
+    if (Wo % 8 || Ho % 8 || Do % 4) return false;
+    G.nw = 4; G.bd = 4; G.bh = 8; G.bw = 8; G.hr = false;
+  }
+  if (sparse) {
+    if (n_active <= 0) return false;
+    G.pq = patch; G.pbd = patch / G.bd; G.pbh = patch / G.bh; G.pbw = patch / G.bw;
+    G.nbrick = n_active * G.pbd * G.pbh * G.pbw;
+  } else {
+    G.pq = 0; G.pbd = G.pbh = G.pbw = 1;
+    G.nbrick = B * (Do / G.bd) * (Ho / G.bh) * (Wo / G.bw);
+  }
+  const int slices = (Cout + G.nt_tile - 1) / G.nt_tile;
+  int nwg = 256 / slices; if (nwg < 1) nwg = 1;            // one persistent workgroup per CU (LDS: weights + brick > 80 KB)
+  if (nwg > G.nbrick) nwg = G.nbrick;
+  G.nwg = nwg;
+  return G.nbrick > 0;
+}
+
+template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR>
+int rw_launch(ConvArgs& a, RwArgs& r, const RwGeo& G, size_t lds, hipStream_t st) {
+  auto kern = conv_rw_kernel<NW, BD, BH, BW, NS, NIT, HR>;
+  static std::once_flag lds_cap;
+  std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  dim3 grid(G.nwg, (a.Cout + 16 * NS - 1) / (16 * NS), 1);
+  AM_LAUNCH(kern, grid, dim3(NW * 64), lds, st, a, r);
+  AM_CHECK_LAUNCH();
+  return 1;
+}
+
+}  // namespace
+
+namespace amconv {
+
+int conv_rw_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, int out_sparse, int out_bshift,
+                 int n_active) {
+  RwGeo G;
+  return rw_geometry(G, mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse != 0, out_bshift, n_active) ? G.nwg : 0;
+}
+
+int conv_rw_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, const int* active_list, int n_active, void* stream) {
+  const bool sparse = a0.out_mask.m != nullptr;
+  if (sparse != (a0.in_mask.m != nullptr) || (sparse && a0.in_mask.m != a0.out_mask.m)) return 0;
+  if (a0.accumulate || a0.ep_scale || a0.ep_res || a0.ep_act != AM_ACT_NONE) return 0;
+  if (sparse && !active_list) return 0;
+  RwGeo G;
+  if (!rw_geometry(G, mode, dtype, ksize, stride, a0.B, a0.Do, a0.Ho, a0.Wo, a0.Cin, a0.Cout, sparse, a0.out_mask.bs, n_active)) return 0;
+  if (sparse) {                                          // the source halo must stay inside the 3x3x3 patch neighbourhood
+    const int in_patch = 1 << a0.in_mask.bs;
+    if (in_patch < 4 || (in_patch != (1 << a0.out_mask.bs) * (mode == AM_CONV_FWD ? stride : 1))) return 0;
+  }
+  Plan P;
+  P.a = a0;
+  P.bd = G.bd; P.bh = G.bh; P.bw = G.bw; P.nt_tile = G.nt_tile;
+  const int rc = build_plan(P, mode, ksize, stride);
+  if (rc) return rc;
+  ConvArgs& a = P.a;
+  if (G.hr && !a.hreuse) return 0;
+  int ntaps = a.tap_begin[a.nunit];
+  size_t mxv = 0;
+  for (int c = 0; c < a.nunit; ++c) { const size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
+  size_t brick = mxv * LROWB;
+  if (brick < 8192) brick = 8192;                        // the statistics fold reuses the head of the brick
+  a.w_lds_off = (int)brick;
+  const size_t lds = brick + (size_t)ntaps * G.nt_tile * ROWB;
+  if (lds > 160 * 1024) return 0;
+  const int nit = (int)((mxv * 4 + G.nw * 64 - 1) / (G.nw * 64));
+  a.nbd = a.Do / G.bd; a.nbh = a.Ho / G.bh; a.nbw = a.Wo / G.bw;
+  RwArgs r;
+  r.plist = sparse ? active_list : nullptr; r.nbrick = G.nbrick; r.pbd = G.pbd; r.pbh = G.pbh; r.pbw = G.pbw; r.pq = G.pq; r.ntaps = ntaps;
+  hipStream_t st = (hipStream_t)stream;
+  if (G.hr) {                                            // 8x4x16 brick, haloed 10x6x18 = 1080 rows -> 9 staging iterations of 128 rows
+    if (nit > 9) return 0;
+    return rw_launch<8, 8, 4, 16, 2, 9, true>(a, r, G, lds, st);
+  }
+  if (nit > 7) return 0;                                 // 4x8x8 brick, sub-lattice sub-bricks of <= 5x9x9 = 405 rows -> 7 iterations of 64 rows
+  return G.nt_tile == 32 ? rw_launch<4, 4, 8, 8, 2, 7, false>(a, r, G, lds, st) : rw_launch<4, 4, 8, 8, 4, 7, false>(a, r, G, lds, st);
+}
+
+}  // namespace amconv

@@ -82,10 +82,10 @@ def packed_dims(dtype: torch.dtype, rows: int, k: int):
 class ConvPartials:
     """Per-workgroup per-channel (sum, sumsq) rows a conv launch leaves behind for the norm / bias-grad that follows."""
 
-    def __init__(self, mode, ksize, stride, B, out_spatial, cout, device, out_sparse=False, out_bshift=0):
+    def __init__(self, mode, ksize, stride, B, out_spatial, cout, device, out_sparse=False, out_bshift=0, dtype=hip.DT_F32, cin=64, n_active=0):
         import ctypes
         n = ctypes.c_int(0)
-        hip.lib().conv3d_partials_rows(mode, ksize, stride, B, *out_spatial, cout, int(out_sparse), out_bshift, ctypes.addressof(n))
+        hip.lib().conv3d_partials_rows(mode, dtype, ksize, stride, B, *out_spatial, cin, cout, int(out_sparse), out_bshift, n_active, ctypes.addressof(n))
         self.rows, self.C = n.value, cout
         self.t = torch.empty(self.rows, cout, 2, device=device, dtype=torch.float32)
 
@@ -117,6 +117,12 @@ def _stats_workspace(device, C: int) -> torch.Tensor:
     if ws is None or ws.numel() < 2 * C + 2:
         ws = _WS[key] = torch.zeros(2 * max(C, 2048) + 2, device=device, dtype=torch.float64)
     return ws
+
+
+import ctypes as _ct
+
+_ROWS_OUT = _ct.c_int(0)
+_ROWS_ADDR = _ct.addressof(_ROWS_OUT)
 
 
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_dgrad: bool) -> torch.Tensor:
@@ -183,17 +189,22 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     Cout, Kl = w_packed.logical
     assert Kl == Cin and w_packed.dtype == x.dtype, (w_packed.logical, x.shape)
     Do, Ho, Wo = out_spatial
-    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift) if want_partials else None
-    if out is None:
-        out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
     mk = in_mask or out_mask
     mp, fd, fh, fw = _mk(mk)
+    # thin block-sparse layers (Cin <= 32) run on the resident-weight kernel, which walks the active-patch list
+    alp, aln = _al(out_mask) if (out_mask is not None and out_mask is in_mask and Cin <= 32 and x.dtype == torch.bfloat16) else (None, 0)
+    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift, _dt(x), Cin, aln) if want_partials else None
+    if out is None:
+        out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
+    rows = _ROWS_OUT
     hip.lib().conv3d(mode, _dt(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
                      B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
                      in_mask.t.data_ptr() if in_mask else None, in_bshift,
                      out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate),
                      part.t.data_ptr() if part else None, _p(ep_scale), _p(ep_shift),
-                     ep_res.data_ptr() if ep_res is not None else None, int(ep_act), _stream())
+                     ep_res.data_ptr() if ep_res is not None else None, int(ep_act), alp, aln, _ROWS_ADDR if part else None, _stream())
+    if part is not None:
+        part.rows = rows.value                                   # what this launch actually wrote (<= the allocated bound)
     return (out, part) if want_partials else out
 
 

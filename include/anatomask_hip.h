@@ -53,10 +53,15 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               const float* ep_scale, const float* ep_shift /* NULL or [Cout]: y = conv * scale + shift -- an eval-mode BatchNorm
               (running statistics, the EMA teacher's decoder: P/decoder3D.py:20-22 under model_ema.ema.eval()) folded into the store */,
               const void* ep_res /* NULL or a tensor shaped like y that is added (x = x + to_dec[i], P/decoder3D.py:59) */,
-              int ep_act /* AM_ACT_*: applied last */, void* stream);
+              int ep_act /* AM_ACT_*: applied last */,
+              const int32_t* active_list, int n_active /* am_mask_compact of the patch mask, or NULL / 0: lets thin block-sparse layers
+              (Cin <= 32) run on persistent workgroups that walk only the active bricks with all weights resident in LDS */,
+              int* partial_rows_written /* NULL or (host) the number of partials rows this launch wrote (<= am_conv3d_partials_rows) */,
+              void* stream);
 int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded);
-int am_conv3d_partials_rows(int mode, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cout,
-                            int out_sparse, int out_bshift /* the launch's out_mask != NULL and its block shift: they select the brick */, int* rows);
+int am_conv3d_partials_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout,
+                            int out_sparse, int out_bshift /* the launch's out_mask != NULL and its block shift: they select the brick */,
+                            int n_active, int* rows /* upper bound: size the partials buffer with it */);
 /* partials [rows][C][2] -> sums[C][2] (double, overwritten; may be NULL) and/or sum_accum[C] += sum (may be NULL) */
 int am_partials_reduce(const float* partials, int rows, int C, double* sums, float* sum_accum, void* stream);
 

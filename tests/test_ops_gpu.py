@@ -534,3 +534,78 @@ def test_abi_rejects_bad_arguments(ops):
         ops.conv3d_wgrad(ops.CONV_FWD, x16, x16, 5, 1)
     with pytest.raises(RuntimeError, match="am_stem_conv_fwd failed with code -2"):   # the stem kernels need the 16^3 patch mask
         ops.stem_conv_fwd(torch.zeros(1, 16, 16, 16, device=DEV), torch.zeros(16, 1, 3, 3, 3, device=DEV), None, None, 4, torch.bfloat16)
+
+
+# ------------------------------------------------------------------ resident-weight kernel for thin block-sparse layers (conv_rw.hip)
+@pytest.mark.parametrize("case", [(32, 32), (16, 24), (8, 32)])
+@pytest.mark.parametrize("sparse", [True, False])
+def test_conv_rw_k3_s1_level0(ops, case, sparse):
+    """STUNet stage-0 conv2 shape family (Cin, Cout <= 32, k3 s1, 16^3 patches, bf16): the persistent resident-weight kernel walking
+    the active-patch list -- forward (+ statistics partials) and data gradient vs F.conv3d-then-mask (P/encoder3D.py:12-15)."""
+    dtype = torch.bfloat16
+    cin, cout = case
+    B, f, bs = 2, (1, 2, 3), 4
+    so = tuple(v << bs for v in f)               # (16, 32, 48)
+    x = q(rnd(B, cin, *so, seed=41), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=42, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    bias = rnd(cout, seed=43)
+    dy = q(rnd(B, cout, *so, seed=44), dtype)
+    mask = mk_mask(B, f, 3, seed=5) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    mo = O.upsample_mask(mask, so).float() if sparse else None
+    if sparse:
+        x, dy = x * mo, dy * mo
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv3d(xr, w, bias, padding=1)
+    if sparse:
+        yr = yr * mo
+    yr.backward(dy)
+    wp = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=False)
+    xd = to_cl(x, dtype)
+    if sparse:                                   # inactive voxels may hold anything: the kernel must never read them
+        xd = torch.where(to_cl(mo.expand_as(x), dtype) > 0, xd, torch.full_like(xd, float("nan")))
+    y, part = ops.conv3d(ops.CONV_FWD, xd, wp, bias.to(DEV), so, 3, 1, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs, want_partials=True)
+    assert part.rows <= 256                      # ONE row per persistent workgroup (the generic kernel leaves one per brick)
+    close(from_cl(y), yr.detach(), TOL[dtype], "rw conv fwd", mo)
+    st_a, st_b = ops.NormStats(cout, DEV), ops.NormStats(cout, DEV)
+    part.reduce(sums=st_a.sums)
+    ops.chan_stats(y, mi, bs if sparse else 0, st_b)
+    ref = st_b.sums.cpu().sum(0)
+    assert (st_a.sums.cpu()[0] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    wpd = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=True)
+    dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), wpd, None, so, 3, 1, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs)
+    close(from_cl(dx), xr.grad, TOL[dtype], "rw conv dgrad", mo)
+
+
+@pytest.mark.parametrize("case", [(32, 64), (16, 40), (32, 32)])
+@pytest.mark.parametrize("sparse", [True, False])
+def test_conv_rw_k3_s2_level1(ops, case, sparse):
+    """STUNet stage-1 conv1 shape family (Cin <= 32 -> Cout <= 64, k3 stride 2, fine 16^3 -> coarse 8^3 patches, bf16): eight parity
+    sub-lattice units per brick on the resident-weight kernel."""
+    dtype = torch.bfloat16
+    cin, cout = case
+    B, f = 2, (2, 1, 3)
+    si, so = tuple(v * 16 for v in f), tuple(v * 8 for v in f)
+    x = q(rnd(B, cin, *si, seed=51), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=52, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    bias = rnd(cout, seed=53)
+    mask = mk_mask(B, f, 3, seed=6) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    if sparse:
+        x = x * O.upsample_mask(mask, si).float()
+    yr = F.conv3d(x, w, bias, stride=2, padding=1)
+    mo = O.upsample_mask(mask, so).float() if sparse else None
+    if sparse:
+        yr = yr * mo
+    wp = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=False)
+    xd = to_cl(x, dtype)
+    if sparse:
+        xd = torch.where(to_cl(O.upsample_mask(mask, si).float().expand_as(x), dtype) > 0, xd, torch.full_like(xd, float("nan")))
+    y, part = ops.conv3d(ops.CONV_FWD, xd, wp, bias.to(DEV), so, 3, 2, in_mask=mi, in_bshift=4, out_mask=mi, out_bshift=3, want_partials=True)
+    assert part.rows <= 256
+    close(from_cl(y), yr, TOL[dtype], "rw conv s2 fwd", mo)
+    st_a, st_b = ops.NormStats(cout, DEV), ops.NormStats(cout, DEV)
+    part.reduce(sums=st_a.sums)
+    ops.chan_stats(y, mi, 3 if sparse else 0, st_b)
+    ref = st_b.sums.cpu().sum(0)
+    assert (st_a.sums.cpu()[0] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
