@@ -454,6 +454,10 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
     a.in_mask = MaskView{in_mask, fd, fh, fw, in_bshift};
     a.out_mask = MaskView{out_mask, fd, fh, fw, out_bshift};
     a.accumulate = accumulate; a.nt_store = 0; a.brick_in_patch = 0; a.hreuse = 0;
+#ifdef AM_ABLATE
+    { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
+    if (getenv("AM_CV_NORW")) goto generic;
+#endif
     const int rc = conv_rw_launch(mode, dtype, ksize, stride, a, active_list, n_active, stream);
     if (rc < 0) return rc;
     if (rc == 1) {
@@ -461,6 +465,9 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
       return 0;
     }
   }
+#ifdef AM_ABLATE
+generic:
+#endif
   const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
   int shape = brick_shape(os_, (Wo + os_ - 1) / os_, out_mask != nullptr, out_bshift, &P.bd, &P.bh, &P.bw);
   P.nt_tile = Cout <= 32 ? 32 : 64;

@@ -36,7 +36,7 @@ typedef bf16_t T;
 constexpr int EPC = 8;
 constexpr unsigned OOB = 0x80000000u;
 
-template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR>
+template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR, int LR>
 __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) {
   constexpr int NTH = NW * 64;
   constexpr int MV = BD * BH * BW;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
   {
     const int tp = a.taps[lane];
     const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8, un = (tp >> 18) & 7;
-    tapv = (((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LROWB;
+    tapv = (((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LR;
   }
   int aoff[NS];
 #pragma unroll
@@ -96,43 +96,61 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
     bia[i] = (a.bias && co < a.Cout) ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const int cchunk = (tid & 3) * EPC;
-  const int sdst = (tid >> 2) * LROWB + (tid & 3) * 16;
+  const int sdst = (tid >> 2) * LR + (tid & 3) * 16;
   const size_t plane_elems = (size_t)a.Hi * a.Wi * a.Cin;
   const bool cok = cchunk < a.Cin;
   T* __restrict__ yg = (T*)a.y;
   const int bpp = r.pbd * r.pbh * r.pbw;
 
-  // brick index -> sample, q origin, fmap patch (uniform)
-  auto decode = [&](int bi, int& b, int& q0d, int& q0h, int& q0w, int& pd, int& ph, int& pw) {
+  // ---- brick table of this workgroup (LDS, built once): sample, q origin, fmap patch, activity bits of the 27 neighbour patches.
+  // Decoding a brick index takes runtime integer divisions, and the CU's single scalar unit executing them three times per stage for
+  // eight waves was the largest cost of this kernel's skeleton (tools/rw_ablate.py); the stages only read the table.
+  int* tbl = (int*)(ldsW + r.ntaps * NT * ROWB);
+  for (int i = tid; i < b1 - b0; i += NTH) {
+    const int bi = b0 + i;
+    int b, q0d, q0h, q0w, pd = 0, ph = 0, pw = 0, nbm = 0;
     if (sparse) {
       const int ai = bi / bpp, s_ = bi - ai * bpp;
-      const int pk = __builtin_amdgcn_readfirstlane(r.plist[ai]);
+      const int pk = r.plist[ai];
       b = (pk >> 24) & 255; pd = (pk >> 16) & 255; ph = (pk >> 8) & 255; pw = pk & 255;
       const int sd = s_ / (r.pbh * r.pbw), sh = (s_ / r.pbw) % r.pbh, sw = s_ % r.pbw;
       q0d = pd * r.pq + sd * BD; q0h = ph * r.pq + sh * BH; q0w = pw * r.pq + sw * BW;
+      for (int l = 0; l < 27; ++l) {
+        const int nd = pd + l / 9 - 1, nh = ph + (l / 3) % 3 - 1, nw = pw + l % 3 - 1;
+        const bool ok = (unsigned)nd < (unsigned)a.in_mask.fd && (unsigned)nh < (unsigned)a.in_mask.fh && (unsigned)nw < (unsigned)a.in_mask.fw;
+        if (ok && a.in_mask.m[((b * a.in_mask.fd + nd) * a.in_mask.fh + nh) * a.in_mask.fw + nw]) nbm |= 1 << l;
+      }
     } else {
       int t = bi;
       const int bw_ = t % a.nbw; t /= a.nbw;
       const int bh_ = t % a.nbh; t /= a.nbh;
       const int bd_ = t % a.nbd; b = t / a.nbd;
-      q0d = bd_ * BD; q0h = bh_ * BH; q0w = bw_ * BW; pd = ph = pw = 0;
+      q0d = bd_ * BD; q0h = bh_ * BH; q0w = bw_ * BW;
     }
-  };
-  // mask byte of neighbour patch `lane` (3x3x3 around the brick's patch), 0 outside the patch grid
-  auto nb_byte = [&](int bi) -> int {
-    if (!sparse || bi >= b1) return 0;
-    int b, q0d, q0h, q0w, pd, ph, pw;
-    decode(bi, b, q0d, q0h, q0w, pd, ph, pw);
-    const int nd = pd + lane / 9 - 1, nh = ph + (lane / 3) % 3 - 1, nw = pw + lane % 3 - 1;
-    const bool ok = lane < 27 && (unsigned)nd < (unsigned)a.in_mask.fd && (unsigned)nh < (unsigned)a.in_mask.fh && (unsigned)nw < (unsigned)a.in_mask.fw;
-    return ok ? (int)a.in_mask.m[((b * a.in_mask.fd + nd) * a.in_mask.fh + nh) * a.in_mask.fw + nw] : 0;
+    int* e = tbl + i * 8;
+    e[0] = b; e[1] = q0d; e[2] = q0h; e[3] = q0w; e[4] = pd | (ph << 8) | (pw << 16); e[5] = nbm;
+  }
+  __syncthreads();
+  // table entry of brick bi -> scalars
+  auto fetch = [&](int bi, int& b, int& q0d, int& q0h, int& q0w, int& pd, int& ph, int& pw, int& nbm) {
+    const int* e = tbl + (bi - b0) * 8;
+    const int p = __builtin_amdgcn_readfirstlane(e[4]);
+    b = __builtin_amdgcn_readfirstlane(e[0]); q0d = __builtin_amdgcn_readfirstlane(e[1]); q0h = __builtin_amdgcn_readfirstlane(e[2]);
+    q0w = __builtin_amdgcn_readfirstlane(e[3]); nbm = __builtin_amdgcn_readfirstlane(e[5]);
+    pd = p & 255; ph = (p >> 8) & 255; pw = (p >> 16) & 255;
   };
 
-  u32x4 stg[NIT];
+  // Source rows travel global -> registers -> LDS; TWO register sets alternate so that the rows of stage s+2 are requested while
+  // stage s computes (one stage of cover -- a few hundred to 3 500 cycles -- does not hide an HBM round trip under load).
+  u32x4 stgA[NIT], stgB[NIT];
   // staging plan of stage (brick bi, unit un) + issue of its loads into stg.  nbm: activity bits of the 27 neighbour patches.
-  auto plan_and_load = [&](int bi, int un, unsigned long long nbm) {
-    int b, q0d, q0h, q0w, pd, ph, pw;
-    decode(bi, b, q0d, q0h, q0w, pd, ph, pw);
+  // `valid` = false (past the last stage): the same number of loads is issued, all out of range (zeros, no traffic) -- the
+  // compiler counts vector-memory operations statically, and a CONDITIONAL prefetch makes it wait for everything in flight.
+  auto plan_and_load = [&](u32x4 (&stg)[NIT], int bi_, int un_, bool valid) {
+    // everything that shapes the stage is wave-uniform: say so (scalar registers, scalar buffer descriptor)
+    const int bi = __builtin_amdgcn_readfirstlane(valid ? bi_ : b0), un = __builtin_amdgcn_readfirstlane(valid ? un_ : 0);
+    int b, q0d, q0h, q0w, pd, ph, pw, nbm;
+    fetch(bi, b, q0d, q0h, q0w, pd, ph, pw, nbm);
     const int EH = a.eh[un], EW = a.ew[un], nvox = a.ed[un] * EH * EW, EHW = EH * EW;
     const int mW = a.mdiv_w[un], mHW = a.mdiv_hw[un];
     const int upd = (a.upar[un] >> 2) & 1, uph = (a.upar[un] >> 1) & 1, upw = a.upar[un] & 1;
@@ -147,10 +165,11 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
       const int ez = (e * mHW) >> 20, rem = e - ez * EHW;
       const int ey = (rem * mW) >> 20, ex = rem - ey * EW;
       const int id = (i0d + ez) * a.GS + upd, ih = (i0h + ey) * a.GS + uph, iw = (i0w + ex) * a.GS + upw;
-      bool ok = cok && e < nvox && (unsigned)id < (unsigned)a.Di && (unsigned)ih < (unsigned)a.Hi && (unsigned)iw < (unsigned)a.Wi;
+      // branch-free (bitwise &, not &&: the short-circuit form compiles to an exec-mask branch in front of every load)
+      bool ok = valid & !AM_DBG(a, 2) & cok & (e < nvox) & ((unsigned)id < (unsigned)a.Di) & ((unsigned)ih < (unsigned)a.Hi) & ((unsigned)iw < (unsigned)a.Wi);
       if (sparse) {
         const int pidx = ((id >> ibs) - pd + 1) * 9 + ((ih >> ibs) - ph + 1) * 3 + ((iw >> ibs) - pw + 1);
-        ok = ok && ((nbm >> (pidx & 31)) & 1ull);
+        ok = ok & (((nbm >> (pidx & 31)) & 1) != 0);
       }
       const unsigned off = ok ? (unsigned)(((((id - dbase) * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T)) : OOB;
       stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
@@ -158,129 +177,131 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
   };
 
   if (b0 < b1) {
-    unsigned long long nbm_cur = __ballot(nb_byte(b0) != 0);
-    int mbyte = nb_byte(b0 + 1);                         // in flight: consumed one stage later
-    unsigned long long nbm_next = 0;
-    plan_and_load(b0, 0, nbm_cur);
+    // Pipeline state lives in plain locals and the stage body is a macro expanded once per register set: a lambda that mutates
+    // captured state sends that state to scratch memory, and scratch traffic shares the vector-memory counter with the prefetches
+    // (every scratch read would drain them).
+    // stage cursor: (brick, unit), skipping units without taps
+#define AM_RW_FIRST(UN_) while ((UN_) < a.nunit && a.tap_begin[(UN_) + 1] == a.tap_begin[(UN_)]) ++(UN_);
+#define AM_RW_ADVANCE(BI_, UN_) { ++(UN_); AM_RW_FIRST(UN_) if ((UN_) >= a.nunit) { (UN_) = 0; AM_RW_FIRST(UN_) ++(BI_); } }
     int bi = b0, un = 0;
+    AM_RW_FIRST(un)
+    int bi1 = bi, un1 = un; AM_RW_ADVANCE(bi1, un1)     // stage s+1
+    int bi2 = bi1, un2 = un1; AM_RW_ADVANCE(bi2, un2)   // stage s+2
+    plan_and_load(stgA, bi, un, true);
+    plan_and_load(stgB, bi1, un1, bi1 < b1);
+#define AM_RW_STAGE(STG) \
+    { \
+      bi = __builtin_amdgcn_readfirstlane(bi); un = __builtin_amdgcn_readfirstlane(un); \
+      const int tb = a.tap_begin[un], nt = a.tap_begin[un + 1] - tb; \
+      const int EH = a.eh[un], EW = a.ew[un], nvox = a.ed[un] * EH * EW; \
+      __syncthreads(); \
+_Pragma("unroll") \
+      for (int it = 0; it < NIT; ++it) \
+        if ((tid >> 2) + it * RPI < nvox) *(u32x4*)(lds + sdst + it * RPI * LR) = STG[it]; \
+      __syncthreads(); \
+      plan_and_load(STG, bi2, un2, bi2 < b1); \
+      int bb[VS]; \
+_Pragma("unroll") \
+      for (int j = 0; j < VS; ++j) { \
+        const int v = wave * (MV / NW) + j * 16 + r16; \
+        bb[j] = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * LR + g * 16; \
+      } \
+      __builtin_amdgcn_sched_barrier(0); \
+      if (AM_DBG(a, 4)) { } else if constexpr (HR) { \
+        const int ewb = EW * LR; \
+_Pragma("unroll") \
+        for (int tr = 0; tr < 9; ++tr) { \
+          const int tob = __builtin_amdgcn_readlane(tapv, tr * 3); \
+          u32x4 brow[VS + 2]; \
+_Pragma("unroll") \
+          for (int q = 0; q < VS + 2; ++q) brow[q] = *(const u32x4*)(lds + bb[0] + tob + q * ewb); \
+_Pragma("unroll") \
+          for (int th = 0; th < 3; ++th) { \
+            u32x4 af[NS]; \
+_Pragma("unroll") \
+            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tr * 3 + th) * NT * ROWB + aoff[i]); \
+_Pragma("unroll") \
+            for (int j = 0; j < VS; ++j) \
+_Pragma("unroll") \
+              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], brow[j + th], acc[i][j]); \
+          } \
+        } \
+      } else { \
+        auto taps = [&](auto NTAP_) { \
+          constexpr int NTAP = decltype(NTAP_)::value; \
+_Pragma("unroll") \
+          for (int tl = 0; tl < NTAP; ++tl) { \
+            const int tob = __builtin_amdgcn_readlane(tapv, tb + tl); \
+            u32x4 af[NS]; \
+_Pragma("unroll") \
+            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tb + tl) * NT * ROWB + aoff[i]); \
+_Pragma("unroll") \
+            for (int j = 0; j < VS; ++j) { \
+              const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob); \
+_Pragma("unroll") \
+              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]); \
+            } \
+          } \
+        }; \
+        if (nt == 8) taps(std::integral_constant<int, 8>{}); \
+        else if (nt == 4) taps(std::integral_constant<int, 4>{}); \
+        else if (nt == 2) taps(std::integral_constant<int, 2>{}); \
+        else if (nt == 1) taps(std::integral_constant<int, 1>{}); \
+        else { \
+          for (int tl = 0; tl < nt; ++tl) { \
+            const int tob = __builtin_amdgcn_readlane(tapv, tb + tl); \
+            u32x4 af[NS]; \
+_Pragma("unroll") \
+            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tb + tl) * NT * ROWB + aoff[i]); \
+_Pragma("unroll") \
+            for (int j = 0; j < VS; ++j) { \
+              const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob); \
+_Pragma("unroll") \
+              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]); \
+            } \
+          } \
+        } \
+      } \
+      __builtin_amdgcn_sched_barrier(0); \
+      if (bi1 != bi) { \
+        int b, q0d, q0h, q0w, pd, ph, pw, nbm_; \
+        fetch(bi, b, q0d, q0h, q0w, pd, ph, pw, nbm_); \
+_Pragma("unroll") \
+        for (int j = 0; j < VS; ++j) { \
+          const int v = wave * (MV / NW) + j * 16 + r16; \
+          const int od = q0d + v / (BW * BH), oh = q0h + (v / BW) % BH, ow = q0w + v % BW; \
+          const bool inr = od < a.Do && oh < a.Ho && ow < a.Wo; \
+          const size_t ovox = ((size_t)(b * a.Do + od) * a.Ho + oh) * a.Wo + ow; \
+          T* dstv = yg + ovox * a.Cout + co0 + g * 8; \
+_Pragma("unroll") \
+          for (int h = 0; h < NS / 2; ++h) { \
+            const f32x4 o0 = acc[2 * h][j] + bia[2 * h], o1 = acc[2 * h + 1][j] + bia[2 * h + 1]; \
+            const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout; \
+            typedef __attribute__((ext_vector_type(4))) __bf16 bfx4; \
+            typedef __attribute__((ext_vector_type(8))) __bf16 bfx8; \
+            const bfx4 p0 = __builtin_convertvector(o0, bfx4), p1 = __builtin_convertvector(o1, bfx4); \
+            if (wr && !AM_DBG(a, 1)) *(bfx8*)(dstv + h * 32) = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7); \
+            const f32x4 q0 = __builtin_convertvector(p0, f32x4), q1 = __builtin_convertvector(p1, f32x4); \
+_Pragma("unroll") \
+            for (int q = 0; q < 4; ++q) { \
+              if (wr) { s1a[2 * h][q] += q0[q]; s2a[2 * h][q] += q0[q] * q0[q]; s1a[2 * h + 1][q] += q1[q]; s2a[2 * h + 1][q] += q1[q] * q1[q]; } \
+            } \
+            acc[2 * h][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[2 * h + 1][j] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+          } \
+        } \
+      } \
+      bi = bi1; un = un1; bi1 = bi2; un1 = un2; \
+      if (bi2 < b1) { AM_RW_ADVANCE(bi2, un2); } \
+    } \
+
     while (bi < b1) {
-      const int tb = a.tap_begin[un], nt = a.tap_begin[un + 1] - tb;
-      const int EH = a.eh[un], EW = a.ew[un], nvox = a.ed[un] * EH * EW;
-      __syncthreads();                                   // the previous stage's fragment reads are done
-#pragma unroll
-      for (int it = 0; it < NIT; ++it)
-        if ((tid >> 2) + it * RPI < nvox) *(u32x4*)(lds + sdst + it * RPI * LROWB) = stg[it];
-      if (un == 0) {                                     // (the wait above covered the neighbour bytes fetched a stage ago)
-        nbm_next = __ballot(mbyte != 0);
-        mbyte = nb_byte(bi + 2);
-      }
-      __syncthreads();
-      // next stage's source rows fly while this stage's taps issue
-      {
-        int nbi = bi, nun = un + 1;
-        if (nun == a.nunit) { nun = 0; ++nbi; }
-        while (nbi < b1 && a.tap_begin[nun + 1] == a.tap_begin[nun]) { if (++nun == a.nunit) { nun = 0; ++nbi; } }   // (units without taps)
-        if (nbi < b1) plan_and_load(nbi, nun, nbi == bi ? nbm_cur : nbm_next);
-      }
-      int bb[VS];
-#pragma unroll
-      for (int j = 0; j < VS; ++j) {
-        const int v = wave * (MV / NW) + j * 16 + r16;
-        bb[j] = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * LROWB + g * 16;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (HR) {
-        // taps ordered in (d, w) runs of h = -1, 0, +1; subtile j = h-row j of this wave's d-plane: 6 fragment rows serve 3 taps
-        const int ewb = EW * LROWB;
-#pragma unroll
-        for (int tr = 0; tr < 9; ++tr) {
-          const int tob = __builtin_amdgcn_readlane(tapv, tr * 3);
-          u32x4 brow[VS + 2];
-#pragma unroll
-          for (int q = 0; q < VS + 2; ++q) brow[q] = *(const u32x4*)(lds + bb[0] + tob + q * ewb);
-#pragma unroll
-          for (int th = 0; th < 3; ++th) {
-            u32x4 af[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tr * 3 + th) * NT * ROWB + aoff[i]);
-#pragma unroll
-            for (int j = 0; j < VS; ++j)
-#pragma unroll
-              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], brow[j + th], acc[i][j]);
-          }
-        }
-      } else {
-        auto taps = [&](auto NTAP_) {
-          constexpr int NTAP = decltype(NTAP_)::value;
-#pragma unroll
-          for (int tl = 0; tl < NTAP; ++tl) {
-            const int tob = __builtin_amdgcn_readlane(tapv, tb + tl);
-            u32x4 af[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tb + tl) * NT * ROWB + aoff[i]);
-#pragma unroll
-            for (int j = 0; j < VS; ++j) {
-              const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
-#pragma unroll
-              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
-            }
-          }
-        };
-        if (nt == 8) taps(std::integral_constant<int, 8>{});
-        else if (nt == 4) taps(std::integral_constant<int, 4>{});
-        else if (nt == 2) taps(std::integral_constant<int, 2>{});
-        else if (nt == 1) taps(std::integral_constant<int, 1>{});
-        else {
-          for (int tl = 0; tl < nt; ++tl) {              // any other count (27-tap single units without h-run layout)
-            const int tob = __builtin_amdgcn_readlane(tapv, tb + tl);
-            u32x4 af[NS];
-#pragma unroll
-            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + (tb + tl) * NT * ROWB + aoff[i]);
-#pragma unroll
-            for (int j = 0; j < VS; ++j) {
-              const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
-#pragma unroll
-              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
-            }
-          }
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- last unit of the brick: epilogue ----
-      int nun = un + 1;
-      while (nun < a.nunit && a.tap_begin[nun + 1] == a.tap_begin[nun]) ++nun;
-      if (nun >= a.nunit) {
-        int b, q0d, q0h, q0w, pd, ph, pw;
-        decode(bi, b, q0d, q0h, q0w, pd, ph, pw);
-#pragma unroll
-        for (int j = 0; j < VS; ++j) {
-          const int v = wave * (MV / NW) + j * 16 + r16;
-          const int od = q0d + v / (BW * BH), oh = q0h + (v / BW) % BH, ow = q0w + v % BW;
-          const bool inr = od < a.Do && oh < a.Ho && ow < a.Wo;
-          const size_t ovox = ((size_t)(b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-          T* dstv = yg + ovox * a.Cout + co0 + g * 8;
-#pragma unroll
-          for (int h = 0; h < NS / 2; ++h) {
-            const f32x4 o0 = acc[2 * h][j] + bia[2 * h], o1 = acc[2 * h + 1][j] + bia[2 * h + 1];
-            const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout;
-            typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
-            typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
-            const bfx4 p0 = __builtin_convertvector(o0, bfx4), p1 = __builtin_convertvector(o1, bfx4);
-            if (wr) *(bfx8*)(dstv + h * 32) = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
-            const f32x4 q0 = __builtin_convertvector(p0, f32x4), q1 = __builtin_convertvector(p1, f32x4);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if (wr) { s1a[2 * h][q] += q0[q]; s2a[2 * h][q] += q0[q] * q0[q]; s1a[2 * h + 1][q] += q1[q]; s2a[2 * h + 1][q] += q1[q] * q1[q]; }
-            }
-            acc[2 * h][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[2 * h + 1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          }
-        }
-        un = 0; ++bi; nbm_cur = nbm_next;
-        while (bi < b1 && a.tap_begin[un + 1] == a.tap_begin[un]) ++un;
-      } else {
-        un = nun;
-      }
+      AM_RW_STAGE(stgA)
+      if (bi >= b1) break;
+      AM_RW_STAGE(stgB)
     }
+#undef AM_RW_STAGE
+#undef AM_RW_ADVANCE
+#undef AM_RW_FIRST
   }
   // ---- ONE partials row per workgroup ----
   if (a.partials) {
@@ -345,9 +366,9 @@ bool rw_geometry(RwGeo& G, int mode, int dtype, int k, int stride, int B, int Do
   return G.nbrick > 0;
 }
 
-template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR>
+template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR, int LR>
 int rw_launch(ConvArgs& a, RwArgs& r, const RwGeo& G, size_t lds, hipStream_t st) {
-  auto kern = conv_rw_kernel<NW, BD, BH, BW, NS, NIT, HR>;
+  auto kern = conv_rw_kernel<NW, BD, BH, BW, NS, NIT, HR, LR>;
   static std::once_flag lds_cap;
   std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   dim3 grid(G.nwg, (a.Cout + 16 * NS - 1) / (16 * NS), 1);
@@ -387,10 +408,12 @@ int conv_rw_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, con
   int ntaps = a.tap_begin[a.nunit];
   size_t mxv = 0;
   for (int c = 0; c < a.nunit; ++c) { const size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
-  size_t brick = mxv * LROWB;
+  constexpr int LR = 96;                                 // conflict-free AND additive row stride (the generic kernel's 80 B is 2-way conflicted: it must fit two workgroups per CU)
+  size_t brick = mxv * LR;
   if (brick < 8192) brick = 8192;                        // the statistics fold reuses the head of the brick
   a.w_lds_off = (int)brick;
-  const size_t lds = brick + (size_t)ntaps * G.nt_tile * ROWB;
+  const int chunk = (G.nbrick + G.nwg - 1) / G.nwg;      // bricks per workgroup -> 32-byte rows of its brick table
+  const size_t lds = brick + (size_t)ntaps * G.nt_tile * ROWB + (size_t)chunk * 32;
   if (lds > 160 * 1024) return 0;
   const int nit = (int)((mxv * 4 + G.nw * 64 - 1) / (G.nw * 64));
   a.nbd = a.Do / G.bd; a.nbh = a.Ho / G.bh; a.nbw = a.Wo / G.bw;
@@ -399,10 +422,10 @@ int conv_rw_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, con
   hipStream_t st = (hipStream_t)stream;
   if (G.hr) {                                            // 8x4x16 brick, haloed 10x6x18 = 1080 rows -> 9 staging iterations of 128 rows
     if (nit > 9) return 0;
-    return rw_launch<8, 8, 4, 16, 2, 9, true>(a, r, G, lds, st);
+    return rw_launch<8, 8, 4, 16, 2, 9, true, LR>(a, r, G, lds, st);
   }
   if (nit > 7) return 0;                                 // 4x8x8 brick, sub-lattice sub-bricks of <= 5x9x9 = 405 rows -> 7 iterations of 64 rows
-  return G.nt_tile == 32 ? rw_launch<4, 4, 8, 8, 2, 7, false>(a, r, G, lds, st) : rw_launch<4, 4, 8, 8, 4, 7, false>(a, r, G, lds, st);
+  return G.nt_tile == 32 ? rw_launch<4, 4, 8, 8, 2, 7, false, LR>(a, r, G, lds, st) : rw_launch<4, 4, 8, 8, 4, 7, false, LR>(a, r, G, lds, st);
 }
 
 }  // namespace amconv
