@@ -407,6 +407,22 @@ static int brick_shape(int os, int qw, bool out_sparse, int out_bshift, int* bd,
   *bh = 8; *bw = 8; return 0;
 }
 
+// Tiling of a launch: brick shape + output-channel tile.  Small grids (deep levels: 8^3..16^3 voxels, 256-512 channels) first halve
+// the channel tile (2x the workgroups, each still 4 subtiles x 2 channel tiles per wave = 24 MFMAs per weight group); only if
+// that still leaves most CUs idle do they drop to 64-voxel bricks (6 MFMAs per barrier: measured 151 us for the 512->512 conv
+// at 8^3 where the 256-voxel brick x 32 channels takes a third of that).
+static int pick_tiling(int os, int B, int qd, int qh, int qw, int Cout, bool out_sparse, int out_bshift, int* bd, int* bh, int* bw, int* nt) {
+  int shape = brick_shape(os, qw, out_sparse, out_bshift, bd, bh, bw);
+  *nt = Cout <= 32 ? 32 : 64;
+  const long q = (long)qd * qh * qw;
+  auto nwg = [&](int tile) { return (long)B * ((q + *bd * *bh * *bw - 1) / (*bd * *bh * *bw)) * ((Cout + tile - 1) / tile) * (os == 2 ? 8 : 1); };
+  if (nwg(*nt) < 256) {
+    *nt = 32;
+    if (nwg(32) < 192 && shape != 2) { shape = 2; *bh = 4; *bw = 4; }
+  }
+  return shape;
+}
+
 extern "C" int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded) {
   const int tile = rows <= 32 ? 32 : 64;
   const int kc = dtype == AM_DT_BF16 ? 32 : 16;
@@ -419,14 +435,8 @@ extern "C" int am_conv3d_partials_rows(int mode, int dtype, int ksize, int strid
                                        int out_bshift, int n_active, int* rows) {
   const int os = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
   const int qd = (Do + os - 1) / os, qh = (Ho + os - 1) / os, qw = (Wo + os - 1) / os;
-  int bd, bh, bw;
-  const int shape0 = brick_shape(os, qw, out_sparse != 0, out_bshift, &bd, &bh, &bw);
-  {
-    const int tile = Cout <= 32 ? 32 : 64;
-    const long q = (long)qd * qh * qw;
-    const long nwg = (long)B * ((q + bd * bh * bw - 1) / (bd * bh * bw)) * ((Cout + tile - 1) / tile) * (os == 2 ? 8 : 1);
-    if (nwg < 256 && shape0 != 2) { bh = 4; bw = 4; }
-  }
+  int bd, bh, bw, nt;
+  pick_tiling(os, B, qd, qh, qw, Cout, out_sparse != 0, out_bshift, &bd, &bh, &bw, &nt);
   *rows = B * ((qd + bd - 1) / bd) * ((qh + bh - 1) / bh) * ((qw + bw - 1) / bw) * (os == 2 ? 8 : 1);
   // upper bound over the kernels a launch of this shape may take (am_conv3d reports the rows it actually wrote)
   const int rw = conv_rw_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse, out_bshift, n_active);
@@ -469,15 +479,8 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
 generic:
 #endif
   const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
-  int shape = brick_shape(os_, (Wo + os_ - 1) / os_, out_mask != nullptr, out_bshift, &P.bd, &P.bh, &P.bw);
-  P.nt_tile = Cout <= 32 ? 32 : 64;
-  {  // deep levels (8^3..16^3 grids, 256-512 channels): the default tiling gives a few dozen workgroups that each walk
-     // 16 channel slabs serially while 90 % of the chip idles -> 64-voxel bricks x 32 channels = 8x more workgroups
-    const long q = (long)((Do + os_ - 1) / os_) * ((Ho + os_ - 1) / os_) * ((Wo + os_ - 1) / os_);
-    const long nwg = (long)B * ((q + P.bd * P.bh * P.bw - 1) / (P.bd * P.bh * P.bw)) * ((Cout + P.nt_tile - 1) / P.nt_tile) * (os_ == 2 ? 8 : 1);
-    if (nwg < 256 && shape != 2) { shape = 2; P.bh = 4; P.bw = 4; P.nt_tile = 32; }
-    else if (nwg < 256) P.nt_tile = 32;
-  }
+  int shape = pick_tiling(os_, B, (Do + os_ - 1) / os_, (Ho + os_ - 1) / os_, (Wo + os_ - 1) / os_, Cout, out_mask != nullptr, out_bshift,
+                          &P.bd, &P.bh, &P.bw, &P.nt_tile);
   int rc = build_plan(P, mode, ksize, stride);
   if (rc) return rc;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;

@@ -8,6 +8,10 @@
 
 namespace {
 
+// MFMA tile row -> output channel (same permutation as the convolution kernels, conv_plan.h): a lane's registers of tiles (2h, 2h+1)
+// are 8 consecutive channels
+__device__ __forceinline__ int crow(int R) { return ((R >> 5) << 5) + (((R >> 2) & 3) << 3) + (((R >> 4) & 1) << 2) + (R & 3); }
+
 constexpr int NREP = 8;      // replicated reduction accumulators (spreads same-address atomic contention)
 
 struct Geo {                 // a channels-last tensor [B][D][H][W][C] and its (optional) patch mask
@@ -851,6 +855,112 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
   }
 }
 
+
+// ------------------------------------------------------------------ stem k3 on the matrix cores (bf16 storage mode)
+// The Cin = 1 stem is a [voxels x 27] x [27 x C] product: K = 27 taps padded to the 32 of one v_mfma_f32_16x16x32_bf16.  One
+// workgroup owns one ACTIVE 16^3 patch (active-patch list): the haloed 18^3 input patch is staged once into LDS as bf16 with the
+// patch mask and the volume bounds applied, the weights live in registers as MFMA A-fragments for the whole kernel, and per
+// 16-voxel w-row a lane gathers the 8 taps of its k-group from LDS (8 two-byte reads), issues C/16 MFMAs, adds the bias and
+// stores 8 consecutive channels (16 bytes; a wave writes 1 KB runs).  The VALU form (stem_conv_fwd_kernel) spends 27 LDS reads and
+// 216 FMAs per voxel-chunk and runs at 24 TFLOP/s (450 us for 430 MB of output); this one is bound by its output stream.
+// One partials row per patch (the VALU kernel leaves one per 512-voxel brick, inactive ones included).
+template <int NS>
+__global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __restrict__ x, int D, int H, int W, int C, MaskView mask,
+                                                             const int* __restrict__ plist, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                             float* __restrict__ part) {
+  constexpr int E = 18;                                          // haloed patch edge
+  __shared__ bf16_t xl[E * E * E + 8];
+  __shared__ float red[4 * 16 * NS * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+  const int pk = plist[blockIdx.x];
+  const int b = (pk >> 24) & 255, pd = (pk >> 16) & 255, ph = (pk >> 8) & 255, pw = pk & 255;
+  const int d0 = pd * 16, h0 = ph * 16, w0 = pw * 16;
+  // ---- haloed patch -> LDS (bf16), zero outside the volume and in inactive neighbour patches
+  for (int e = tid; e < E * E * E; e += 256) {
+    const int ex = e % E, ey = (e / E) % E, ez = e / (E * E);
+    const int id = d0 + ez - 1, ih = h0 + ey - 1, iw = w0 + ex - 1;
+    float v = 0.f;
+    if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && mask.active(b, id, ih, iw))
+      v = x[((size_t)(b * D + id) * H + ih) * W + iw];
+    xl[e] = f2bf(v);
+  }
+  // ---- weights -> A fragments (row R of tile i <-> channel crow(16 i + R): a lane ends up with 8 consecutive channels)
+  typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+  bfx8 af[NS];
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int t = 8 * g + j;
+    toff[j] = t < 27 ? ((t / 9) * E + (t / 3) % 3) * E + t % 3 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int ch = crow(i * 16 + r16);
+    s16x8 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int t = 8 * g + j; q[j] = (short)f2bf(t < 27 ? w[ch * 27 + t] : 0.f); }
+    af[i] = __builtin_bit_cast(bfx8, q);
+  }
+  f32x4 bia[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) bia[i] = bias ? *(const f32x4*)(bias + (i >> 1) * 32 + g * 8 + (i & 1) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  float s1[NS][4], s2[NS][4];
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s1[i][q] = s2[i][q] = 0.f;
+  __syncthreads();
+  // ---- 256 w-rows of 16 voxels: wave `wave` takes rows wave, wave + 4, ...
+  for (int row = wave; row < 256; row += 4) {
+    const int dz = row >> 4, dy = row & 15;
+    const int base = (dz * E + dy) * E + r16;                    // (d - 1 + td, h - 1 + th, w - 1 + tw) with the halo offset folded in
+    s16x8 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = (short)xl[base + toff[j]];
+    const bfx8 bf = __builtin_bit_cast(bfx8, q);
+    f32x4 o[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, bia[i], 0, 0, 0);
+    const size_t vox = ((size_t)(b * D + d0 + dz) * H + h0 + dy) * W + w0 + r16;
+    bf16_t* dst = y + vox * C + g * 8;
+#pragma unroll
+    for (int h = 0; h < NS / 2; ++h) {
+      typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
+      const bfx4 p0 = __builtin_convertvector(o[2 * h], bfx4), p1 = __builtin_convertvector(o[2 * h + 1], bfx4);
+      *(bfx8*)(dst + h * 32) = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+      const f32x4 q0 = __builtin_convertvector(p0, f32x4), q1 = __builtin_convertvector(p1, f32x4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        s1[2 * h][c] += q0[c]; s2[2 * h][c] += q0[c] * q0[c];
+        s1[2 * h + 1][c] += q1[c]; s2[2 * h + 1][c] += q1[c] * q1[c];
+      }
+    }
+  }
+  if (part) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a1 = s1[i][c], a2 = s2[i][c];
+#pragma unroll
+        for (int o_ = 8; o_ > 0; o_ >>= 1) { a1 += __shfl_xor(a1, o_, 64); a2 += __shfl_xor(a2, o_, 64); }
+        if (r16 == 0) {
+          const int ch = (i >> 1) * 32 + g * 8 + (i & 1) * 4 + c;
+          red[(wave * 16 * NS + ch) * 2] = a1; red[(wave * 16 * NS + ch) * 2 + 1] = a2;
+        }
+      }
+    __syncthreads();
+    if (tid < 16 * NS) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 4; ++wv) { a1 += red[(wv * 16 * NS + tid) * 2]; a2 += red[(wv * 16 * NS + tid) * 2 + 1]; }
+      float* pr = part + ((size_t)blockIdx.x * C + tid) * 2;
+      pr[0] = a1; pr[1] = a2;
+    }
+  }
+}
+
 // dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]     (same brick staging; 9 taps at a time in registers).
 // Persistent: a workgroup walks a strided set of bricks and keeps its [C][k^3+1] partial sums in LDS, so the global
 // atomics happen once per workgroup, not once per brick.
@@ -1444,13 +1554,24 @@ int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void*
 }
 
 int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int C, int ksize, const uint8_t* mask, int bshift,
-                     int fd, int fh, int fw, const float* w, const float* bias, void* y, float* partials, void* stream) {
+                     int fd, int fh, int fw, const float* w, const float* bias, void* y, float* partials,
+                     const int32_t* active_list, int n_active, int* partial_rows_written, void* stream) {
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;      // stage-0 tensor: 16^3 patches
+  if (partial_rows_written) *partial_rows_written = B * (D / SBD) * (H / SBH) * (W / SBW);
+  if (dtype == AM_DT_BF16 && ksize == 3 && active_list && n_active > 0 && (C == 32 || C == 64 || C == 96) && B <= 255 && fd <= 255 && fh <= 255 && fw <= 255) {
+    const MaskView mv{mask, fd, fh, fw, bshift};
+    if (C == 32) AM_LAUNCH(stem_conv_mfma_kernel<2>, dim3(n_active), dim3(256), 0, st, x, D, H, W, C, mv, active_list, w, bias, (bf16_t*)y, partials);
+    else if (C == 64) AM_LAUNCH(stem_conv_mfma_kernel<4>, dim3(n_active), dim3(256), 0, st, x, D, H, W, C, mv, active_list, w, bias, (bf16_t*)y, partials);
+    else AM_LAUNCH(stem_conv_mfma_kernel<6>, dim3(n_active), dim3(256), 0, st, x, D, H, W, C, mv, active_list, w, bias, (bf16_t*)y, partials);
+    AM_CHECK_LAUNCH();
+    if (partial_rows_written) *partial_rows_written = n_active;
+    return 0;
+  }
   const int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
   const int pad_ = ksize / 2;
   size_t fl = (size_t)C * ksize * ksize * ksize;

@@ -237,7 +237,9 @@ def stem_conv_fwd(x_b1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
         part.rows, part.C = B * (D // 4) * (H // 8) * (W // 16), Cc
         part.t = torch.empty(part.rows, Cc, 2, device=x_b1.device, dtype=torch.float32)
     hip.lib().stem_conv_fwd(_dt(y), x_b1.data_ptr(), B, D, H, W, Cc, k, mp, bshift, fd, fh, fw, w.data_ptr(), _p(bias),
-                            y.data_ptr(), part.t.data_ptr() if part else None, _stream())
+                            y.data_ptr(), part.t.data_ptr() if part else None, *_al(mask), _ROWS_ADDR if part else None, _stream())
+    if part is not None:
+        part.rows = _ROWS_OUT.value
     return (y, part) if want_partials else y
 
 

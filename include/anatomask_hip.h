@@ -91,7 +91,9 @@ int am_unpack_grad(const float* src_packed, float* dst, int R, int K, int taps, 
 int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int C, int ksize, const uint8_t* mask, int bshift,
                      int fd, int fh, int fw, const float* w, const float* bias, void* y,
                      float* partials /* NULL or [B*(D/4)*(H/8)*(W/16)][C][2]: per-workgroup sum / sum of squares of y, as am_conv3d */,
-                     void* stream);
+                     const int32_t* active_list, int n_active /* am_mask_compact: bf16 k3 stems then run on the matrix cores, one
+                     workgroup per active patch (K = 27 taps padded to one 16x16x32 MFMA); NULL / 0: the VALU kernel */,
+                     int* partial_rows_written /* NULL or (host) the partials rows written (<= the bound above) */, void* stream);
 int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum, void* stream);
 
