@@ -190,6 +190,63 @@ __global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x
   }
 }
 
+
+// ---- fused tails of the backward kernels (last-workgroup pattern, as partials_finalize_kernel) --------------------------------
+// The tiny finalize / replica-fold kernels that used to follow the backward reduce / apply passes each waited ~130 us for a CU slot
+// whenever the weight-gradient kernels of the side stream owned the chip (profiles/r02: 22 + 10 such waits per step on the critical
+// chain).  Now the LAST workgroup of the streaming kernel does that work itself; the accumulators are device-scope atomics on a
+// workspace that is zero on entry and left zero on exit (no memset launch either).
+struct BwdFin {
+  unsigned* ticket;                  // behind the accumulators; nullptr: no fused tail
+  const double* count_ptr; double count_host;
+  const float* gamma; const float* rstd;
+  float *k0, *k1, *k2, *dgamma, *dbeta, *dtoken, *dbeta2;
+};
+
+__device__ __forceinline__ bool last_workgroup(unsigned* ticket) {
+  __shared__ unsigned tk;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) tk = atomicAdd(ticket, 1u);
+  __syncthreads();
+  return tk == gridDim.x - 1;
+}
+
+// bsum [NREP][C][3] -> k0/k1/k2 + parameter gradients (norm_bwd_finalize_kernel's arithmetic), accumulators re-zeroed
+__device__ __forceinline__ void bwd_reduce_tail(double* bsum, int C, const BwdFin& f) {
+  if (!f.ticket) return;
+  if (!last_workgroup(f.ticket)) return;
+  const double n = f.count_ptr ? f.count_ptr[0] : f.count_host;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    for (int r = 0; r < NREP; ++r) {
+      double* q = bsum + ((size_t)r * C + c) * 3;
+      b1 += __longlong_as_double(atomicExch((unsigned long long*)&q[0], 0ull));
+      b2 += __longlong_as_double(atomicExch((unsigned long long*)&q[1], 0ull));
+      b3 += __longlong_as_double(atomicExch((unsigned long long*)&q[2], 0ull));
+    }
+    const float gr = f.gamma[c] * f.rstd[c];
+    f.k0[c] = gr; f.k1[c] = gr * (float)(b1 / n); f.k2[c] = gr * (float)(b2 / n);
+    if (f.dgamma) f.dgamma[c] += (float)b2;
+    if (f.dbeta) f.dbeta[c] += (float)b1;
+    if (f.dbeta2) f.dbeta2[c] += (float)b1;
+    if (f.dtoken) f.dtoken[c] += (float)b3;
+  }
+  if (threadIdx.x == 0) atomicExch(f.ticket, 0u);
+}
+
+// dxsum replicas [nrep][C] -> accum[c] += sum, replicas re-zeroed
+__device__ __forceinline__ void dxsum_tail(float* rep, int nrep, int C, float* accum, unsigned* ticket) {
+  if (!ticket) return;
+  if (!last_workgroup(ticket)) return;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s_ = 0.f;
+    for (int r = 0; r < nrep; ++r) s_ += __uint_as_float(atomicExch((unsigned*)&rep[(size_t)r * C + c], 0u));
+    accum[c] += s_;
+  }
+  if (threadIdx.x == 0) atomicExch(ticket, 0u);
+}
+
 // ------------------------------------------------------------------ backward: reduce
 // dpre = dout * act'(out);  bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout (token grad)}
 template <typename T>
@@ -197,7 +254,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restric
                                                               const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, int fill,
                                                               double* __restrict__ bsum, const float* __restrict__ psc,
-                                                              const float* __restrict__ psh) {
+                                                              const float* __restrict__ psh, BwdFin fin) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 3 * 8];
   Walk<T> wk(g.C);
@@ -261,6 +318,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restric
       if (fill) atomicAdd(&br[c * 3 + 2], a3[i]);
     }
   }
+  bwd_reduce_tail(bsum, g.C, fin);
 }
 
 // per-channel coefficients of the apply pass + parameter gradients (accumulated into fp32 grads)
@@ -290,7 +348,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const float* __restrict__ rstd, const float* __restrict__ k0,
                                                              const float* __restrict__ k1, const float* __restrict__ k2, int act,
                                                              T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum,
-                                                             int dxrep, const float* __restrict__ psc, const float* __restrict__ psh) {
+                                                             int dxrep, const float* __restrict__ psc, const float* __restrict__ psh,
+                                                             float* __restrict__ dx_accum, unsigned* dx_ticket) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 8];
   Walk<T> wk(g.C);
@@ -350,6 +409,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
 #pragma unroll
       for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], a1[i]);
     }
+    dxsum_tail(dxsum, dxrep, g.C, dx_accum, dx_ticket);
   }
 }
 
@@ -510,7 +570,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_rows_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                                    const T* __restrict__ x, RowGeo g, const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, int act, double* __restrict__ bsum,
-                                                                   const float* __restrict__ psc, const float* __restrict__ psh) {
+                                                                   const float* __restrict__ psc, const float* __restrict__ psh, BwdFin fin) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 2 * 8];
   RowWalk<T> wk(g);
@@ -575,6 +635,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_rows_kernel(const T* __re
       atomicAdd(&br[c * 3], a1[i]); atomicAdd(&br[c * 3 + 1], a2[i]);
     }
   }
+  bwd_reduce_tail(bsum, g.C, fin);
 }
 
 template <typename T>
@@ -583,7 +644,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
                                                                   const float* __restrict__ rstd, const float* __restrict__ k0,
                                                                   const float* __restrict__ k1, const float* __restrict__ k2, int act,
                                                                   T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum,
-                                                                  int dxrep, const float* __restrict__ psc, const float* __restrict__ psh) {
+                                                                  int dxrep, const float* __restrict__ psc, const float* __restrict__ psh,
+                                                                  float* __restrict__ dx_accum, unsigned* dx_ticket) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 8];
   RowWalk<T> wk(g);
@@ -655,6 +717,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
 #pragma unroll
       for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], a1[i]);
     }
+    dxsum_tail(dxsum, dxrep, g.C, dx_accum, dx_ticket);
   }
 }
 
@@ -1458,29 +1521,38 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
 int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd, int act,
                        int fill, double* bsum, const float* pre_scale, const float* pre_shift, const int32_t* active_list,
-                       int n_active, void* stream) {
+                       int n_active, const double* count_ptr, double count_host, const float* gamma, float* k0, float* k1, float* k2,
+                       float* dgamma, float* dbeta, float* dtoken, float* dbeta2, void* stream) {
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C * NREP, st);
+  BwdFin fin{};
+  if (k0) {                                  // fused finalize: bsum is a zero workspace [AM_NREP][C][3] doubles + one ticket word, left zero
+    if (!gamma || !k1 || !k2) return -1;
+    fin.ticket = (unsigned*)(bsum + (size_t)3 * C * NREP);
+    fin.count_ptr = count_ptr; fin.count_host = count_host; fin.gamma = gamma; fin.rstd = rstd;
+    fin.k0 = k0; fin.k1 = k1; fin.k2 = k2; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.dtoken = dtoken; fin.dbeta2 = dbeta2;
+  } else {
+    hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C * NREP, st);
+  }
   RowGeo rg;
   if (mask && !fill && mkrows(rg, dtype, true, B, D, H, W, C, bshift, active_list, n_active)) {
     DISPATCH_T(dtype,
                AM_LAUNCH(norm_bwd_reduce_rows_kernel<float>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const float*)dout,
-                         (const float*)out, (const float*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift),
+                         (const float*)out, (const float*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift, fin),
                AM_LAUNCH(norm_bwd_reduce_rows_kernel<bf16_t>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout,
-                         (const bf16_t*)out, (const bf16_t*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift));
+                         (const bf16_t*)out, (const bf16_t*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift, fin));
     AM_CHECK_LAUNCH();
     return 0;
   }
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift),
+                                (const float*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin),
              AM_LAUNCH(norm_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,
-                                (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift));
+                                (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin));
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -1498,7 +1570,7 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, float* dxsum_accum,
                       float* dxsum_scratch, const float* pre_scale, const float* pre_shift, const int32_t* active_list, int n_active,
-                      void* stream) {
+                      int scratch_is_zero_workspace, void* stream) {
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
@@ -1512,21 +1584,26 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
   const bool rep = dxsum_accum && dxsum_scratch;
   float* dxs = rep ? dxsum_scratch : dxsum_accum;
   const int nrep = rep ? AM_DXREP : 1;
-  if (rep) hipMemsetAsync(dxsum_scratch, 0, sizeof(float) * AM_DXREP * C, st);
+  // scratch_is_zero_workspace: [AM_DXREP][C] floats + one ticket word, zero on entry and left zero: the last workgroup folds the
+  // replicas into dxsum_accum itself (no memset launch before, no fold launch after)
+  const bool fused = rep && scratch_is_zero_workspace;
+  float* dx_accum = fused ? dxsum_accum : nullptr;
+  unsigned* dx_ticket = fused ? (unsigned*)(dxsum_scratch + (size_t)AM_DXREP * C) : nullptr;
+  if (rep && !fused) hipMemsetAsync(dxsum_scratch, 0, sizeof(float) * AM_DXREP * C, st);
   if (rows) {
     DISPATCH_T(dtype,
                AM_LAUNCH(norm_bwd_apply_rows_kernel<float>, dim3(nb), dim3(rows_threads(rg)), 0, st, (const float*)dout, (const float*)out,
-                         (const float*)x, rg, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift),
+                         (const float*)x, rg, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket),
                AM_LAUNCH(norm_bwd_apply_rows_kernel<bf16_t>, dim3(nb), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                         (const bf16_t*)x, rg, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift));
+                         (const bf16_t*)x, rg, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket));
   } else
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift),
+                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket),
              AM_LAUNCH(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift));
+                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket));
   AM_CHECK_LAUNCH();
-  if (rep) { AM_LAUNCH(rep_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dxsum_scratch, AM_DXREP, C, dxsum_accum); AM_CHECK_LAUNCH(); }
+  if (rep && !fused) { AM_LAUNCH(rep_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dxsum_scratch, AM_DXREP, C, dxsum_accum); AM_CHECK_LAUNCH(); }
   return 0;
 }
 

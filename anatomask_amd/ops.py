@@ -307,9 +307,7 @@ def norm_apply(x: torch.Tensor, st: NormStats, act: int, mask: Optional[MaskInfo
 
 class NormBwdScratch:
     def __init__(self, C: int, device):
-        self.bsum = torch.empty(NREP, C, 3, device=device, dtype=torch.float64)
         self.k = torch.empty(3, C, device=device, dtype=torch.float32)
-        self.dxrep = torch.empty(DXREP, C, device=device, dtype=torch.float32)
 
 
 def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tensor, st: NormStats, gamma: torch.Tensor, act: int,
@@ -324,17 +322,32 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
     mp, fd, fh, fw = _mk(mask)
     L = hip.lib()
     s = _stream()
+    ws_b, ws_x = _bwd_workspaces(x.device, Cc)
+    # reduce + finalize in ONE launch (the last workgroup folds the sums into k0/k1/k2 and the parameter gradients)
     L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
-                      st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), sc.bsum.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
-                      *_al(mask), s)
-    L.norm_bwd_finalize(sc.bsum.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
-                        sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
+                      st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), ws_b.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                      *_al(mask), _p(st.count_ptr), float(st.count_host), gamma.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(),
+                      sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
     if dx is None:
         dx = torch.empty_like(x)
     L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                      st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
-                     dx.data_ptr(), _p(dres), _p(dxsum), sc.dxrep.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), *_al(mask), s)
+                     dx.data_ptr(), _p(dres), _p(dxsum), ws_x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), *_al(mask), 1, s)
     return dx
+
+
+_BWS = {}
+
+
+def _bwd_workspaces(device, C: int):
+    """zero-initialised accumulators of the fused backward tails (left zero by every call), one pair per (device, stream)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _BWS.get(key)
+    if ws is None or ws[2] < C:
+        cap = max(C, 2048)
+        ws = _BWS[key] = (torch.zeros(NREP * cap * 3 + 2, device=device, dtype=torch.float64),
+                          torch.zeros(DXREP * cap + 2, device=device, dtype=torch.float32), cap)
+    return ws[0], ws[1]
 
 
 def chan_sum(x: torch.Tensor, mask: Optional[MaskInfo], bshift: int, out_accum: torch.Tensor):

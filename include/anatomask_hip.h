@@ -133,7 +133,12 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
                        int fill, double* bsum /* [AM_NREP][C][3], zeroed inside */,
                        const float* pre_scale, const float* pre_shift /* out == NULL with an activation (no residual): the
                        derivative is taken from the recomputed pre-activation x*pre_scale + pre_shift -- one read less */,
-                       const int32_t* active_list, int n_active, void* stream);
+                       const int32_t* active_list, int n_active,
+                       const double* count_ptr, double count_host, const float* gamma, float* k0, float* k1, float* k2,
+                       float* dgamma_accum, float* dbeta_accum, float* dtoken_accum, float* dbeta2_accum
+                       /* k0 != NULL: am_norm_bwd_finalize is FUSED into this launch (its last workgroup does it); bsum is then a
+                          workspace of AM_NREP*C*3 doubles + 1 that is ZERO on entry and left ZERO (no memset, no finalize launch) */,
+                       void* stream);
 int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double count_host, int C, const float* gamma,
                          const float* rstd, float* k0, float* k1, float* k2, float* dgamma_accum, float* dbeta_accum,
                          float* dtoken_accum, float* dbeta2_accum /* bias of a conv added after the norm: same sum */, void* stream);
@@ -143,7 +148,9 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
                       float* dxsum_accum /* NULL or += per-channel sum of dx: bias gradient of the conv feeding the norm */,
                       float* dxsum_scratch /* [AM_DXREP][C] workspace when dxsum_accum != NULL (NULL: direct atomics) */,
                       const float* pre_scale, const float* pre_shift /* as in am_norm_bwd_reduce */,
-                      const int32_t* active_list, int n_active, void* stream);
+                      const int32_t* active_list, int n_active,
+                      int scratch_is_zero_workspace /* 1: dxsum_scratch = AM_DXREP*C floats + 1, zero on entry / left zero; the fold into
+                      dxsum_accum happens in the last workgroup of this launch */, void* stream);
 int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                 int fw, float* out_accum, void* stream);   /* conv bias gradients */
 int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream);   /* x + to_dec[i], P/decoder3D.py:59 */

@@ -36,10 +36,11 @@ ops.norm_finalize(st, gam, bet, 1e-5)
 timed(lambda: ops.norm_apply(x, st, ops.ACT_RELU6, out=y), "norm_apply (1r 1w)", 2 * nb)
 timed(lambda: ops.norm_apply(x, st, ops.ACT_NONE, res=d, out=y), "norm_apply+res (2r 1w)", 3 * nb)
 sc = ops.NormBwdScratch(C, dev)
+bsum = torch.zeros(ops.NREP, C, 3, device=dev, dtype=torch.float64)
 L = __import__("anatomask_amd.hip", fromlist=["lib"]).lib()
 s = torch.cuda.current_stream().cuda_stream
 timed(lambda: L.norm_bwd_reduce(1, d.data_ptr(), y.data_ptr(), x.data_ptr(), B, S, S, S, C, None, 0, 1, 1, 1, st.mean.data_ptr(),
-                                st.rstd.data_ptr(), ops.ACT_RELU6, 0, sc.bsum.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), None, 0, s), "bwd_reduce (3 reads)", 3 * nb)
+                                st.rstd.data_ptr(), ops.ACT_RELU6, 0, bsum.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), None, 0, None, 0.0, None, None, None, None, None, None, None, None, s), "bwd_reduce (3 reads)", 3 * nb)
 timed(lambda: ops.norm_backward(d, y, x, st, gam, ops.ACT_RELU6, None, 0, None, None, dx=dx, scratch=sc), "bwd reduce+apply (6r 1w)", 7 * nb)
 out = torch.zeros(C, device=dev)
 timed(lambda: ops.chan_sum(x, None, 0, out), "chan_sum (1 read)", nb)
