@@ -205,7 +205,10 @@ struct BwdFin {
 
 __device__ __forceinline__ bool last_workgroup(unsigned* ticket) {
   __shared__ unsigned tk;
-  __threadfence();
+  // The accumulators are only ever touched by device-scope atomics, which execute at the memory side (MI355X_MICROARCH.md "Global
+  // float atomics"): what the ticket must follow is their ACKNOWLEDGEMENT (vmcnt), not an L2 write-back.  __threadfence() here
+  // (buffer_wbl2 + invalidate in all 256 threads of ~2000 workgroups, flushing the kernel's own streaming stores) cost 3.5 ms/step.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) tk = atomicAdd(ticket, 1u);
   __syncthreads();
@@ -1341,7 +1344,7 @@ __global__ __launch_bounds__(256) void partials_finalize_kernel(const float* __r
       atomicAdd(&sums[2 * c], s1); atomicAdd(&sums[2 * c + 1], s2);
     }
   }
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the sums are memory-side atomics: acknowledged is visible
   __syncthreads();
   if (t == 0) ticket_s = atomicAdd(ticket, 1u);
   __syncthreads();

@@ -323,6 +323,18 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
     L = hip.lib()
     s = _stream()
     ws_b, ws_x = _bwd_workspaces(x.device, Cc)
+    if not FUSED_BWD_TAILS:                      # (tools/step_ab.py: the three-launch form, for same-process A/B timing)
+        L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
+                          st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), ws_b.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                          *_al(mask), None, 0.0, None, None, None, None, None, None, None, None, s)
+        L.norm_bwd_finalize(ws_b.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
+                            sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
+        if dx is None:
+            dx = torch.empty_like(x)
+        L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
+                         st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
+                         dx.data_ptr(), _p(dres), _p(dxsum), ws_x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), *_al(mask), 0, s)
+        return dx
     # reduce + finalize in ONE launch (the last workgroup folds the sums into k0/k1/k2 and the parameter gradients)
     L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                       st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), ws_b.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
@@ -337,6 +349,7 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
 
 
 _BWS = {}
+FUSED_BWD_TAILS = True
 
 
 def _bwd_workspaces(device, C: int):

@@ -1,6 +1,6 @@
 """Interleaved A/B of a knob on the full step in ONE process (robust to noisy neighbours on the GPU):
 usage: python tools/step_ab.py KNOB=v1,v2,... [batch]
-  KNOB = engine.<attr> flips a module attribute of anatomask_amd.engine (e.g. engine._USE_SIDE=1,0);
+  KNOB = engine.<attr> / ops.<attr> flips a module attribute (e.g. engine._USE_SIDE=1,0, ops.FUSED_BWD_TAILS=1,0);
   any other KNOB is set as an environment variable (only the -DAM_ABLATE tools build reads any)."""
 import os
 import sys
@@ -26,9 +26,11 @@ for _ in range(3):
 res = {v: [] for v in vals}
 for rep in range(4):
     for v in vals:
-        if knob.startswith("engine."):
-            from anatomask_amd import engine
-            setattr(engine, knob[7:], type(getattr(engine, knob[7:]))(int(v)))
+        if knob.startswith(("engine.", "ops.")):
+            import importlib
+            mod = importlib.import_module("anatomask_amd." + knob.split(".")[0])
+            attr = knob.split(".", 1)[1]
+            setattr(mod, attr, type(getattr(mod, attr))(int(v)))
         else:
             os.environ[knob] = v
         tr.step(x, epoch=500)
