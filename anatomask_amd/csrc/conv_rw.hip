@@ -76,6 +76,12 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
     const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8, un = (tp >> 18) & 7;
     tapv = (((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LR;
   }
+  // per-unit plan parameters -> lane tables (lane u = unit u): a v_readlane per use instead of a scalar load from the kernel
+  // argument segment (indexed by the runtime unit number those are s_load + s_waitcnt chains, ~20 of them per stage)
+  const int ul = lane & 7;
+  const int u_eh = a.eh[ul], u_ew = a.ew[ul], u_ed = a.ed[ul], u_mdw = a.mdiv_w[ul], u_mdhw = a.mdiv_hw[ul], u_par = a.upar[ul];
+  const int u_md = a.mind[ul], u_mh = a.minh[ul], u_mw = a.minw[ul], u_tb = a.tap_begin[ul], u_te = a.tap_begin[ul + 1];
+#define UP(V_, UN_) __builtin_amdgcn_readlane(V_, UN_)
   int aoff[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) aoff[i] = swz(i * 16 + r16, g);
@@ -146,19 +152,58 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
   // staging plan of stage (brick bi, unit un) + issue of its loads into stg.  nbm: activity bits of the 27 neighbour patches.
   // `valid` = false (past the last stage): the same number of loads is issued, all out of range (zeros, no traffic) -- the
   // compiler counts vector-memory operations statically, and a CONDITIONAL prefetch makes it wait for everything in flight.
+  // Single-unit (k3 s1) block-sparse launches: a row's position inside the haloed brick never changes, so its packed (d, h, w)
+  // and its byte offset relative to the brick origin are computed ONCE per thread; per stage a row then costs one packed add, the
+  // 3 x 3 x 3 neighbour-patch index (bit fields of that sum) and a bit test -- 11 vector instructions instead of ~35
+  // (tools/rw_ablate.py: the staging-plan arithmetic was 100 us of this kernel's 205 us skeleton).
+  int relf[HR ? NIT : 1];
+  unsigned roff[HR ? NIT : 1];
+  if constexpr (HR) {
+    const int EH = UP(u_eh, 0), EW = UP(u_ew, 0), nvox = UP(u_ed, 0) * EH * EW, EHW = EH * EW;
+    const int mW = UP(u_mdw, 0), mHW = UP(u_mdhw, 0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = (tid >> 2) + it * RPI;
+      const int ez = (e * mHW) >> 20, rem = e - ez * EHW;
+      const int ey = (rem * mW) >> 20, ex = rem - ey * EW;
+      relf[it] = (cok && e < nvox) ? (ez | (ey << 8) | (ex << 16)) : (int)0x80000000;
+      roff[it] = (unsigned)((((ez * a.Hi + ey) * a.Wi + ex) * a.Cin + cchunk) * (int)sizeof(T));
+    }
+  }
   auto plan_and_load = [&](u32x4 (&stg)[NIT], int bi_, int un_, bool valid) {
     // everything that shapes the stage is wave-uniform: say so (scalar registers, scalar buffer descriptor)
     const int bi = __builtin_amdgcn_readfirstlane(valid ? bi_ : b0), un = __builtin_amdgcn_readfirstlane(valid ? un_ : 0);
     int b, q0d, q0h, q0w, pd, ph, pw, nbm;
     fetch(bi, b, q0d, q0h, q0w, pd, ph, pw, nbm);
-    const int EH = a.eh[un], EW = a.ew[un], nvox = a.ed[un] * EH * EW, EHW = EH * EW;
-    const int mW = a.mdiv_w[un], mHW = a.mdiv_hw[un];
-    const int upd = (a.upar[un] >> 2) & 1, uph = (a.upar[un] >> 1) & 1, upw = a.upar[un] & 1;
-    const int i0d = q0d + a.mind[un], i0h = q0h + a.minh[un], i0w = q0w + a.minw[un];
+    const int EH = UP(u_eh, un), EW = UP(u_ew, un), nvox = UP(u_ed, un) * EH * EW, EHW = EH * EW;
+    const int mW = UP(u_mdw, un), mHW = UP(u_mdhw, un), par = UP(u_par, un);
+    const int upd = (par >> 2) & 1, uph = (par >> 1) & 1, upw = par & 1;
+    const int i0d = q0d + UP(u_md, un), i0h = q0h + UP(u_mh, un), i0w = q0w + UP(u_mw, un);
     int dbase = i0d * a.GS + upd; dbase = dbase < 0 ? 0 : (dbase > a.Di ? a.Di : dbase);
     const size_t left = (size_t)(a.Di - dbase) * plane_elems * sizeof(T);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const T*)a.x + ((size_t)b * a.Di + dbase) * plane_elems), 0, (int)(left < 0x7fffff00ull ? left : 0x7fffff00ull), 0x00020000);
+    if constexpr (HR) {
+      if (sparse && ibs == 4) {                            // (uniform)
+        const int P = 16;
+        const unsigned sbase = (unsigned)(((((i0d - dbase) * a.Hi + i0h) * a.Wi + i0w) * a.Cin) * (int)sizeof(T));   // (wraps for halo origins; valid rows come out >= 0)
+        const int sb = (i0d - pd * P + P) | ((i0h - ph * P + P) << 8) | ((i0w - pw * P + P) << 16);
+        const bool live = valid & !AM_DBG(a, 2);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const int t = relf[it] + sb;
+          const int idx = ((t >> 4) & 3) * 9 + ((t >> 12) & 3) * 3 + ((t >> 20) & 3);
+          const bool ok = live & (relf[it] >= 0) & (((nbm >> idx) & 1) != 0);
+          stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? roff[it] + sbase : OOB, 0, 0));
+        }
+        return;
+      }
+    }
+    if (AM_DBG(a, 16)) {                                  // (ablation: no staging-plan arithmetic)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, OOB, 0, 0));
+      return;
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = (tid >> 2) + it * RPI;
@@ -181,7 +226,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
     // captured state sends that state to scratch memory, and scratch traffic shares the vector-memory counter with the prefetches
     // (every scratch read would drain them).
     // stage cursor: (brick, unit), skipping units without taps
-#define AM_RW_FIRST(UN_) while ((UN_) < a.nunit && a.tap_begin[(UN_) + 1] == a.tap_begin[(UN_)]) ++(UN_);
+#define AM_RW_FIRST(UN_) while ((UN_) < a.nunit && UP(u_te, UN_) == UP(u_tb, UN_)) ++(UN_);
 #define AM_RW_ADVANCE(BI_, UN_) { ++(UN_); AM_RW_FIRST(UN_) if ((UN_) >= a.nunit) { (UN_) = 0; AM_RW_FIRST(UN_) ++(BI_); } }
     int bi = b0, un = 0;
     AM_RW_FIRST(un)
@@ -192,12 +237,12 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
 #define AM_RW_STAGE(STG) \
     { \
       bi = __builtin_amdgcn_readfirstlane(bi); un = __builtin_amdgcn_readfirstlane(un); \
-      const int tb = a.tap_begin[un], nt = a.tap_begin[un + 1] - tb; \
-      const int EH = a.eh[un], EW = a.ew[un], nvox = a.ed[un] * EH * EW; \
+      const int tb = UP(u_tb, un), nt = UP(u_te, un) - tb; \
+      const int EH = UP(u_eh, un), EW = UP(u_ew, un), nvox = UP(u_ed, un) * EH * EW; \
       __syncthreads(); \
 _Pragma("unroll") \
       for (int it = 0; it < NIT; ++it) \
-        if ((tid >> 2) + it * RPI < nvox) *(u32x4*)(lds + sdst + it * RPI * LR) = STG[it]; \
+        if ((tid >> 2) + it * RPI < nvox && !AM_DBG(a, 8)) *(u32x4*)(lds + sdst + it * RPI * LR) = STG[it]; \
       __syncthreads(); \
       plan_and_load(STG, bi2, un2, bi2 < b1); \
       int bb[VS]; \
@@ -263,7 +308,7 @@ _Pragma("unroll") \
         } \
       } \
       __builtin_amdgcn_sched_barrier(0); \
-      if (bi1 != bi) { \
+      if (bi1 != bi && !AM_DBG(a, 32)) { \
         int b, q0d, q0h, q0w, pd, ph, pw, nbm_; \
         fetch(bi, b, q0d, q0h, q0w, pd, ph, pw, nbm_); \
 _Pragma("unroll") \
@@ -302,6 +347,7 @@ _Pragma("unroll") \
 #undef AM_RW_STAGE
 #undef AM_RW_ADVANCE
 #undef AM_RW_FIRST
+#undef UP
   }
   // ---- ONE partials row per workgroup ----
   if (a.partials) {

@@ -1,5 +1,6 @@
 """Ablation timing of the resident-weight conv kernel (conv_rw.hip) on the level-0 / level-1 encoder shapes, B=8, mask 0.6.
-AM_CV_DBG bits (tools build only): 1 no stores, 2 no source loads, 4 no MFMA phase; AM_CV_NORW=1: the generic kernel instead."""
+AM_CV_DBG bits (tools build only): 1 no stores, 2 no source loads, 4 no MFMA phase, 8 no LDS staging writes, 16 no staging-plan
+arithmetic, 32 no epilogue; AM_CV_NORW=1: the generic kernel instead."""
 import os
 import sys
 
@@ -34,7 +35,7 @@ for name, cin, cout, si, so, stride, ibs, obs in (("level-0 conv2 32->32 s1 @128
     wp = ops.pack_weight(w, torch.bfloat16, False, False)
     y = torch.empty(B, so, so, so, cout, device=dev, dtype=torch.bfloat16)
     out = []
-    for dbg in (0, 1, 2, 4, 6, 7):
+    for dbg in (0, 7, 7 + 8, 7 + 16, 7 + 32, 7 + 8 + 16, 63):
         os.environ["AM_CV_DBG"] = str(dbg)
         t = timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (so,) * 3, 3, stride, in_mask=mi, in_bshift=ibs, out_mask=mi, out_bshift=obs, out=y))
         out.append(f"dbg{dbg}: {t:.0f}")
