@@ -69,12 +69,17 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
       *(u32x4*)(ldsW + tap * NT * ROWB + swz(row, ch)) = v;
     }
   }
+  // Strided (8-unit) block-sparse launches stage EVERY unit with the same (BD+1) x (BH+1) x (BW+1) sub-brick (a unit whose parity
+  // needs no halo along an axis gets one unused row there: +25 % staged rows), so that the staging plan of a row is the same for
+  // all units and can be precomputed like the single-unit one.
+  const bool uni = !HR && sparse && a.GS == 2 && a.nunit == 8 && ibs == 4;
   // tap table -> one VGPR (lane t = tap t): byte offset of the tap's window inside its unit's brick
   int tapv;
   {
     const int tp = a.taps[lane];
     const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8, un = (tp >> 18) & 7;
-    tapv = (((ud - a.mind[un]) * a.eh[un] + (uh - a.minh[un])) * a.ew[un] + (uw - a.minw[un])) * LR;
+    const int eh_ = uni ? BH + 1 : a.eh[un], ew_ = uni ? BW + 1 : a.ew[un];
+    tapv = (((ud - a.mind[un]) * eh_ + (uh - a.minh[un])) * ew_ + (uw - a.minw[un])) * LR;
   }
   // per-unit plan parameters -> lane tables (lane u = unit u): a v_readlane per use instead of a scalar load from the kernel
   // argument segment (indexed by the runtime unit number those are s_load + s_waitcnt chains, ~20 of them per stage)
@@ -156,18 +161,17 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
   // and its byte offset relative to the brick origin are computed ONCE per thread; per stage a row then costs one packed add, the
   // 3 x 3 x 3 neighbour-patch index (bit fields of that sum) and a bit test -- 11 vector instructions instead of ~35
   // (tools/rw_ablate.py: the staging-plan arithmetic was 100 us of this kernel's 205 us skeleton).
-  int relf[HR ? NIT : 1];
-  unsigned roff[HR ? NIT : 1];
-  if constexpr (HR) {
-    const int EH = UP(u_eh, 0), EW = UP(u_ew, 0), nvox = UP(u_ed, 0) * EH * EW, EHW = EH * EW;
-    const int mW = UP(u_mdw, 0), mHW = UP(u_mdhw, 0);
+  int relf[NIT];
+  unsigned roff[NIT];
+  {
+    const int EH = HR ? UP(u_eh, 0) : BH + 1, EW = HR ? UP(u_ew, 0) : BW + 1, ED = HR ? UP(u_ed, 0) : BD + 1;
+    const int nvox = ED * EH * EW, EHW = EH * EW, gs = HR ? 1 : 2;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e = (tid >> 2) + it * RPI;
-      const int ez = (e * mHW) >> 20, rem = e - ez * EHW;
-      const int ey = (rem * mW) >> 20, ex = rem - ey * EW;
-      relf[it] = (cok && e < nvox) ? (ez | (ey << 8) | (ex << 16)) : (int)0x80000000;
-      roff[it] = (unsigned)((((ez * a.Hi + ey) * a.Wi + ex) * a.Cin + cchunk) * (int)sizeof(T));
+      const int ez = e / EHW, rem = e - ez * EHW, ey = rem / EW, ex = rem - ey * EW;       // (once per thread)
+      relf[it] = (cok && e < nvox) ? ((ez * gs) | ((ey * gs) << 8) | ((ex * gs) << 16)) : (int)0x80000000;   // fine-grid steps
+      roff[it] = (unsigned)((((ez * gs * a.Hi + ey * gs) * a.Wi + ex * gs) * a.Cin + cchunk) * (int)sizeof(T));
     }
   }
   auto plan_and_load = [&](u32x4 (&stg)[NIT], int bi_, int un_, bool valid) {
@@ -183,11 +187,12 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
     const size_t left = (size_t)(a.Di - dbase) * plane_elems * sizeof(T);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const T*)a.x + ((size_t)b * a.Di + dbase) * plane_elems), 0, (int)(left < 0x7fffff00ull ? left : 0x7fffff00ull), 0x00020000);
-    if constexpr (HR) {
-      if (sparse && ibs == 4) {                            // (uniform)
+    {
+      if ((HR && sparse && ibs == 4) || uni) {             // (uniform)
         const int P = 16;
-        const unsigned sbase = (unsigned)(((((i0d - dbase) * a.Hi + i0h) * a.Wi + i0w) * a.Cin) * (int)sizeof(T));   // (wraps for halo origins; valid rows come out >= 0)
-        const int sb = (i0d - pd * P + P) | ((i0h - ph * P + P) << 8) | ((i0w - pw * P + P) << 16);
+        const int f0d = i0d * a.GS + upd, f0h = i0h * a.GS + uph, f0w = i0w * a.GS + upw;        // fine-grid origin of the (sub-)brick
+        const unsigned sbase = (unsigned)(((((f0d - dbase) * a.Hi + f0h) * a.Wi + f0w) * a.Cin) * (int)sizeof(T));   // (wraps for halo origins; valid rows come out >= 0)
+        const int sb = (f0d - pd * P + P) | ((f0h - ph * P + P) << 8) | ((f0w - pw * P + P) << 16);
         const bool live = valid & !AM_DBG(a, 2);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
     { \
       bi = __builtin_amdgcn_readfirstlane(bi); un = __builtin_amdgcn_readfirstlane(un); \
       const int tb = UP(u_tb, un), nt = UP(u_te, un) - tb; \
-      const int EH = UP(u_eh, un), EW = UP(u_ew, un), nvox = UP(u_ed, un) * EH * EW; \
+      const int EH = uni ? BH + 1 : UP(u_eh, un), EW = uni ? BW + 1 : UP(u_ew, un), nvox = (uni ? BD + 1 : UP(u_ed, un)) * EH * EW; \
       __syncthreads(); \
 _Pragma("unroll") \
       for (int it = 0; it < NIT; ++it) \
