@@ -4,10 +4,12 @@ data_loader_3d.py:6-49, base_data_loader.py:10-139), restated without batchgener
 
 Kept: the folder layout (`<case>.npy` [+ `<case>_seg.npy`] or `<case>.npz` with 'data'/'seg', `<case>.pkl` with
 'class_locations'), batches `{'data','seg','properties','keys'}`, cases drawn with replacement, foreground oversampling of the
-LAST round(B*(1-p)).. samples of a batch (p = 0.33, P/pretrain_AntoMask.py:337), the bounding-box rules (random corner inside
-[-pad//2, shape+pad//2+pad%2-patch], foreground: a random voxel of a random class centred, clamped at the low side), data padded
-with 0 and seg with -1.  Added: mirroring (the reference enables `MirrorTransform` on all axes, `:112-113`).  NOT restated: the
-`SpatialTransform` rotations / scalings (p = 0.2 each, `:90-97`) -- parity of this module is unpinned (no reference run possible).
+LAST round(B*(1-p)).. samples of a batch (p = 0.33, P/pretrain_AntoMask.py:337), the bounding-box rules with `need_to_pad`
+(enlarged initial patch, compute_initial_patch_size.py:4-24), data padded with 0 and seg with -1 -- pinned bit for bit against the
+reference's own loader (tests/golden/make_loader_fixtures.py imports it with a stub of the absent batchgenerators base class).
+The train transforms the drivers enable (SpatialTransform rotation / scaling, MirrorTransform; the intensity transforms are
+commented out in the reference, P/pretrain_AntoMask.py:99-109) run ON THE DEVICE (DeviceAugmenter -> csrc/aug_ops.hip); the host
+side only draws their parameters.  PrefetchLoader + DeviceFeed keep the GPU fed (pinned, double-buffered H2D on a copy stream).
 """
 import os
 import pickle
@@ -49,13 +51,24 @@ class PreprocessedDataset:
 
 
 class PatchLoader3D:
-    """Infinite iterator of nnU-Net style batches for `AnatoMaskTrainer.step(batch['data'])`."""
+    """nnUNetDataLoader3D.generate_train_batch (nnunetv2/training/dataloading/data_loader_3d.py:6-49) over get_bbox
+    (base_data_loader.py:64-139), restated without batchgenerators: an infinite iterator of
+    {'data' (B,C,*patch_size) fp32, 'seg' int16, 'properties', 'keys'} batches.
+
+    `patch_size` is what is CROPPED (the reference passes the enlarged `initial_patch_size` of get_patch_size, :312-318),
+    `final_patch_size` what the network gets after the spatial transform; need_to_pad = patch_size - final_patch_size lets the
+    crop hang over the volume border (base_data_loader.py:28-35).  One RandomState drives exactly the reference's draws in the
+    reference's order -- np.random.choice of the cases (batchgenerators DataLoader.get_indices, infinite=True), then per sample
+    either randint per axis or choice(class) + choice(voxel) -- so a loader seeded like np.random.seed reproduces the reference's
+    batches bit for bit (tests/golden/loader_tiny.npz).  Augmentation draws live in their own stream (SpatialAugmenter)."""
 
     def __init__(self, dataset: PreprocessedDataset, batch_size: int, patch_size: Sequence[int],
-                 oversample_foreground_percent: float = 0.33, seed: int = 0, mirror_axes: Tuple[int, ...] = (0, 1, 2),
-                 pin_memory: bool = True):
+                 oversample_foreground_percent: float = 0.33, seed: int = 0, final_patch_size: Optional[Sequence[int]] = None,
+                 pin_memory: bool = False):
         self.ds, self.B, self.patch = dataset, batch_size, tuple(int(v) for v in patch_size)
-        self.p_fg, self.rs, self.mirror_axes, self.pin = oversample_foreground_percent, np.random.RandomState(seed), mirror_axes, pin_memory
+        self.final = tuple(int(v) for v in (final_patch_size if final_patch_size is not None else patch_size))
+        self.need_to_pad = [self.patch[d] - self.final[d] for d in range(3)]
+        self.p_fg, self.rs, self.pin = oversample_foreground_percent, np.random.RandomState(seed), pin_memory
         self.keys = dataset.keys()
 
     def _force_fg(self, j: int) -> bool:                       # base_data_loader.py:47-51
@@ -63,15 +76,19 @@ class PatchLoader3D:
 
     def _bbox(self, shape, force_fg: bool, class_locations: Optional[Dict]):   # base_data_loader.py:64-139 (no ignore label)
         dim = len(shape)
-        pad = [max(self.patch[d] - shape[d], 0) for d in range(dim)]
+        pad = list(self.need_to_pad)
+        for d in range(dim):
+            if pad[d] + shape[d] < self.patch[d]:
+                pad[d] = self.patch[d] - shape[d]
         lbs = [-pad[d] // 2 for d in range(dim)]
         ubs = [shape[d] + pad[d] // 2 + pad[d] % 2 - self.patch[d] for d in range(dim)]
         voxel = None
-        if force_fg and class_locations:
+        if force_fg:
             eligible = [k for k, v in class_locations.items() if len(v) > 0]
             if eligible:
                 locs = class_locations[eligible[self.rs.choice(len(eligible))]]
-                voxel = locs[self.rs.choice(len(locs))]
+                if len(locs) > 0:
+                    voxel = locs[self.rs.choice(len(locs))]
         if voxel is not None:
             lb = [max(lbs[d], int(voxel[d + 1]) - self.patch[d] // 2) for d in range(dim)]
         else:
@@ -98,14 +115,153 @@ class PatchLoader3D:
             src = tuple(slice(vlb[d], vub[d]) for d in range(3))
             data_all[(j, slice(None)) + dst] = data[(slice(None),) + src]
             seg_all[(j, slice(None)) + dst] = seg[(slice(None),) + src]
-            for ax in self.mirror_axes:                        # MirrorTransform: each axis flipped with probability 1/2
-                if self.rs.uniform() < 0.5:
-                    data_all[j] = np.flip(data_all[j], ax + 1)
-                    seg_all[j] = np.flip(seg_all[j], ax + 1)
-        d = torch.from_numpy(np.ascontiguousarray(data_all))
+        d = torch.from_numpy(data_all)
         if self.pin and torch.cuda.is_available():
             d = d.pin_memory()
-        return {"data": d, "seg": torch.from_numpy(np.ascontiguousarray(seg_all)), "properties": props, "keys": sel}
+        return {"data": d, "seg": torch.from_numpy(seg_all), "properties": props, "keys": sel}
+
+
+# --------------------------------------------------------------------------- spatial augmentation
+def _rot_x(a):
+    return np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+
+
+def _rot_y(a):
+    return np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+
+
+def _rot_z(a):
+    return np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+
+
+def get_patch_size(final_patch_size, rot_x, rot_y, rot_z, scale_range):
+    """nnunetv2/training/data_augmentation/compute_initial_patch_size.py:4-24: the enlarged crop that still covers the final patch
+    after the largest rotation about each axis and the strongest zoom-out.  (rotate_coords_3d is batchgenerators': coords @ Rx Ry Rz.)"""
+    r = [min(np.pi / 2, max(np.abs(v)) if isinstance(v, (tuple, list)) else v) for v in (rot_x, rot_y, rot_z)]
+    coords = np.array(final_patch_size, dtype=np.float64)
+    final_shape = coords.copy()
+    for m in (_rot_x(r[0]), _rot_y(r[1]), _rot_z(r[2])):
+        final_shape = np.max(np.vstack((np.abs(coords @ m), final_shape)), 0)
+    final_shape /= min(scale_range)
+    return final_shape.astype(int)
+
+
+ROTATION_FOR_DA = (-30. / 360 * 2. * np.pi, 30. / 360 * 2. * np.pi)      # P/pretrain_AntoMask.py:303-307
+
+
+class SpatialAugmenter:
+    """Draws the per-sample parameters of the reference's train transforms (P/pretrain_AntoMask.py:78-113: SpatialTransform with
+    do_rotation p 0.2 (all three axes, +-30 deg), do_scale p 0.2 in (0.7, 1.4), no elastic deformation, order-3 data interpolation,
+    constant border 0, random_crop False; then MirrorTransform on axes (0, 1, 2) with p 0.5 each) and turns them into one 3x4 affine
+    per sample: output voxel index -> coordinate in the enlarged patch.  batchgenerators (>= 0.25, unpinned, absent here) is restated
+    from its published behaviour: zero-centred coordinate mesh, coords <- R^T coords with R = Rx Ry Rz, coords *= scale (scale < 1
+    with probability 1/2), + centre of the enlarged patch.  Its RNG stream cannot be reproduced (worker processes, unseeded), so only
+    the ARITHMETIC of a given draw is pinned (tests: against scipy.ndimage.map_coordinates)."""
+
+    def __init__(self, final_patch_size, seed: int = 0, p_rot: float = 0.2, p_scale: float = 0.2, scale=(0.7, 1.4),
+                 angle=ROTATION_FOR_DA, mirror_axes=(0, 1, 2), order: int = 3):
+        self.final = tuple(int(v) for v in final_patch_size)
+        self.rs = np.random.RandomState(seed)
+        self.p_rot, self.p_scale, self.scale, self.angle, self.mirror_axes, self.order = p_rot, p_scale, scale, angle, mirror_axes, order
+
+    def draw(self) -> dict:
+        rs, p = self.rs, {"angles": (0.0, 0.0, 0.0), "scale": 1.0, "modified": False, "mirror": [False, False, False]}
+        if rs.uniform() < self.p_rot:
+            p["angles"] = tuple(float(rs.uniform(*self.angle)) for _ in range(3))
+            p["modified"] = True
+        if rs.uniform() < self.p_scale:
+            lo, hi = self.scale
+            p["scale"] = float(rs.uniform(lo, 1)) if (rs.uniform() < 0.5 and lo < 1) else float(rs.uniform(max(lo, 1), hi))
+            p["modified"] = True
+        for ax in self.mirror_axes:
+            p["mirror"][ax] = bool(rs.uniform() < 0.5)
+        return p
+
+    def affine(self, p: dict, in_shape) -> np.ndarray:
+        """3x4: source coordinate = A (o, 1) for output index o of the final patch (mirroring folded in as o -> n-1-o)."""
+        ax, ay, az = p["angles"]
+        R = (_rot_x(ax) @ _rot_y(ay) @ _rot_z(az)).T * p["scale"]
+        ctr_out = np.array([(n - 1) / 2.0 for n in self.final])
+        ctr_in = np.array([n / 2.0 - 0.5 for n in in_shape])
+        if not p["modified"]:                      # batchgenerators centre-crops instead of interpolating: integer offsets
+            ctr_in = np.array([(in_shape[d] - self.final[d]) // 2 + ctr_out[d] for d in range(3)])
+            R = np.eye(3)
+        M = np.eye(3)
+        t = np.zeros(3)
+        for d in range(3):
+            if p["mirror"][d]:
+                M[d, d] = -1.0
+                t[d] = self.final[d] - 1
+        A = np.zeros((3, 4))
+        A[:, :3] = R @ M
+        A[:, 3] = R @ (t - ctr_out) + ctr_in
+        return A
+
+
+class DeviceAugmenter:
+    """Applies SpatialAugmenter draws ON THE GPU (am_spline_prefilter + am_resample_affine): enlarged device batch (B,1,De,He,We)
+    -> (B,1,D,H,W).  Unmodified samples are integer crops / flips of the raw volume (order 0); rotated / scaled ones are prefiltered in
+    a scratch copy and interpolated with order 3 (or 1)."""
+
+    def __init__(self, aug: SpatialAugmenter):
+        self.aug = aug
+        self._scratch = None
+
+    def __call__(self, x_enl: torch.Tensor, params: Optional[List[dict]] = None) -> torch.Tensor:
+        from . import ops
+        B, C = x_enl.shape[:2]
+        assert C == 1 and x_enl.dtype == torch.float32 and x_enl.is_cuda
+        params = params if params is not None else [self.aug.draw() for _ in range(B)]
+        out = torch.empty(B, 1, *self.aug.final, device=x_enl.device, dtype=torch.float32)
+        for b in range(B):
+            src = x_enl[b, 0]
+            A = self.aug.affine(params[b], src.shape)
+            if params[b]["modified"] and self.aug.order == 3:
+                if self._scratch is None or self._scratch.shape != src.shape:
+                    self._scratch = torch.empty_like(src)
+                self._scratch.copy_(src)
+                src = ops.spline_prefilter(self._scratch)
+            ops.resample_affine(src.contiguous(), out[b, 0], A.reshape(-1), self.aug.order if params[b]["modified"] else 0)
+        return out
+
+
+class PrefetchLoader:
+    """Background producers around a batch iterator factory (the role of LimitedLenWrapper / NonDetMultiThreadedAugmenter with
+    num_cached = 6, P/pretrain_AntoMask.py:343-345): `n_workers` threads each own a loader (their own RandomState: the reference's
+    workers are unseeded and unordered too) and push batches into one bounded queue.  numpy crops / copies / np.load release the
+    GIL, so threads scale; batches arrive in completion order."""
+
+    def __init__(self, make_loader, n_workers: int = 4, num_cached: int = 6):
+        import queue
+        import threading
+        self.q = queue.Queue(maxsize=num_cached)
+        self._stop = threading.Event()
+        self.threads = [threading.Thread(target=self._run, args=(make_loader, w), daemon=True) for w in range(n_workers)]
+        for t in self.threads:
+            t.start()
+
+    def _run(self, make_loader, w):
+        it = iter(make_loader(w))
+        while not self._stop.is_set():
+            try:
+                b = next(it)
+            except StopIteration:
+                break
+            while not self._stop.is_set():
+                try:
+                    self.q.put(b, timeout=0.1)
+                    break
+                except Exception:                   # queue.Full
+                    continue
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self.q.get()
+
+    def close(self):
+        self._stop.set()
 
 
 class DeviceFeed:

@@ -433,3 +433,19 @@ def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, e
 
 def ema(ema_t: torch.Tensor, p: torch.Tensor, decay: float):
     hip.lib().ema(ema_t.data_ptr(), p.data_ptr(), p.numel(), decay, _stream())
+
+
+# ------------------------------------------------------------------ data-feed augmentation (device side)
+def spline_prefilter(vol: torch.Tensor):
+    """in place: cubic B-spline coefficients of an fp32 [D,H,W] volume (== scipy.ndimage.spline_filter(order=3, mode='mirror'))."""
+    assert vol.dtype == torch.float32 and vol.dim() == 3 and vol.is_contiguous()
+    hip.lib().spline_prefilter(vol.data_ptr(), *vol.shape, _stream())
+    return vol
+
+
+def resample_affine(src: torch.Tensor, dst: torch.Tensor, affine_3x4, order: int, cval: float = 0.0):
+    """dst[o] = interp(src, A (o, 1)); src fp32 [Ds,Hs,Ws] (prefiltered when order == 3), dst fp32 [D,H,W]."""
+    assert src.dtype == dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous()
+    arr = (_ct.c_float * 12)(*[float(v) for v in affine_3x4])
+    hip.lib().resample_affine(src.data_ptr(), *src.shape, dst.data_ptr(), *dst.shape, _ct.addressof(arr), int(order), float(cval), _stream())
+    return dst

@@ -183,6 +183,16 @@ int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema /* may
                  float* gnorm_out, void* stream);
 int am_ema(float* ema, const float* p, long n, double decay, void* stream);
 
+/* Device-side spatial augmentation of the data feed: batchgenerators' SpatialTransform (rotation, isotropic scale,
+ * order-3 spline interpolation, constant border) + MirrorTransform as the reference configures them (P/pretrain_AntoMask.py:78-113),
+ * applied on the GPU to the enlarged patch the loader crops.  vol / src / dst: fp32 [D][H][W] device buffers of ONE sample.
+ * am_spline_prefilter: in place, == scipy.ndimage.spline_filter(order=3, mode='mirror').  am_resample_affine: dst[o] =
+ * interp(src, A (o,1)) with A a HOST array of 12 floats (3x4, row-major: output index -> source coordinate); order 0 (integer crop /
+ * flip), 1 (trilinear) or 3 (cubic B-spline over prefiltered coefficients, scipy map_coordinates(mode='constant') rules). */
+int am_spline_prefilter(float* vol, int D, int H, int W, void* stream);
+int am_resample_affine(const float* src, int Ds, int Hs, int Ws, float* dst, int D, int H, int W, const float* affine_host12, int order,
+                       float cval, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

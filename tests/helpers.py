@@ -69,3 +69,25 @@ def assert_checks(got, want, rtol, what=""):
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def make_synthetic_folder(folder, seed=7):
+    """A small nnU-Net v2 preprocessed folder (both storage forms, volumes smaller AND larger than the patches used in the tests,
+    two foreground classes of which one is empty in one case) -- the same call in tests/golden/make_loader_fixtures.py."""
+    import pickle
+    rs = np.random.RandomState(seed)
+    for name, shape in [("case_a", (40, 56, 48)), ("case_b", (20, 70, 33)), ("case_c", (64, 64, 64)), ("case_d", (30, 30, 90)), ("case_e", (52, 41, 37))]:
+        data = rs.standard_normal((1, *shape)).astype(np.float32)
+        seg = np.zeros((1, *shape), dtype=np.int16)
+        c = [s // 3 for s in shape]
+        seg[0, c[0]:c[0] + 4, c[1]:c[1] + 5, c[2]:c[2] + 3] = 1
+        if name != "case_d":
+            seg[0, -6:-2, 2:6, 1:4] = 2
+        locs = {k: np.argwhere(seg == k) for k in (1, 2)}          # rows (0, d, h, w) as nnU-Net stores them
+        if name in ("case_b", "case_e"):
+            np.savez(os.path.join(folder, name + ".npz"), data=data, seg=seg)
+        else:
+            np.savez(os.path.join(folder, name + ".npz"), data=data[:, :1], seg=seg[:, :1])     # (placeholder: the .npy pair is what is read)
+            np.save(os.path.join(folder, name + ".npy"), data); np.save(os.path.join(folder, name + "_seg.npy"), seg)
+        with open(os.path.join(folder, name + ".pkl"), "wb") as f:
+            pickle.dump({"class_locations": locs, "spacing": [1.0, 1.0, 1.0]}, f)
