@@ -35,6 +35,7 @@ class Spec:
     out_ch: int = 1
     downsample: int = 16
     n_stage: int = 5
+    sync_bn: bool = False        # decoder BatchNorm statistics over ALL ranks (nn.SyncBatchNorm, P/decoder3D.py:42-43)
     enc_chs: List[int] = field(init=False)
     dec_chs: List[int] = field(init=False)
     fmap: Tuple[int, int, int] = field(init=False)
@@ -97,8 +98,32 @@ def _sparse_norm(x, mask, bs, counts, gamma, beta, eps, part=None) -> NormStats:
     return st
 
 
-def _batch_norm(x, W, prefix, train: bool, part=None, update_running: bool = True) -> NormStats:
+def _sync_world(sync: bool) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if (sync and dist.is_available() and dist.is_initialized()) else 1
+
+
+def _batch_norm(x, W, prefix, train: bool, part=None, update_running: bool = True, sync: bool = False) -> NormStats:
     st = NormStats(x.shape[-1], x.device)
+    world = _sync_world(sync and train)
+    if train and world > 1:
+        # SyncBatchNorm: per-channel (sum, sum of squares) of the LOCAL batch -> all-reduce -> statistics of the global batch
+        # (every rank holds the same number of voxels: equal per-GPU batches), running stats from the global unbiased variance
+        import torch.distributed as dist
+        st.count_host = float(x.numel() // x.shape[-1]) * world
+        if part is not None:
+            part.reduce(sums=st.sums); st.nrep = 1
+        else:
+            ops.chan_stats(x, None, 0, st)
+        red = st.sums[:st.nrep]
+        dist.all_reduce(red)
+        st.sync_world = world
+        if update_running:
+            ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5, W[f"{prefix}.running_mean"], W[f"{prefix}.running_var"], 0.1)
+            W[f"{prefix}.num_batches_tracked"].add_(1)
+        else:
+            ops.norm_finalize(st, W[f"{prefix}.weight"], W[f"{prefix}.bias"], 1e-5)
+        return st
     if train:
         st.count_host = float(x.numel() // x.shape[-1])
         if part is not None:                                      # reduce + finalize (+ running stats, num_batches_tracked) in one launch
@@ -194,7 +219,7 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
     return out, rec_
 
 
-def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False, out_skip=None):
+def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False, out_skip=None, sync: bool = False):
     """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record)."""
     q = f"{DEC}.{i}"
     so = tuple(2 * v for v in x.shape[1:4])
@@ -216,12 +241,12 @@ def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, 
     c1, pt1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1, want_partials=train), None
     if train:
         c1, pt1 = c1
-    st1 = _batch_norm(c1, W, f"{q}.conv.1", train, pt1, update_running)
+    st1 = _batch_norm(c1, W, f"{q}.conv.1", train, pt1, update_running, sync)
     r = ops.norm_apply(c1, st1, ACT_RELU6)
     c2, pt2 = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1, want_partials=train), None
     if train:
         c2, pt2 = c2
-    st2 = _batch_norm(c2, W, f"{q}.conv.4", train, pt2, update_running)
+    st2 = _batch_norm(c2, W, f"{q}.conv.4", train, pt2, update_running, sync)
     o = ops.norm_apply(c2, st2, ACT_NONE, res=nxt)            # x = x + to_dec[i+1] fused into the BN apply
     return o, {"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2}
 
@@ -274,7 +299,7 @@ def decoder_forward(spec: Spec, W, pk: PackCache, to_dec, train: bool, tape: Opt
     for i in range(n_dec):
         nxt = to_dec[i + 1] if i + 1 < n_dec else None
         o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=fuse_eval,
-                             out_skip=needed_patches if (i == n_dec - 1 and tape is None and not train) else None)
+                             out_skip=needed_patches if (i == n_dec - 1 and tape is None and not train) else None, sync=spec.sync_bn)
         if tape is not None:
             tape.dec.append({"q": rec_["q"], "xin": x, "nxt": nxt} if recompute else rec_)
         x = o
@@ -359,7 +384,7 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
     for i in reversed(range(n_dec)):
         t = tape.dec[i]
         if tape.recompute:                        # P/GC.py:68: re-run the block forward from its saved input
-            _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False)
+            _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False, sync=spec.sync_bn)
             tape.dec[i] = None
         q = t["q"]
         if i + 1 < n_dec:

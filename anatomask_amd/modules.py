@@ -261,8 +261,10 @@ class LightDecoder(nn.Module):
         super().__init__()
         self.width = width
         assert up_sample_ratio > 0 and up_sample_ratio & (up_sample_ratio - 1) == 0
-        if sbn or use_IN:
-            raise NotImplementedError("AnatoMask drivers use sbn=False, use_IN=False (P/pretrain_AntoMask.py:212)")
+        if use_IN:
+            raise NotImplementedError("the drivers use use_IN=False (P/pretrain_AntoMask.py:212)")
+        self.sbn = bool(sbn)              # nn.SyncBatchNorm in the reference (P/decoder3D.py:42-43; on in plain-SparK DDP, P/pretrain_DDP.py:225):
+        # same parameters / buffers / state_dict keys as BatchNorm3d; the engine all-reduces the batch statistics when a process group is up
         n = round(math.log2(up_sample_ratio))
         channels = [self.width // 2 ** i for i in range(n + 1)]
         self.dec = nn.ModuleList([UNetBlock(cin, cout, nn.BatchNorm3d) for cin, cout in zip(channels[:-1], channels[1:])])
@@ -412,7 +414,7 @@ class SparK(nn.Module):
             self.densify_projs.append(proj)
             d_width //= 2
         cnn = sparse_encoder.sp_cnn
-        self.spec = Spec(cnn.dims, cnn.depth, dense_decoder.width, tuple(input_size))
+        self.spec = Spec(cnn.dims, cnn.depth, dense_decoder.width, tuple(input_size), sync_bn=bool(getattr(dense_decoder, "sbn", False)))
         self.compute_dtype = compute_dtype
         import weakref                       # sub-modules called on their own (model.sparse_encoder(x), model.dense_decoder(to_dec))
         cnn.__dict__["_owner"] = dense_decoder.__dict__["_owner"] = weakref.ref(self)   # run on THIS model's flat buffers
@@ -690,11 +692,11 @@ def ema_decay_for_epoch(i: int, total_epochs: int) -> float:
     return 0.999 + i / q * (0.9999 - 0.999) if i < q else 0.9999
 
 
-def build_spark(dims, depth, width, input_size, mask_ratio=0.6, compute_dtype=torch.float32, recompute=False) -> SparK:
-    """The model build of P/pretrain_AntoMask.py:184-217 in one call."""
+def build_spark(dims, depth, width, input_size, mask_ratio=0.6, compute_dtype=torch.float32, recompute=False, sbn=False) -> SparK:
+    """The model build of P/pretrain_AntoMask.py:184-217 in one call (sbn=True: the decoder of P/pretrain_DDP.py:225)."""
     head = STUNet(1, 1, depth=list(depth), dims=list(dims))
     enc = SparseEncoder(head, input_size=tuple(input_size), sbn=False)
-    dec = LightDecoder(enc.downsample_ratio, sbn=False, width=width, out_channel=1)
+    dec = LightDecoder(enc.downsample_ratio, sbn=sbn, width=width, out_channel=1)
     return SparK(sparse_encoder=enc, dense_decoder=dec, mask_ratio=mask_ratio, densify_norm="in", compute_dtype=compute_dtype,
                  recompute=recompute)
 

@@ -266,6 +266,7 @@ class NormStats:
         self.mean, self.rstd, self.scale, self.shift = self.buf[0], self.buf[1], self.buf[2], self.buf[3]
         self.count_ptr: Optional[torch.Tensor] = None
         self.count_host: float = 0.0
+        self.sync_world: int = 1          # > 1: SyncBatchNorm statistics (the backward all-reduces its two sums as well)
 
 
 def chan_stats(x: torch.Tensor, mask: Optional[MaskInfo], bshift: int, st: NormStats):
@@ -323,6 +324,25 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
     L = hip.lib()
     s = _stream()
     ws_b, ws_x = _bwd_workspaces(x.device, Cc)
+    if st.sync_world > 1:
+        # SyncBatchNorm backward (torch.nn.SyncBatchNorm): dx needs the sums over the GLOBAL batch, the affine gradients stay LOCAL
+        # sums (DDP then averages them like every other gradient): reduce -> finalize (param grads) -> all-reduce -> finalize (k's)
+        import torch.distributed as dist
+        L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
+                          st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), ws_b.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),
+                          *_al(mask), None, 0.0, None, None, None, None, None, None, None, None, s)
+        L.norm_bwd_finalize(ws_b.data_ptr(), None, float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
+                            sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
+        dist.all_reduce(ws_b[:NREP * Cc * 3])
+        L.norm_bwd_finalize(ws_b.data_ptr(), None, float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
+                            sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), None, None, None, None, s)
+        ws_b[:NREP * Cc * 3].zero_()                                   # the workspace contract: left zero
+        if dx is None:
+            dx = torch.empty_like(x)
+        L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
+                         st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
+                         dx.data_ptr(), _p(dres), _p(dxsum), ws_x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), *_al(mask), 1, s)
+        return dx
     if not FUSED_BWD_TAILS:                      # (tools/step_ab.py: the three-launch form, for same-process A/B timing)
         L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                           st.mean.data_ptr(), st.rstd.data_ptr(), act, int(fill), ws_b.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(),

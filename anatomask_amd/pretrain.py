@@ -1,68 +1,117 @@
 #!/usr/bin/env python
-"""AnatoMask pretraining driver on the HIP engine: the loop of P/pretrain_AntoMask.py:371-479 (single GPU) and
-P/pretrain_AnatoMask_DDP.py:421-513 (torchrun, one process per GPU, RCCL) with the reference's hyper-parameters as defaults,
-lifted from in-script literals into flags (SURVEY.md 5 "Config").
+"""Pretraining driver on the HIP engine: the loops of P/pretrain_AntoMask.py:371-479 (AnatoMask, single GPU),
+P/pretrain_AnatoMask_DDP.py:421-513 (one process per GPU, RCCL) and P/pretrain.py:376-493 (plain SparK: per-epoch validation pass
+in eval mode, best + latest checkpoints) with the reference's hyper-parameters as defaults, lifted from in-script literals into
+flags (SURVEY.md 5 "Config").
 
-    python -m anatomask_amd.pretrain --model B --input-size 112 112 128 --batch-size 4 --data /path/with/npy --out run1
-    python -m torch.distributed.run --nproc-per-node 8 -m anatomask_amd.pretrain ...
+    python -m anatomask_amd.pretrain --model B --input-size 112 112 128 --batch-size 4 --data /path/to/preprocessed --out run1
+    python -m anatomask_amd.pretrain --gpus 8 ...          # launches itself: one rank per GPU (anatomask_amd.launch), or run under torchrun
 
-Data: any iterator yielding nnU-Net style batches {'data': float32 (B,1,H,W,D)} works (that is all the step consumes,
-P/pretrain_AntoMask.py:390-392).  `--data DIR`: an nnU-Net v2 preprocessed folder (<case>.npy|.npz + <case>.pkl) goes through
-`anatomask_amd.data` (foreground oversampling 0.33, mirroring, as the reference's loader); a folder of bare .npy volumes gets
-random crops; without --data the batches are synthetic.
+Data (`--data DIR`, an nnU-Net v2 preprocessed folder: <case>.npy|.npz + <case>.pkl): loader threads crop the ENLARGED patch
+(get_patch_size) with foreground oversampling 0.33 straight into pinned buffers (anatomask_amd.data), a copy stream moves them to
+the GPU one batch ahead, and the spatial augmentation of the reference's train transforms (rotation / scaling p 0.2, order-3
+interpolation; mirroring p 0.5 per axis) runs on the device.  Without --data the batches are synthetic N(0,1).
 """
 import argparse
-import glob
 import math
 import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import checkpoint
-from .data import PatchLoader3D, PreprocessedDataset
-from .modules import STUNET_CONFIGS, build_spark, ema_decay_for_epoch, linear_warmup_cosine_lrs
+from . import checkpoint, launch
+from .data import (DeviceAugmenter, DeviceFeed, PatchLoader3D, PinnedPool, PrefetchLoader, PreprocessedDataset, ROTATION_FOR_DA, SpatialAugmenter,
+                   get_patch_size)
+from .modules import STUNET_CONFIGS, build_spark, linear_warmup_cosine_lrs
 from .trainer import AnatoMaskTrainer
 
 
-def npy_crop_batches(files, batch, size, iters, seed):
-    """Random crops of preprocessed volumes (zero-padded when a volume is smaller), the role nnUNetDataLoader3D plays."""
-    rs = np.random.RandomState(seed)
-    for _ in range(iters):
-        out = np.zeros((batch, 1, *size), dtype=np.float32)
-        for b in range(batch):
-            v = np.load(files[rs.randint(len(files))], mmap_mode="r")
-            v = v[0] if v.ndim == 4 else v
-            lo = [rs.randint(0, max(s - c, 0) + 1) for s, c in zip(v.shape, size)]
-            crop = np.asarray(v[lo[0]:lo[0] + size[0], lo[1]:lo[1] + size[1], lo[2]:lo[2] + size[2]], dtype=np.float32)
-            out[b, 0, :crop.shape[0], :crop.shape[1], :crop.shape[2]] = crop
-        yield {"data": torch.from_numpy(out).pin_memory()}
-
-
-def synthetic_batches(batch, size, iters, seed):
+def synthetic_batches(batch, size, seed):
     g = torch.Generator().manual_seed(seed)
-    for _ in range(iters):
+    while True:
         yield {"data": torch.randn(batch, 1, *size, generator=g)}
+
+
+def split_cases(keys, val_fraction=0.2, seed=12345):
+    """train / validation split of the case list (the reference: sklearn train_test_split(test_size 0.2, random_state 12345) on the
+    sorted keys, P/pretrain.py:283-285 -- restated as a seeded permutation; the exact sklearn shuffle is not reproduced)."""
+    import numpy as np
+    keys = sorted(keys)
+    perm = np.random.RandomState(seed).permutation(len(keys))
+    n_val = max(1, int(round(len(keys) * val_fraction))) if len(keys) > 1 else 0
+    val = sorted(keys[i] for i in perm[:n_val])
+    return [k for k in keys if k not in set(val)], val
+
+
+class Feed:
+    """loader threads -> pinned pool -> copy stream -> device augmentation; next(feed) is a (B,1,*input_size) device tensor."""
+
+    def __init__(self, folder, cases, batch, input_size, dev, rank, workers, augment: bool, seed: int):
+        ds = PreprocessedDataset(folder, cases)
+        rot = ROTATION_FOR_DA
+        enl = tuple(int(v) for v in get_patch_size(tuple(input_size), rot, rot, rot, (0.85, 1.25))) if augment else tuple(input_size)
+        self.pool = PinnedPool((batch, 1, *enl), n=6 + 2 + workers)
+        self.loaders = {}
+
+        def make(w):
+            ld = PatchLoader3D(ds, batch, enl, 0.33, seed=seed + 1000 * rank + w, final_patch_size=tuple(input_size), pool=self.pool)
+            self.loaders[w] = ld
+            return ld
+        self.pf = PrefetchLoader(make, n_workers=workers, num_cached=6)
+        self.feed = DeviceFeed(self.pf, dev)
+        self.aug = DeviceAugmenter(SpatialAugmenter(tuple(input_size), seed=seed + 77 + rank,
+                                                    p_rot=0.2 if augment else 0.0, p_scale=0.2 if augment else 0.0,
+                                                    mirror_axes=(0, 1, 2) if augment else ()))
+
+    def __next__(self):
+        return self.aug(next(self.feed))
+
+    def state(self):
+        return {"loader_rng": {w: ld.rs.get_state() for w, ld in self.loaders.items()}, "aug_rng": self.aug.aug.rs.get_state()}
+
+    def load_state(self, st):
+        for w, s in (st or {}).get("loader_rng", {}).items():
+            if w in self.loaders:
+                self.loaders[w].rs.set_state(s)
+        if st and "aug_rng" in st:
+            self.aug.aug.rs.set_state(st["aug_rng"])
+
+    def close(self):
+        self.pf.close()
+
+
+def all_ranks_finite(value: float, dev, world: int) -> bool:
+    """every rank stops together: a rank that exits alone leaves its peers hanging in the next all-reduce."""
+    ok = torch.tensor([1.0 if math.isfinite(value) else 0.0], device=dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    return bool(ok.item() > 0)
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1, help="> 1 without a launcher: start one rank per GPU (anatomask_amd.launch)")
     ap.add_argument("--model", default="B", choices=list(STUNET_CONFIGS))
     ap.add_argument("--input-size", type=int, nargs=3, default=[112, 112, 128])       # P/pretrain_AntoMask.py:209
     ap.add_argument("--mask-ratio", type=float, default=0.6)                          # :215
     ap.add_argument("--epochs", type=int, default=1000)                               # :228
     ap.add_argument("--iters-per-epoch", type=int, default=250)
+    ap.add_argument("--val-iters", type=int, default=50)
     ap.add_argument("--batch-size", type=int, default=4, help="per GPU (:229)")
     ap.add_argument("--lr", type=float, default=1e-4); ap.add_argument("--weight-decay", type=float, default=1e-5)
     ap.add_argument("--clip", type=float, default=12.0); ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--data", default=None); ap.add_argument("--out", default="anatomask_run")
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--no-augment", action="store_true")
     ap.add_argument("--resume", default=None)
-    ap.add_argument("--plain-spark", action="store_true", help="plain SparK baseline (P/pretrain.py): random mask, no teacher")
+    ap.add_argument("--plain-spark", action="store_true", help="plain SparK baseline (P/pretrain.py): random mask, no teacher, validation + best ckpt")
+    ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm statistics in the decoder (P/pretrain_DDP.py:225)")
     a = ap.parse_args(argv)
+    if a.gpus > 1 and not launch.launched():
+        sys.exit(launch.self_launch(a.gpus, "-m", ["anatomask_amd.pretrain", *(argv if argv is not None else sys.argv[1:])]))
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -73,37 +122,61 @@ def main(argv=None):
     torch.manual_seed(0)
     kw = STUNET_CONFIGS[a.model]
     model = build_spark(kw["dims"], kw["depth"], kw["width"], tuple(a.input_size), a.mask_ratio,
-                        compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32).to(dev)
+                        compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32, sbn=a.sync_bn).to(dev)
     trainer = AnatoMaskTrainer(model, lr=a.lr, weight_decay=a.weight_decay, clip=a.clip, total_epochs=a.epochs, seed=4321 + rank,
                                self_distill=not a.plain_spark)
+    trainer.rank = rank
     lrs = linear_warmup_cosine_lrs(a.epochs, a.lr, a.warmup, 1e-6)                    # :359
-    start = checkpoint.load_checkpoint(a.resume, trainer) if a.resume else 0
-    files = sorted(glob.glob(os.path.join(a.data, "*.npy"))) if a.data else None
-    nnunet_feed = None
-    if a.data and glob.glob(os.path.join(a.data, "*.pkl")):          # nnU-Net v2 preprocessed folder
-        nnunet_feed = PatchLoader3D(PreprocessedDataset(a.data), a.batch_size, a.input_size, 0.33, seed=1000 + rank)
-    epoch_loss, ema_loss = [], None
+    feed = val_feed = None
+    if a.data:
+        tr_keys, val_keys = split_cases(PreprocessedDataset(a.data).keys()) if a.plain_spark else (PreprocessedDataset(a.data).keys(), [])
+        feed = Feed(a.data, tr_keys, a.batch_size, a.input_size, dev, rank, a.workers, not a.no_augment, seed=1000)
+        if a.plain_spark and val_keys:
+            val_feed = Feed(a.data, val_keys, a.batch_size, a.input_size, dev, rank, max(1, a.workers // 4), False, seed=5000)
+    else:
+        gen = synthetic_batches(a.batch_size, a.input_size, 1000 + rank)
+        feed = type("Syn", (), {"__next__": lambda s: next(gen)["data"].to(dev, non_blocking=True), "state": lambda s: {}, "load_state": lambda s, st: None,
+                                "close": lambda s: None})()
+    start, epoch_loss, val_loss, ema_loss, best_val = 0, [], [], None, 1e9
+    if a.resume:
+        ck = checkpoint.load_checkpoint(a.resume, trainer, rank)
+        start = int(ck["current_epoch"]) + 1
+        epoch_loss, val_loss, ema_loss = list(ck.get("train_loss", [])), list(ck.get("val_loss", [])), ck.get("ema_loss")
+        best_val = ck.get("best_val_loss", best_val)
+        feed.load_state(ck.get("feed_state", {}).get(rank))
     for i in range(start, a.epochs):
         trainer.set_epoch(i); trainer.lr = lrs[i]                                     # :383-386, :452
-        if nnunet_feed is not None:
-            it = (next(nnunet_feed) for _ in range(a.iters_per_epoch))
-        else:
-            it = (npy_crop_batches(files, a.batch_size, a.input_size, a.iters_per_epoch, 1000 * i + rank) if files
-                  else synthetic_batches(a.batch_size, a.input_size, a.iters_per_epoch, 1000 * i + rank))
         t0, acc = time.time(), torch.zeros(1, device=dev)
-        for batch in it:
-            out = trainer.step(batch["data"].to(dev, non_blocking=True), epoch=i)
+        for _ in range(a.iters_per_epoch):
+            out = trainer.step(next(feed), epoch=i)
             acc += out["loss"]
         loss = acc.item() / a.iters_per_epoch                                          # ONE host sync per epoch
-        if not math.isfinite(loss):                                                    # :443-446
+        if not all_ranks_finite(loss, dev, world):                                     # :443-446, on every rank together
             print(f"[rk{rank:02d}] Loss is {loss}, stopping training!", flush=True)
             sys.exit(-1)
         epoch_loss.append(loss)
         ema_loss = loss if ema_loss is None else 0.9 * ema_loss + 0.1 * loss           # :456-461
+        extra = {"ema_loss": ema_loss, "feed_state": {rank: feed.state()}}
+        if a.plain_spark and val_feed is not None:                                     # P/pretrain.py:426-463: eval() pass, no grad, BN on running stats
+            vacc = torch.zeros(1, device=dev)
+            for _ in range(a.val_iters):
+                vacc += trainer.eval_loss(next(val_feed))
+            v = vacc.item() / a.val_iters
+            val_loss.append(v)
+            if v < best_val and rank == 0:
+                best_val = v
+                checkpoint.save_checkpoint(os.path.join(a.out, f"STUNet_{a.model}_head_best.pt"), trainer, epoch_loss, i, val_loss,
+                                           dict(extra, best_val_loss=best_val))
         if rank == 0:
-            print(f"Epoch {i} lr {lrs[i]:.2e} ema_decay {trainer.teacher.decay:.5f} train loss {loss:.4f} (ema {ema_loss:.4f}) "
-                  f"{time.time() - t0:.1f} s, {a.iters_per_epoch * a.batch_size * world / (time.time() - t0):.1f} volumes/s", flush=True)
-            checkpoint.save_checkpoint(os.path.join(a.out, f"STUNet_{a.model}_head_latest.pt"), trainer, epoch_loss, i)   # :472-479
+            dt = time.time() - t0
+            print(f"Epoch {i} lr {lrs[i]:.2e} ema_decay {trainer.teacher.decay:.5f} train loss {loss:.4f} (ema {ema_loss:.4f})"
+                  + (f" val loss {val_loss[-1]:.4f} (best {best_val:.4f})" if val_loss else "")
+                  + f" {dt:.1f} s, {a.iters_per_epoch * a.batch_size * world / dt:.1f} volumes/s", flush=True)
+            checkpoint.save_checkpoint(os.path.join(a.out, f"STUNet_{a.model}_head_latest.pt"), trainer, epoch_loss, i,
+                                       val_loss if a.plain_spark else None, dict(extra, best_val_loss=best_val))   # :472-479
+    feed.close()
+    if val_feed is not None:
+        val_feed.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -147,6 +147,22 @@ class AnatoMaskTrainer:
         m.weights_changed(); t.weights_changed()
         return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": recon, "rec_loss": l2m}
 
+    @torch.no_grad()
+    def eval_loss(self, inp_bchwd: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Validation pass of the plain-SparK driver (P/pretrain.py:426-441: model.eval(), no grad, random mask, the normalised
+        masked MSE of P/spark3D.py:130-146): student in eval mode -- decoder BatchNorm on running statistics.  Returns loss[1]."""
+        m, spec = self.model, self.model.spec
+        x = inp_bchwd[:, 0].float().contiguous()
+        B, L = x.shape[0], spec.fmap[0] * spec.fmap[1] * spec.fmap[2]
+        if mask is None:
+            mk = ops.mask_sampler(torch.zeros(B, L, device=x.device), torch.rand(B, L, device=x.device, generator=self.gen), m.len_keep, 0)
+            mi = ops.MaskInfo(mk.view(B, *spec.fmap), n_active=B * m.len_keep)
+        else:
+            mi = ops.MaskInfo(mask.reshape(B, *spec.fmap).to(device=x.device, dtype=torch.uint8).contiguous())
+        rec = engine.forward(spec, m._W, m._pack, x, mi, train=False)
+        _, _, _, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
+        return info[0:1]
+
     def set_epoch(self, i: int):
         """per-epoch EMA decay ramp (P/pretrain_AntoMask.py:383-386)."""
         self.teacher.decay = ema_decay_for_epoch(i, self.total_epochs)

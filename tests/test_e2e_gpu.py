@@ -424,6 +424,7 @@ def test_trainer_distributed_path_single_rank_nccl():
 
 
 def test_checkpoint_roundtrip_and_finetune_handoff(tmp_path):
+    import os
     """Reference checkpoint format (P/pretrain_AntoMask.py:472-479), resume, and the key contract of
     load_stunet_ssl_weights (nnunetv2/run/load_pretrained_weights.py:66-106)."""
     from anatomask_amd import checkpoint
@@ -444,8 +445,16 @@ def test_checkpoint_roundtrip_and_finetune_handoff(tmp_path):
     assert ck["grad_scaler_state"] is None and len(ck["network_weights"]) == 131
     enc = checkpoint.encoder_weights_for_finetuning(ck["network_weights"])
     assert len(enc) == 50 and "conv_blocks_context.0.0.conv1.weight" in enc and all(k.startswith("conv_blocks_context.") for k in enc)
+    # the reference's resume hint (P/pretrain_AntoMask.py:360): torch.optim.AdamW built from get_param_groups accepts 'optimizer_state'
+    from anatomask_amd import modules as M
+    ref_opt = torch.optim.AdamW(M.get_param_groups(a.model, nowd_keys={"cls_token", "pos_embed", "mask_token", "gamma"}), lr=1e-3, weight_decay=1e-5)
+    ref_opt.load_state_dict(ck["optimizer_state"])
+    first = ref_opt.param_groups[0]["params"][0]
+    assert ref_opt.state[first]["exp_avg"].shape == first.shape and float(ref_opt.state[first]["step"]) == 1.0
+    assert torch.equal(ref_opt.state[first]["exp_avg"].cpu(), a.m[:first.numel()].view(first.shape).cpu())
+    assert not os.path.exists(p + ".tmp")
     b = fresh()
-    assert checkpoint.load_checkpoint(p, b) == 1
+    assert int(checkpoint.load_checkpoint(p, b)["current_epoch"]) + 1 == 1
     oa, ob = a.step(x, epoch=500), b.step(x, epoch=500)          # same RNG state, weights, moments, teacher -> same step
     assert abs(oa["loss"].item() - ob["loss"].item()) < 1e-6
     assert torch.equal(oa["mask"], ob["mask"])
@@ -660,3 +669,36 @@ def test_standalone_encoder_outside_spark_matches(fwd):
     M._cur_active = None
     for fa, fb in zip(a, b):
         assert torch.equal(fa, fb)
+
+
+def test_plain_spark_validation_loss_vs_oracle(fwd):
+    """AnatoMaskTrainer.eval_loss: the per-epoch validation pass of the plain-SparK driver (P/pretrain.py:426-441, eval mode: decoder
+    BatchNorm on running statistics, no grad) against the CPU oracle."""
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    cfg = tiny_cfg(fwd)
+    W0 = fixture_weights(cfg, fwd)
+    x = np_volume(2, cfg.input_size, 61)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(12))
+    tr = AnatoMaskTrainer(make_model(cfg, W0), lr=1e-3, total_epochs=1000, distributed=False, self_distill=False)
+    got = tr.eval_loss(x.to(DEV), mask).item()
+    ip, rp = O.spark_forward(cfg, {k: v.clone() for k, v in W0.items()}, x, mask, train=False)
+    want = float(O.forward_loss(ip, rp, mask)[0])
+    assert abs(got - want) < 2e-4 * abs(want), (got, want)
+    sd = tr.model.state_dict()
+    assert all(int(v) == 0 for k, v in sd.items() if k.endswith("num_batches_tracked"))      # eval: buffers untouched
+    assert torch.isfinite(tr.eval_loss(x.to(DEV))).all()                                     # random-mask form
+
+
+def test_syncbn_two_ranks_equal_one_big_batch():
+    """LightDecoder(sbn=True) (nn.SyncBatchNorm in the reference, P/decoder3D.py:42-43, P/pretrain_DDP.py:225): two ranks x 2 volumes ==
+    one rank x 4 volumes with plain BatchNorm (tools/syncbn_two_ranks.py; gloo over device tensors on the one GPU a box has)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(root, "tools", "syncbn_two_ranks.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("syncbn ok: True") == 2, r.stdout[-2000:]
