@@ -307,5 +307,36 @@ def main():
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) == 1:
     main()
+
+
+def finetune_handoff_fixture():
+    """F10: the reference's OWN finetune loader (nnunetv2/run/load_pretrained_weights.py:66-106, load_stunet_ssl_weights) applied to a
+    checkpoint in the layout anatomask_amd.checkpoint writes ('network_weights' with 'module.'-prefixed SparK keys): which keys of the
+    encoder-only STUNet (P/STUNet_head.py) it fills and with what.  Run: python tests/golden/make_fixtures.py finetune"""
+    import tempfile
+    from nnunetv2.run.load_pretrained_weights import load_stunet_ssl_weights
+    cfg = O.Config([8, 16, 32, 64, 128, 128], [1] * 6, 128, (32, 48, 64), 0.6)
+    W0 = O.seeded_state(cfg, WEIGHT_SEED)
+    net = ref_head.STUNet(1, 1, depth=cfg.depth, dims=cfg.dims, pool_op_kernel_sizes=[[2, 2, 2]] * 4 + [[1, 1, 1]],
+                          conv_kernel_sizes=[[3, 3, 3]] * 6, enable_deep_supervision=True)
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "STUNet_tiny_head_latest.pt")
+        torch.save({"network_weights": {"module." + k: v for k, v in W0.items()}, "optimizer_state": {}, "grad_scaler_state": None,
+                    "train_loss": [1.0], "current_epoch": 0}, f)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            load_stunet_ssl_weights(net, f)
+    after = net.state_dict()
+    keys = list(after.keys())
+    out = {"keys": np.array(keys), "changed": np.array([not torch.equal(before[k], after[k]) for k in keys]),
+           "checks": np.stack([checks(after[k].float()) for k in keys]), "weight_seed": np.array(WEIGHT_SEED)}
+    np.savez_compressed(os.path.join(HERE, "finetune_tiny.npz"), **out)
+    print("finetune_tiny.npz:", len(keys), "keys,", int(out["changed"].sum()), "filled by the reference loader")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "finetune":
+    finetune_handoff_fixture()

@@ -246,3 +246,18 @@ def test_bf16_storage_emulation_is_identity_in_fp32_mode_and_close_in_bf16(fwd, 
     e = grad_errors({k: v for k, v in g1.items() if v is not None}, fwd)
     med = np.median([v[0] for v in e.values() if v[1] is not None])
     assert 0.02 < med < 0.6, med
+
+
+def test_finetune_handoff_matches_reference_loader():
+    """tests/golden/finetune_tiny.npz: what the reference's load_stunet_ssl_weights (nnunetv2/run/load_pretrained_weights.py:66-106)
+    put into the encoder-only STUNet from a checkpoint in our layout.  encoder_weights_for_finetuning must hand over exactly those
+    50 tensors under exactly those keys."""
+    from anatomask_amd.checkpoint import encoder_weights_for_finetuning
+    ft, f = load("finetune_tiny.npz"), load("forward_tiny.npz")
+    cfg = tiny_cfg(f)
+    W0 = O.seeded_state(cfg, int(ft["weight_seed"]))
+    enc = encoder_weights_for_finetuning({"module." + k: v for k, v in W0.items()})
+    keys = [str(k) for k in ft["keys"]]
+    assert sorted(enc) == sorted(keys) and len(keys) == 50 and bool(ft["changed"].all())
+    for k, want in zip(keys, ft["checks"]):
+        assert_checks(enc[k], want, 0.0, k)
