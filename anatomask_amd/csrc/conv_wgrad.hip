@@ -37,7 +37,7 @@ struct WgArgs {
   MaskView x_mask, y_mask;
   int split;                  // brick-walk slots per (tile, group)
 #ifdef AM_ABLATE
-  int dbg;                    // tools-only build (-DAM_ABLATE): AM_WG_DBG ablation bits, 1 no flush, 2 no contraction
+  int dbg;                    // tools-only build (-DAM_ABLATE): AM_WG_DBG ablation bits, 1 no flush, 2 no contraction, 4 no global loads, 8 no LDS staging writes
 #endif
 };
 #ifdef AM_ABLATE
@@ -46,6 +46,12 @@ struct WgArgs {
 #define AM_DBG(a_, bit_) false
 #endif
 
+
+inline int wg_slots(int occ) {                    // resident workgroups of the whole device
+  static int ncu = 0;
+  if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
+  return occ * ncu;
+}
 
 __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -211,17 +217,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     // are then OOB-marked); hardware zero-fill for OOB rows
 #pragma unroll
     for (int it = 0; it < NITY; ++it)
-      ys[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, yo[it] == OOB ? OOB : yo[it] + (unsigned)ybaseB, 0, 0));
+      ys[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (yo[it] == OOB || AM_DBG(a, 4)) ? OOB : yo[it] + (unsigned)ybaseB, 0, 0));
 #pragma unroll
     for (int it = 0; it < NITX; ++it)
-      xs[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, xo[it] == OOB ? OOB : xo[it] + (unsigned)xbaseB, 0, 0));
+      xs[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo[it] == OOB || AM_DBG(a, 4)) ? OOB : xo[it] + (unsigned)xbaseB, 0, 0));
     __syncthreads();                                     // previous brick's fragment reads are done
 #pragma unroll
     for (int it = 0; it < NITY; ++it)
-      if (tid / CPRY + it * VPI_Y < MV) *(u32x4*)(ldsY + ydst0 + it * VPI_Y * RSY) = ys[it];
+      if (tid / CPRY + it * VPI_Y < MV && !AM_DBG(a, 8)) *(u32x4*)(ldsY + ydst0 + it * VPI_Y * RSY) = ys[it];
 #pragma unroll
     for (int it = 0; it < NITX; ++it)
-      if (tid / CPRX + it * VPI_X < nvox) *(u32x4*)(ldsX + xdst0 + it * VPI_X * RSX) = xs[it];
+      if (tid / CPRX + it * VPI_X < nvox && !AM_DBG(a, 8)) *(u32x4*)(ldsX + xdst0 + it * VPI_X * RSX) = xs[it];
     __syncthreads();
 
     // ---- contract over the brick's voxels ----
@@ -308,8 +314,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
+// Workgroups per launch: the kernel is persistent-style (each workgroup walks a contiguous run of bricks), so the grid must be a
+// whole number of "rounds" of the resident set -- (resident workgroups per CU) x 256 CUs.  One workgroup more than two rounds costs a
+// third round with the chip empty.
+constexpr int AM_WG_ROUNDS = 2;
+
 template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4>
-int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
+int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, hipStream_t st) {
   auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX>;
   constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
   constexpr int CT = 16 * MI, KT = 16 * NWX;
@@ -317,7 +328,35 @@ int launch(WgArgs& a, size_t maxvox, int split, hipStream_t st) {
   if (lds > 160 * 1024) return -3;
   if (maxvox * (KT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
   static std::once_flag lds_cap;                  // per instantiation, thread-safe
-  std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  static int regs_occ = 2;                        // resident workgroups per CU the register file allows (LDS is accounted per launch)
+  std::call_once(lds_cap, [&] {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, 0) == hipSuccess && nb > 0) regs_occ = nb;
+    (void)hipGetLastError();
+  });
+  int occ = (int)((size_t)160 * 1024 / lds);
+  if (occ > regs_occ) occ = regs_occ;
+  if (occ < 1) occ = 1;
+  // Workgroup ids go round-robin over the 8 XCDs and gridDim.x is a multiple of 8, so XCD x runs the slots with slot % 8 == x, times
+  // `tiles`: choose slots-per-XCD so that no XCD gets one workgroup more than R whole rounds of its resident set
+  const int cap = wg_slots(occ) / 8;                       // resident workgroups per XCD
+  int split8 = 0;
+  double best = 0.0;
+  int R0 = AM_WG_ROUNDS;
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_ROUNDS"); if (e_) R0 = atoi(e_); }
+#endif
+  for (int R = R0; R <= 2 * R0 || !split8; ++R) {
+    const int s8 = cap * R / tiles;
+    const double eff = (double)s8 * tiles / (cap * R);
+    if (s8 >= 1 && eff > best + 0.02) { best = eff; split8 = s8; }
+  }
+  int split = split8 * 8;
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_OLDSPLIT"); if (e_ && atoi(e_)) split = (1024 + tiles - 1) / tiles; }
+#endif
+  if (split > nbrick) split = nbrick;
   a.split = split;
   dim3 grid(((split + 7) / 8) * 8 * a.ngroup, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a);
@@ -411,21 +450,17 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     a.ngroup = 0;
     for (int gI = 0; gI < nunit; ++gI) if (ucount[gI] == ntap) a.zmap[a.ngroup++] = gI;
     if (!a.ngroup) continue;
-    // enough workgroups to fill 256 CUs x 2, few enough that the atomic flush stays small
     const int tiles = ((Cy + 16 * mi - 1) / (16 * mi)) * ((Cx + 16 * nwx - 1) / (16 * nwx)) * a.ngroup;
-    int split = (1024 + tiles - 1) / tiles;
-    if (split > nbrick) split = nbrick;
-    if (split < 1) split = 1;
     int rc = -2;
-#define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, split, st)
+#define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, tiles, nbrick, st)
     if (bf && bw == 16 && (mi == 2 || nwx == 2)) {
-      if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2>(a, maxvox, split, st);
-      else if (ntap == 9 && mi == 2) rc = launch<bf16_t, 2, 4, 16, 9, 7, 2, 4>(a, maxvox, split, st);
-      else if (ntap == 9) rc = launch<bf16_t, 2, 4, 16, 9, 4, 4, 2>(a, maxvox, split, st);
-      else if (ntap == 8) rc = launch<bf16_t, 2, 4, 16, 8, 4, 4, 2>(a, maxvox, split, st);
-      else if (ntap == 4) rc = launch<bf16_t, 2, 4, 16, 4, 4, 4, 2>(a, maxvox, split, st);
-      else if (ntap == 2) rc = launch<bf16_t, 2, 4, 16, 2, 4, 4, 2>(a, maxvox, split, st);
-      else rc = launch<bf16_t, 2, 4, 16, 1, 4, 4, 2>(a, maxvox, split, st);
+      if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2>(a, maxvox, tiles, nbrick, st);
+      else if (ntap == 9 && mi == 2) rc = launch<bf16_t, 2, 4, 16, 9, 7, 2, 4>(a, maxvox, tiles, nbrick, st);
+      else if (ntap == 9) rc = launch<bf16_t, 2, 4, 16, 9, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
+      else if (ntap == 8) rc = launch<bf16_t, 2, 4, 16, 8, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
+      else if (ntap == 4) rc = launch<bf16_t, 2, 4, 16, 4, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
+      else if (ntap == 2) rc = launch<bf16_t, 2, 4, 16, 2, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
+      else rc = launch<bf16_t, 2, 4, 16, 1, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
     } else if (bf && bw == 16) {
       if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
       else if (ntap == 2) WG_CASE(bf16_t, 4, 16, 2, 8); else WG_CASE(bf16_t, 4, 16, 1, 8);

@@ -3,6 +3,7 @@
 // backward passes, the Cin=1 stem convolutions, the 1x1 projection, weight (un)packing.
 // Every kernel walks channels-last rows with one 16-byte chunk per lane (coalesced: consecutive
 // lanes take consecutive chunks of consecutive voxels) and touches only voxels of active patches.
+#include <mutex>
 #include "common.h"
 #include "../../include/anatomask_hip.h"
 
@@ -1027,6 +1028,118 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __rest
   }
 }
 
+// ------------------------------------------------------------------ stem weight gradient on the matrix cores (bf16 storage mode)
+// dW[c][t] = sum_v dy[v][c] * xm[v + t - pad] is a [C x voxels] x [voxels x taps] product whose contraction index is the voxel:
+// M = channel, N = tap (27 taps + one column of ones that yields db, padded to 32; k1: centre tap + ones), K = 32 voxels (two
+// 16-voxel w-rows) per v_mfma_f32_16x16x32_bf16.  Persistent workgroups walk the active-patch list; per patch the haloed 18^3 input
+// patch sits in LDS as bf16 (the values the forward kernel multiplied), dy is staged one 16x16 d-plane at a time in padded rows and
+// fetched as A-fragments with the transposing LDS read (ds_read_b64_tr_b16, as conv_wgrad.hip), the B-fragments (x at the lane's
+// tap, 8 voxels) are 8 two-byte LDS reads.  Accumulators live in registers over the whole walk; one flush of C x 28 atomics per
+// workgroup.  The VALU form below re-stages x three times and runs at 5 TFLOP/s (1.2 ms per call at 128^3, B=8).
+__device__ __forceinline__ s16x4 tr_read16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <int NS, int K>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, int D, int H, int W,
+                                                              MaskView mask, const int* __restrict__ plist, int n_active,
+                                                              float* __restrict__ dw, float* __restrict__ db) {
+  constexpr int E = 18, C = 16 * NS, RS = 2 * C + 32;           // dy rows: C bf16 + 32 B pad (conflict-free transposing reads)
+  constexpr int NTT = K == 3 ? 2 : 1, NTAP = K * K * K;
+  constexpr int XB = (E * E * E + 8) * 2;                        // bytes of the x patch (multiple of 16)
+  constexpr int CPV = C / 8, NLD = CPV;                          // 16-byte chunks per voxel; loads per thread and d-plane (256 voxels)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  bf16_t* xl = (bf16_t*)lds;
+  unsigned char* yl = lds + XB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
+  const int q = (lane >> 2) & 3, p = lane & 3;
+  typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+  f32x4 acc[NS][NTT];
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int toff[NTT], kind[NTT];                                      // kind: 0 real tap, 1 ones column (db), 2 padding
+#pragma unroll
+  for (int n = 0; n < NTT; ++n) {
+    const int t = 16 * n + r16;
+    kind[n] = t < NTAP ? 0 : (t == NTAP ? 1 : 2);
+    toff[n] = t < NTAP ? (K == 3 ? ((t / 9) * E + (t / 3) % 3) * E + t % 3 : (E + 1) * E + 1) : 0;
+  }
+  for (int pi = blockIdx.x; pi < n_active; pi += gridDim.x) {
+    const int pk = plist[pi];
+    const int b = (pk >> 24) & 255, d0 = ((pk >> 16) & 255) * 16, h0 = ((pk >> 8) & 255) * 16, w0 = (pk & 255) * 16;
+    __syncthreads();                                             // the previous patch's reads of xl / yl are done
+    for (int e = tid; e < E * E * E; e += 256) {
+      const int ex = e % E, ey = (e / E) % E, ez = e / (E * E);
+      const int id = d0 + ez - 1, ih = h0 + ey - 1, iw = w0 + ex - 1;
+      float v = 0.f;
+      if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && mask.active(b, id, ih, iw))
+        v = x[((size_t)(b * D + id) * H + ih) * W + iw];
+      xl[e] = f2bf(v);
+    }
+    for (int dz = 0; dz < 16; ++dz) {
+      u32x4 ld[NLD];
+#pragma unroll
+      for (int it = 0; it < NLD; ++it) {
+        const int idx = tid + it * 256, vox = idx / CPV, ch = idx % CPV;
+        const size_t gv = ((size_t)(b * D + d0 + dz) * H + h0 + (vox >> 4)) * W + w0 + (vox & 15);
+        ld[it] = *(const u32x4*)(dy + gv * C + ch * 8);
+      }
+      __syncthreads();                                           // previous plane's fragment reads are done (first plane: xl is published below)
+#pragma unroll
+      for (int it = 0; it < NLD; ++it) {
+        const int idx = tid + it * 256, vox = idx / CPV, ch = idx % CPV;
+        *(u32x4*)(yl + vox * RS + ch * 16) = ld[it];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int s = wave + 4 * s2;                             // k-step: h-rows 2s, 2s+1 of this d-plane
+        const int v1 = s * 32 + g * 4 + q, v2 = v1 + 16;
+        bfx8 af[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const s16x4 lo = tr_read16(yl + v1 * RS + (16 * i + 4 * p) * 2), hi = tr_read16(yl + v2 * RS + (16 * i + 4 * p) * 2);
+          af[i] = __builtin_bit_cast(bfx8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+        }
+        const int xbase = (dz * E + 2 * s) * E + 4 * g;           // halo offset folded into the tap offsets
+#pragma unroll
+        for (int n = 0; n < NTT; ++n) {
+          s16x8 qv;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { qv[j] = (short)xl[xbase + toff[n] + j]; qv[4 + j] = (short)xl[xbase + toff[n] + E + j]; }
+          if (kind[n]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qv[j] = kind[n] == 1 ? (short)0x3F80 : (short)0;
+          }
+          const bfx8 bf = __builtin_bit_cast(bfx8, qv);
+#pragma unroll
+          for (int i = 0; i < NS; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- flush: D row 4g+r of tile i = channel 16i + 4g + r, column r16 of tile n = tap 16n + r16.  Fold the 4 waves in LDS first.
+  __syncthreads();
+  float* red = (float*)lds;                                      // [4 waves][C][16 * NTT]
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int n = 0; n < NTT; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * C + 16 * i + 4 * g + r) * (16 * NTT) + 16 * n + r16] = acc[i][n][r];
+  __syncthreads();
+  for (int i = tid; i < C * (NTAP + 1); i += 256) {
+    const int c = i / (NTAP + 1), t = i % (NTAP + 1);
+    float v = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) v += red[(wv * C + c) * (16 * NTT) + t];
+    if (t < NTAP) atomicAdd(&dw[c * NTAP + t], v);
+    else if (db) atomicAdd(&db[c], v);
+  }
+}
+
 // dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]     (same brick staging; 9 taps at a time in registers).
 // Persistent: a workgroup walks a strided set of bricks and keeps its [C][k^3+1] partial sums in LDS, so the global
 // atomics happen once per workgroup, not once per brick.
@@ -1669,13 +1782,31 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
 }
 
 int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
-                       const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum, void* stream) {
+                       const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum,
+                       const int32_t* active_list, int n_active, void* stream) {
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;
+  if (dtype == AM_DT_BF16 && active_list && n_active > 0 && (C == 32 || C == 64 || C == 96) && B <= 255 && fd <= 255 && fh <= 255 && fw <= 255) {
+    const MaskView mv{mask, fd, fh, fw, bshift};
+    const int nwg = n_active < 512 ? n_active : 512;            // persistent: two workgroups per CU, one atomic flush each
+    const size_t sm = (size_t)(18 * 18 * 18 + 8) * 2 + (size_t)256 * (2 * C + 32);
+#define AM_STEM_WG(NS_, K_)                                                                                                           \
+    {                                                                                                                                 \
+      auto kern = stem_wgrad_mfma_kernel<NS_, K_>;                                                                                    \
+      static std::once_flag cap;                                                                                                      \
+      std::call_once(cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); }); \
+      AM_LAUNCH(kern, dim3(nwg), dim3(256), sm, st, x, (const bf16_t*)dy, D, H, W, mv, active_list, n_active, dw_accum, db_accum);     \
+    }
+    if (ksize == 3) { if (C == 32) AM_STEM_WG(2, 3) else if (C == 64) AM_STEM_WG(4, 3) else AM_STEM_WG(6, 3) }
+    else { if (C == 32) AM_STEM_WG(2, 1) else if (C == 64) AM_STEM_WG(4, 1) else AM_STEM_WG(6, 1) }
+#undef AM_STEM_WG
+    AM_CHECK_LAUNCH();
+    return 0;
+  }
   int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
   if (nb > 1024) nb = 1024;                                   // persistent workgroups: one atomic flush each
   const int pad_ = ksize / 2;

@@ -248,7 +248,7 @@ def stem_conv_wgrad(x_b1: torch.Tensor, dy: torch.Tensor, ksize: int, mask: Opti
     B, D, H, W, Cc = dy.shape
     mp, fd, fh, fw = _mk(mask)
     hip.lib().stem_conv_wgrad(_dt(dy), x_b1.data_ptr(), dy.data_ptr(), B, D, H, W, Cc, ksize, mp, bshift, fd, fh, fw,
-                              dw_accum.data_ptr(), _p(db_accum), _stream())
+                              dw_accum.data_ptr(), _p(db_accum), *_al(mask), _stream())
 
 
 # ------------------------------------------------------------------ norms

@@ -95,7 +95,9 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
                      workgroup per active patch (K = 27 taps padded to one 16x16x32 MFMA); NULL / 0: the VALU kernel */,
                      int* partial_rows_written /* NULL or (host) the partials rows written (<= the bound above) */, void* stream);
 int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
-                       const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum, void* stream);
+                       const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum,
+                       const int32_t* active_list, int n_active /* am_mask_compact: bf16 stems then contract voxels on the matrix
+                       cores (persistent workgroups over the active patches); NULL / 0: the VALU kernel */, void* stream);
 
 /* Pooled sparse InstanceNorm (P/encoder3D.py:138-165: statistics over ALL active voxels of the local
  * batch) and BatchNorm3d (P/decoder3D.py:21-22) share these: stats -> finalize -> apply. */
