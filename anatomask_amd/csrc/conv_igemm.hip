@@ -38,7 +38,7 @@ using namespace amconv;
 namespace {
 
 template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
   constexpr int MV = BD * BH * BW;
