@@ -13,7 +13,8 @@
 // v_mfma_f32_16x16x4_f32.  The tap count is a template parameter: per k-step every fragment read of all
 // taps is issued before the first MFMA, so LDS latency is paid once per k-step, not once per tap.
 // Partial sums leave the workgroup as f32 atomics into the packed [tap][cy][cx] gradient
-// (64-byte runs per 16 lanes; order-dependent in the last bits, like any split-K atomic reduce).
+// (64-byte runs per 16 lanes; order-dependent in the last bits, like any split-K atomic reduce), or -- deterministic mode, a
+// caller-provided workspace -- as plain stores of one partial sum per brick-walk slot that a second kernel folds in slot order.
 #include <mutex>
 #include <stdlib.h>
 #include "common.h"
@@ -36,6 +37,8 @@ struct WgArgs {
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
   int split;                  // brick-walk slots per (tile, group)
+  float* det_ws;              // deterministic mode: [split][k^3][Cy][Cx] per-slot partial sums (plain stores), folded in slot order
+  long det_stride;            //   floats per slot
 #ifdef AM_ABLATE
   int dbg;                    // tools-only build (-DAM_ABLATE): AM_WG_DBG ablation bits, 1 no flush, 2 no contraction, 4 no global loads, 8 no LDS staging writes
 #endif
@@ -299,6 +302,47 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 
   // ---- flush: D row = cy 4g+r, col = cx r16 ----
   const int cx = cx0 + 16 * wx + r16;
+  if (a.det_ws) {
+    // deterministic mode: no atomics.  The KS waves that split the k-steps fold through LDS in a fixed order, then every
+    // (slot, tap, cy, cx) partial sum is stored exactly once; conv_wgrad_fold_kernel adds the slots in slot order.
+    if constexpr (KS > 1) {
+      float* red = (float*)lds;                              // [NWX][MI][4][64] per tap (<= 16 KB; the staging area is dead)
+      for (int k = KS - 1; k > 0; --k) {
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+          __syncthreads();
+          if (wk == k) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) red[((wx * MI + i) * 4 + r) * 64 + lane] = acc[t][i][r];
+          }
+          __syncthreads();
+          if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[t][i][r] += red[((wx * MI + i) * 4 + r) * 64 + lane];
+          }
+        }
+      }
+    }
+    if (wk == 0 && cx < a.Cx) {
+      float* ws = a.det_ws + (size_t)slot * a.det_stride;
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const int widx = a.taps[tb + t] >> 12;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cy = cy0 + 16 * i + 4 * g + r;
+            if (cy < a.Cy) ws[((size_t)widx * a.Cy + cy) * a.Cx + cx] = acc[t][i][r];
+          }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < NTAP; ++t) {
     if (cx < a.Cx && !AM_DBG(a, 1)) {
@@ -314,13 +358,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
+// deterministic mode: dw[tap][cy][cx] += sum over slots (in slot order) of the per-slot partial sums of this launch's taps
+__global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(WgArgs a, int ntap_launch) {
+  const long per_tap = (long)a.Cy * a.Cx;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= per_tap * ntap_launch) return;
+  int j = (int)(i / per_tap);                                 // j-th tap of this launch -> its widx
+  const long e = i % per_tap;
+  int widx = 0;
+  for (int gi = 0; gi < a.ngroup; ++gi) {
+    const int un = a.zmap[gi], n = a.tap_begin[un + 1] - a.tap_begin[un];
+    if (j < n) { widx = a.taps[a.tap_begin[un] + j] >> 12; break; }
+    j -= n;
+  }
+  const float* ws = a.det_ws + (size_t)widx * per_tap + e;
+  float s = 0.f;
+  for (int sl = 0; sl < a.split; ++sl) s += ws[(size_t)sl * a.det_stride];
+  a.dw[(size_t)widx * per_tap + e] += s;
+}
+
 // Workgroups per launch: the kernel is persistent-style (each workgroup walks a contiguous run of bricks), so the grid must be a
-// whole number of "rounds" of the resident set -- (resident workgroups per CU) x 256 CUs.  One workgroup more than two rounds costs a
-// third round with the chip empty.
+// whole number of "rounds" of the resident set -- (resident workgroups per CU) x CUs, counted per XCD.  One workgroup more than
+// two rounds costs a third round with the chip empty (measured: 1026 workgroups 2.24 ms, 1008 workgroups 1.77 ms).
 constexpr int AM_WG_ROUNDS = 2;
 
 template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4>
-int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, hipStream_t st) {
+int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipStream_t st) {
   auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX>;
   constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
   constexpr int CT = 16 * MI, KT = 16 * NWX;
@@ -357,10 +420,17 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, hipStream_t st) {
   { const char* e_ = getenv("AM_WG_OLDSPLIT"); if (e_ && atoi(e_)) split = (1024 + tiles - 1) / tiles; }
 #endif
   if (split > nbrick) split = nbrick;
+  if (a.det_ws && split > det_slots) split = det_slots;     // (the caller checked det_slots >= 1)
   a.split = split;
   dim3 grid(((split + 7) / 8) * 8 * a.ngroup, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a);
   AM_CHECK_LAUNCH();
+  if (a.det_ws) {
+    const int ntl = NTAP * a.ngroup;
+    const long n = (long)a.Cy * a.Cx * ntl;
+    AM_LAUNCH(conv_wgrad_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, ntl);
+    AM_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -369,11 +439,14 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, hipStream_t st) {
 extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, const void* dy, float* dw_packed,
                                int B, int Dx, int Hx, int Wx, int Cx, int Dy, int Hy, int Wy, int Cy,
                                const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift,
-                               int fd, int fh, int fw, void* stream) {
+                               int fd, int fh, int fw, float* det_workspace, long det_workspace_floats, void* stream) {
   if (Cx % 8 || Cy % 8) return -1;
   if ((size_t)8 * Hx * Wx * Cx * 4 >= 0x7fffff00ull || (size_t)8 * Hy * Wy * Cy * 4 >= 0x7fffff00ull) return -5;   // planes a brick spans
   WgArgs a;
   a.x = x; a.dy = dy; a.dw = dw_packed;
+  a.det_ws = det_workspace; a.det_stride = (long)ksize * ksize * ksize * Cy * Cx;
+  const int det_slots = det_workspace ? (int)(det_workspace_floats / a.det_stride < 4096 ? det_workspace_floats / a.det_stride : 4096) : 0;
+  if (det_workspace && det_slots < 1) return -6;               // workspace smaller than one [k^3][Cy][Cx] slot
   a.B = B; a.Dx = Dx; a.Hx = Hx; a.Wx = Wx; a.Cx = Cx; a.Dy = Dy; a.Hy = Hy; a.Wy = Wy; a.Cy = Cy;
   a.x_mask = MaskView{x_mask, fd, fh, fw, x_bshift};
   a.y_mask = MaskView{y_mask, fd, fh, fw, y_bshift};
@@ -452,15 +525,15 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     if (!a.ngroup) continue;
     const int tiles = ((Cy + 16 * mi - 1) / (16 * mi)) * ((Cx + 16 * nwx - 1) / (16 * nwx)) * a.ngroup;
     int rc = -2;
-#define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, tiles, nbrick, st)
+#define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, tiles, nbrick, det_slots, st)
     if (bf && bw == 16 && (mi == 2 || nwx == 2)) {
-      if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2>(a, maxvox, tiles, nbrick, st);
-      else if (ntap == 9 && mi == 2) rc = launch<bf16_t, 2, 4, 16, 9, 7, 2, 4>(a, maxvox, tiles, nbrick, st);
-      else if (ntap == 9) rc = launch<bf16_t, 2, 4, 16, 9, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
-      else if (ntap == 8) rc = launch<bf16_t, 2, 4, 16, 8, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
-      else if (ntap == 4) rc = launch<bf16_t, 2, 4, 16, 4, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
-      else if (ntap == 2) rc = launch<bf16_t, 2, 4, 16, 2, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
-      else rc = launch<bf16_t, 2, 4, 16, 1, 4, 4, 2>(a, maxvox, tiles, nbrick, st);
+      if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 9 && mi == 2) rc = launch<bf16_t, 2, 4, 16, 9, 7, 2, 4>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 9) rc = launch<bf16_t, 2, 4, 16, 9, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 8) rc = launch<bf16_t, 2, 4, 16, 8, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 4) rc = launch<bf16_t, 2, 4, 16, 4, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 2) rc = launch<bf16_t, 2, 4, 16, 2, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+      else rc = launch<bf16_t, 2, 4, 16, 1, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
     } else if (bf && bw == 16) {
       if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
       else if (ntap == 2) WG_CASE(bf16_t, 4, 16, 2, 8); else WG_CASE(bf16_t, 4, 16, 1, 8);

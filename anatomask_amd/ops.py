@@ -208,6 +208,22 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     return (out, part) if want_partials else out
 
 
+# Deterministic weight gradients (am_conv3d_wgrad's det_workspace): per-slot partial sums + an ordered fold instead of fp32 atomics.
+DETERMINISTIC_WGRAD = False
+_DET_WS: dict = {}
+
+
+def _det_workspace(device, floats_per_slot: int):
+    """one cached workspace per device and stream (the side stream's weight gradients run concurrently with the main stream's):
+    256 MB, or 8 slots of the largest gradient if that is more."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    need = max(64 << 20, 8 * floats_per_slot)
+    t = _DET_WS.get(key)
+    if t is None or t.numel() < need:
+        t = _DET_WS[key] = torch.empty(need, device=device, dtype=torch.float32)
+    return t
+
+
 def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int,
                  x_mask: Optional[MaskInfo] = None, x_bshift: int = 0, y_mask: Optional[MaskInfo] = None,
                  y_bshift: int = 0) -> torch.Tensor:
@@ -217,10 +233,12 @@ def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, strid
     dw = torch.zeros(taps, Cy, Cx, device=x.device, dtype=torch.float32)
     mk = x_mask or y_mask
     mp, fd, fh, fw = _mk(mk)
+    ws = _det_workspace(x.device, taps * Cy * Cx) if DETERMINISTIC_WGRAD else None
     hip.lib().conv3d_wgrad(mode, _dt(x), ksize, stride, x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
                            B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy,
                            x_mask.t.data_ptr() if x_mask else None, x_bshift,
-                           y_mask.t.data_ptr() if y_mask else None, y_bshift, fd, fh, fw, _stream())
+                           y_mask.t.data_ptr() if y_mask else None, y_bshift, fd, fh, fw,
+                           ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream())
     return dw
 
 

@@ -67,11 +67,16 @@ int am_partials_reduce(const float* partials, int rows, int C, double* sums, flo
 
 /* Weight gradient (autograd of the above).  mode = AM_CONV_FWD or AM_CONVT_FWD.  x = forward input
  * [B][Dx][Hx][Wx][Cx], dy = gradient of the forward output [B][Dy][Hy][Wy][Cy];
- * dw_packed fp32 [tap][Cy][Cx] is ACCUMULATED into (zero it first). */
+ * dw_packed fp32 [tap][Cy][Cx] is ACCUMULATED into (zero it first).
+ * The partial sums of the workgroups are reduced with fp32 atomics (bits depend on the arrival order, as torch's own
+ * non-deterministic cuDNN/MIOpen weight gradients); with det_workspace != NULL every workgroup slot stores its partial sum to
+ * det_workspace[slot][tap][Cy][Cx] instead and a second kernel adds the slots in slot order: bit-identical from run to run
+ * (the counterpart of torch.use_deterministic_algorithms for this path).  det_workspace_floats >= k^3*Cy*Cx, more slots =
+ * more parallelism (the launch uses min(its own slot count, what fits)). */
 int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, const void* dy, float* dw_packed,
                     int B, int Dx, int Hx, int Wx, int Cx, int Dy, int Hy, int Wy, int Cy,
                     const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift, int fd, int fh, int fw,
-                    void* stream);
+                    float* det_workspace, long det_workspace_floats, void* stream);
 
 /* dst[t][r][k] = src[r*stride_r + k*stride_k + t] (zero in the padding): torch-layout fp32 master -> packed [taps][Rp][Kp]. */
 int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, int Rp, int Kp,

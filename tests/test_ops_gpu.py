@@ -119,6 +119,45 @@ def test_conv_wgrad_narrow_channels_wide_grid(ops, case, sparse):
     close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (narrow channels)")
 
 
+@pytest.mark.parametrize("case", [(64, 64, 3, 1, False), (32, 32, 3, 1, True), (32, 64, 3, 2, True), (16, 24, 1, 2, False), (64, 64, 4, 2, False)])
+def test_conv_wgrad_deterministic_mode(ops, case):
+    """det_workspace: per-slot partial sums folded in slot order instead of fp32 atomics -> bit-identical from run to run (the
+    atomics path differs in the last bits between runs on large grids), and equal to the atomics result up to fp32 summation order.
+    Covers the k-split waves (32-channel tiles), strided units (several launches per call) and the transposed convolution."""
+    cin, cout, k, s, sparse = case
+    dtype = torch.bfloat16
+    B, f, bs_out = 2, (2, 2, 4), 2
+    convt = k == 4
+    so = tuple(v << bs_out for v in f)                       # conv output / convT input grid (8, 8, 16)
+    si = tuple(v * s for v in so)
+    mask = mk_mask(B, f, 13) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    if convt:                                                # x = convT input (coarse), dy = gradient of its output (fine)
+        x = to_cl(q(rnd(B, cin, *so, seed=11), dtype), dtype)
+        dy = to_cl(q(rnd(B, cout, *si, seed=12), dtype), dtype)
+        run = lambda: ops.conv3d_wgrad(ops.CONVT_FWD, x, dy, 4, 2)
+    else:
+        xs = q(rnd(B, cin, *si, seed=11), dtype)
+        dys = q(rnd(B, cout, *so, seed=12), dtype)
+        if sparse:
+            xs = xs * O.upsample_mask(mask, si).float()
+            dys = dys * O.upsample_mask(mask, so).float()
+        x, dy = to_cl(xs, dtype), to_cl(dys, dtype)
+        bs_in = bs_out + (1 if s == 2 else 0)
+        run = lambda: ops.conv3d_wgrad(ops.CONV_FWD, x, dy, k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out)
+    ref = run()                                              # atomics
+    ops.DETERMINISTIC_WGRAD = True
+    try:
+        a, b = run(), run()
+        ops._DET_WS.clear()                                  # a workspace with stale contents must not matter either
+        torch.empty(80 << 20, device=DEV).fill_(float("nan"))
+        c = run()
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
+    assert torch.equal(a, b) and torch.equal(a, c)
+    close(a.cpu(), ref.cpu(), 1e-5, "deterministic vs atomic wgrad")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", CONV_CASES)
 @pytest.mark.parametrize("sparse", [False, True])
