@@ -19,8 +19,14 @@ from .modules import ModelEma, SparK, ema_decay_for_epoch
 class AnatoMaskTrainer:
     def __init__(self, model: SparK, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  clip: float = 12.0, ema_decay: float = 0.999, total_epochs: int = 1000, guide: bool = True, seed: int = 4321,
-                 process_group=None, distributed: Optional[bool] = None, self_distill: bool = True):
+                 process_group=None, distributed: Optional[bool] = None, self_distill: bool = True, deterministic_wgrad: bool = False):
         self.model = model
+        if deterministic_wgrad:
+            # convolution weight gradients as per-slot partial sums folded in a fixed order instead of fp32 atomics (am_conv3d_wgrad's
+            # det_workspace; +3 % step time).  Process-wide, like torch.use_deterministic_algorithms.  The per-channel norm statistics
+            # keep their fp64 atomics (order-dependent at the 1e-16 level).
+            from . import ops
+            ops.DETERMINISTIC_WGRAD = True
         self.self_distill = self_distill      # False: plain SparK step (P/spark3D.py:98-146, P/pretrain.py): random mask, no teacher
         model._ensure_flat()
         model.train()
