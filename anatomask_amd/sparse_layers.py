@@ -1,0 +1,537 @@
+"""Sparse layer zoo of the SparK encoder for backbones other than STUNet, on the HIP kernels of csrc/layer_ops.hip.
+
+Mirror of P/encoder3D.py (= nnunetv2/training/nnUNetTrainer/variants/pretrain/encoder3D.py): same class names, constructor
+arguments, parameter names / shapes (so `state_dict`s interchange) and forward semantics, including the side channel: the modules
+read the current patch mask from `anatomask_amd.modules._cur_active` (bool (B,1,f,f,f); the reference: encoder3D._cur_active :5), and
+`dense_model_to_sparse` (:300-364) swaps the layers of a dense torch model for these.
+
+    SparseConv3d (:27-28)                      channel-mixing conv -> am_conv3d (matrix cores); depthwise (groups == C) -> am_dwconv3d
+    SparseMaxPooling / SparseAvgPooling (:31-36)            am_pool3d_fwd / bwd
+    SparseBatchNorm3d / SparseSyncBatchNorm3d (:39-44)      BatchNorm over the active voxels: am_chan_stats / am_norm_* (the STUNet path's)
+    SparseGroupNorm (:47-78), SparseConvNeXtLayerNorm (:181-232), SparseGRN (:100-135)   am_voxel_norm_fwd / bwd
+    SparseAdaptiveAvgPooling (:171-179)                     am_masked_mean_fwd / bwd
+    SparseConvNeXtBlock (:235-276)                          dwconv -> LayerNorm -> 1x1 -> GELU -> 1x1 -> layer scale -> mask -> residual
+
+Tensors cross the module boundary as torch NCDHW tensors like the reference's; inside they are channels-last ([B,D,H,W,C], the
+kernels' layout) -- a module returns an NCDHW *view* of its channels-last result (torch.channels_last_3d strides), so chains of these
+modules convert nothing.  Outputs carry exact zeros at inactive voxels, as the reference's.  Compute dtype = the input's (fp32 or
+bf16).  No CPU / torch fallback: without the HIP library the import of `ops` fails.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import modules as _M
+from . import ops
+from .hip import lib as _lib
+
+
+# ------------------------------------------------------------------ plumbing
+_MASK_CACHE = {"key": None, "mi": None}
+
+
+def current_mask(device) -> Optional[ops.MaskInfo]:
+    """MaskInfo of `modules._cur_active` (built once per mask tensor), or None (dense)."""
+    act = _M._cur_active
+    if act is None:
+        return None
+    key = (id(act), act._version, str(device))
+    if _MASK_CACHE["key"] != key:
+        _MASK_CACHE["key"], _MASK_CACHE["mi"] = key, ops.MaskInfo.from_bool(act, device)
+    return _MASK_CACHE["mi"]
+
+
+def _bshift(mi: Optional[ops.MaskInfo], D: int) -> int:
+    if mi is None:
+        return 0
+    r = D // mi.fd
+    assert r >= 1 and r * mi.fd == D and (r & (r - 1)) == 0, f"resolution {D} is not a power-of-two multiple of the mask grid {mi.fd}"
+    return r.bit_length() - 1
+
+
+def _cl(x: torch.Tensor) -> torch.Tensor:
+    """NCDHW (any strides) -> contiguous [B,D,H,W,C] (a view when x is channels_last_3d)."""
+    assert x.dim() == 5 and x.dtype in (torch.float32, torch.bfloat16), (x.shape, x.dtype)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _nc(y_cl: torch.Tensor) -> torch.Tensor:
+    return y_cl.permute(0, 4, 1, 2, 3)
+
+
+def _geo(mi, bs):
+    mp, fd, fh, fw = ops._mk(mi)
+    return mp, bs, fd, fh, fw
+
+
+def _al(mi):
+    return ops._al(mi)
+
+
+def _s():
+    return ops._stream()
+
+
+def _check_list(mi):
+    if mi is not None and ops._al(mi)[0] is None:
+        raise RuntimeError("the sparse layer kernels walk the active-patch list: mask grids above 255 per dim / empty masks are not supported")
+
+
+# ------------------------------------------------------------------ per-voxel norms (LayerNorm / GroupNorm / GRN)
+class _VoxelNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl, gamma, beta, kind, groups, eps):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        _check_list(mi)
+        y = torch.zeros_like(x_cl)
+        g32, b32 = gamma.float().contiguous().view(-1), (beta.float().contiguous().view(-1) if beta is not None else None)
+        _lib().voxel_norm_fwd(ops._dt(x_cl), kind, x_cl.data_ptr(), y.data_ptr(), B, D, H, W, C, groups, g32.data_ptr(), ops._p(b32), float(eps),
+                              ops._mk(mi)[0], bs, *_al(mi), _s())
+        ctx.save_for_backward(x_cl, g32)
+        ctx.cfg = (mi, bs, kind, groups, eps, gamma.shape, None if beta is None else beta.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, g32 = ctx.saved_tensors
+        mi, bs, kind, groups, eps, gshape, bshape = ctx.cfg
+        B, D, H, W, C = x_cl.shape
+        dy = dy.contiguous()
+        dx = torch.zeros_like(x_cl)
+        dg = torch.zeros(C, device=x_cl.device, dtype=torch.float32)
+        db = torch.zeros(C, device=x_cl.device, dtype=torch.float32)
+        _lib().voxel_norm_bwd(ops._dt(x_cl), kind, x_cl.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, D, H, W, C, groups, g32.data_ptr(), float(eps),
+                              dg.data_ptr(), db.data_ptr(), ops._mk(mi)[0], bs, *_al(mi), _s())
+        return dx, dg.view(gshape), (db.view(bshape) if bshape is not None else None), None, None, None
+
+
+class SparseGroupNorm(nn.GroupNorm):
+    """encoder3D.py:47-78: GroupNorm of the (N_active, C) matrix, i.e. per voxel over each channel group."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-6, sparse=True):
+        super().__init__(num_groups, num_channels, eps)
+        self.sparse = sparse
+
+    def forward(self, x):
+        if x.ndim != 5 or not self.sparse:
+            raise NotImplementedError("SparseGroupNorm: 5-D sparse input only")
+        return _nc(_VoxelNormFn.apply(_cl(x), self.weight, self.bias, 0, self.num_groups, self.eps))
+
+
+class SparseConvNeXtLayerNorm(nn.LayerNorm):
+    """encoder3D.py:181-232: LayerNorm over C at every active voxel; channels_last input (B,H,W,D,C) or channels_first (B,C,H,W,D)."""
+
+    def __init__(self, normalized_shape, eps=1e-6, data_format="channels_last", sparse=True):
+        if data_format not in ["channels_last", "channels_first"]:
+            raise NotImplementedError
+        super().__init__(normalized_shape, eps, elementwise_affine=True)
+        self.data_format, self.sparse = data_format, sparse
+
+    def forward(self, x):
+        if x.ndim != 5 or not self.sparse:
+            raise NotImplementedError("SparseConvNeXtLayerNorm: 5-D sparse input only")
+        if self.data_format == "channels_last":
+            return _VoxelNormFn.apply(x.contiguous(), self.weight, self.bias, 0, 1, self.eps)
+        return _nc(_VoxelNormFn.apply(_cl(x), self.weight, self.bias, 0, 1, self.eps))
+
+
+class SparseGRN(nn.Module):
+    """encoder3D.py:100-135, sparse branch (:116-127): on the (N_active, C) matrix Gx = ||row||_2, Nx = Gx / (Gx.mean(-1) + 1e-6)
+    with the mean over a size-1 axis, so Nx = Gx / (Gx + 1e-6); y = gamma * (x * Nx) + beta.  Input channels-last (B,H,W,D,C).
+    (The reference derives the mask resolution from x.shape[2:5] of that channels-last tensor, :118, which is only right when C equals
+    the spatial size; here the mask is taken at the tensor's true resolution.)"""
+
+    def __init__(self, dim, use_bias=True, sparse=True):
+        super().__init__()
+        self.use_bias, self.sparse = use_bias, sparse
+        self.gamma = nn.Parameter(torch.zeros(1, dim))
+        if self.use_bias:
+            self.beta = nn.Parameter(torch.zeros(1, dim))
+
+    def forward(self, x):
+        if x.ndim != 5:
+            raise NotImplementedError("SparseGRN supports only 5D tensors")
+        if not self.sparse:
+            raise NotImplementedError("SparseGRN: sparse branch only")
+        return _VoxelNormFn.apply(x.contiguous(), self.gamma, self.beta if self.use_bias else None, 1, 1, 0.0)
+
+
+# ------------------------------------------------------------------ pooling
+class _PoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl, op, k, s, p, cip):
+        mi = current_mask(x_cl.device)
+        B, Di, Hi, Wi, C = x_cl.shape
+        Do, Ho, Wo = ((Di + 2 * p - k) // s + 1, (Hi + 2 * p - k) // s + 1, (Wi + 2 * p - k) // s + 1)
+        bi, bo = _bshift(mi, Di), _bshift(mi, Do)
+        _check_list(mi)
+        y = torch.zeros(B, Do, Ho, Wo, C, device=x_cl.device, dtype=x_cl.dtype)
+        idx = torch.empty(B, Do, Ho, Wo, C, device=x_cl.device, dtype=torch.int32) if op == 0 else None
+        mp, fd, fh, fw = ops._mk(mi)
+        _lib().pool3d_fwd(ops._dt(x_cl), op, x_cl.data_ptr(), y.data_ptr(), ops._p(idx), B, Di, Hi, Wi, C, k, s, p, int(cip), Do, Ho, Wo,
+                          mp, bi, bo, fd, fh, fw, *_al(mi), _s())
+        ctx.save_for_backward(idx if idx is not None else torch.empty(0))
+        ctx.cfg = (mi, op, k, s, p, cip, (B, Di, Hi, Wi, C), (Do, Ho, Wo), bi, bo, x_cl.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        mi, op, k, s, p, cip, (B, Di, Hi, Wi, C), (Do, Ho, Wo), bi, bo, dt = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.zeros(B, Di, Hi, Wi, C, device=dy.device, dtype=dt)
+        mp, fd, fh, fw = ops._mk(mi)
+        _lib().pool3d_bwd(ops._dt(dx), op, dy.data_ptr(), idx.data_ptr() if op == 0 else None, dx.data_ptr(), B, Di, Hi, Wi, C, k, s, p, int(cip),
+                          Do, Ho, Wo, mp, bi, bo, fd, fh, fw, *_al(mi), _s())
+        return dx, None, None, None, None, None
+
+
+def _one(v):
+    if isinstance(v, (tuple, list)):
+        assert all(a == v[0] for a in v), f"cubic pooling windows only, got {v}"
+        return int(v[0])
+    return int(v)
+
+
+class SparseMaxPooling(nn.MaxPool3d):
+    """encoder3D.py:31-32 (sp_conv_forward :12-15): MaxPool3d, then the output is masked."""
+
+    def forward(self, x):
+        if self.ceil_mode or _one(self.dilation) != 1 or self.return_indices:
+            raise NotImplementedError("SparseMaxPooling: ceil_mode / dilation / return_indices are not supported")
+        k = _one(self.kernel_size)
+        return _nc(_PoolFn.apply(_cl(x), 0, k, _one(self.stride if self.stride is not None else k), _one(self.padding), True))
+
+
+class SparseAvgPooling(nn.AvgPool3d):
+    """encoder3D.py:35-36."""
+
+    def forward(self, x):
+        if self.ceil_mode or self.divisor_override is not None:
+            raise NotImplementedError("SparseAvgPooling: ceil_mode / divisor_override are not supported")
+        k = _one(self.kernel_size)
+        return _nc(_PoolFn.apply(_cl(x), 1, k, _one(self.stride if self.stride is not None else k), _one(self.padding), self.count_include_pad))
+
+
+class _AdaptiveAvgFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        mean = torch.empty(B, C, device=x_cl.device, dtype=torch.float32)
+        mp, fd, fh, fw = ops._mk(mi)
+        _lib().masked_mean_fwd(ops._dt(x_cl), x_cl.data_ptr(), mean.data_ptr(), B, D, H, W, C, mp, bs, fd, fh, fw, _s())
+        ctx.cfg = (mi, bs, x_cl.shape, x_cl.dtype)
+        return mean.to(x_cl.dtype)
+
+    @staticmethod
+    def backward(ctx, dmean):
+        mi, bs, (B, D, H, W, C), dt = ctx.cfg
+        _check_list(mi)
+        if mi is None:
+            cnt = torch.full((B,), float(D * H * W), device=dmean.device)
+        else:
+            cnt = mi.t.reshape(B, -1).sum(1).float() * float(1 << (3 * bs))
+        dx = torch.zeros(B, D, H, W, C, device=dmean.device, dtype=dt)
+        _lib().masked_mean_bwd(ops._dt(dx), dmean.float().contiguous().data_ptr(), cnt.data_ptr(), dx.data_ptr(), B, D, H, W, C, ops._mk(mi)[0], bs,
+                               *_al(mi), _s())
+        return dx
+
+
+class SparseAdaptiveAvgPooling(nn.AdaptiveAvgPool3d):
+    """encoder3D.py:171-179: masked mean over the active voxels of each sample -> (B,C,1,1,1)."""
+
+    def __init__(self, output_size, sparse=True):
+        super().__init__(output_size)
+        self.sparse = sparse
+
+    def forward(self, x):
+        return _AdaptiveAvgFn.apply(_cl(x))[:, :, None, None, None]
+
+
+# ------------------------------------------------------------------ BatchNorm over the active voxels
+class _SparseBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, run_mean, run_var, nbt, training, momentum, eps, sync):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        st = ops.NormStats(C, x_cl.device)
+        g32, b32 = weight.float().contiguous(), bias.float().contiguous()
+        use_batch = training or run_mean is None
+        if use_batch:
+            ops.chan_stats(x_cl, mi, bs, st)
+            if mi is None:
+                n = float(B * D * H * W)
+            else:
+                n = float(int(mi.t.count_nonzero().item()) if mi.n_active is None else mi.n_active) * float(1 << (3 * bs))
+            if sync:
+                import torch.distributed as dist
+                cnt = torch.tensor([n], device=x_cl.device, dtype=torch.float64)
+                dist.all_reduce(st.sums[:ops.NREP]); dist.all_reduce(cnt)
+                n = float(cnt.item()); st.sync_world = dist.get_world_size()
+            st.count_host, st.count_ptr = n, None
+            mom = momentum
+            if training and run_mean is not None:
+                nbt += 1
+                if momentum is None:
+                    mom = 1.0 / float(nbt.item())
+            ops.norm_finalize(st, g32, b32, eps, run_mean if training else None, run_var if training else None, 0.0 if mom is None else mom)
+        else:
+            ops.norm_fold_running(st, g32, b32, run_mean, run_var, eps)
+        y = ops.norm_apply(x_cl, st, ops.ACT_NONE, mi, bs, out=torch.zeros_like(x_cl))
+        ctx.save_for_backward(x_cl, g32)
+        ctx.cfg = (mi, bs, st, use_batch)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, g32 = ctx.saved_tensors
+        mi, bs, st, use_batch = ctx.cfg
+        C = x_cl.shape[-1]
+        dg = torch.zeros(C, device=x_cl.device, dtype=torch.float32)
+        db = torch.zeros(C, device=x_cl.device, dtype=torch.float32)
+        if not use_batch:
+            raise NotImplementedError("SparseBatchNorm3d backward in eval mode")
+        dx = ops.norm_backward(dy.contiguous(), None, x_cl, st, g32, ops.ACT_NONE, mi, bs, dg, db, dx=torch.zeros_like(x_cl))
+        return dx, dg, db, None, None, None, None, None, None, None
+
+
+class SparseBatchNorm3d(nn.BatchNorm1d):
+    """encoder3D.py:39-40 (sp_bn_forward :17-25): BatchNorm1d over the (N_active, C) matrix -- batch statistics over all active voxels
+    of the (local) batch, running statistics with the unbiased variance, eval mode on the running statistics."""
+    _sync = False
+
+    def forward(self, x):
+        if not self.affine:
+            raise NotImplementedError("SparseBatchNorm3d: affine=True only")
+        track = self.track_running_stats and self.running_mean is not None
+        y = _SparseBNFn.apply(_cl(x), self.weight, self.bias, self.running_mean if track else None, self.running_var if track else None,
+                              self.num_batches_tracked if track else None, self.training, self.momentum, self.eps,
+                              self._sync and self.training and torch.distributed.is_available() and torch.distributed.is_initialized()
+                              and torch.distributed.get_world_size() > 1)
+        return _nc(y)
+
+
+class SparseSyncBatchNorm3d(SparseBatchNorm3d):
+    """encoder3D.py:43-44: the statistics are all-reduced over the process group (RCCL)."""
+    _sync = True
+
+
+# ------------------------------------------------------------------ convolutions
+class _DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, k):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        w32 = weight.float().contiguous().view(C, -1)
+        y = torch.zeros_like(x_cl)
+        mp, fd, fh, fw = ops._mk(mi)
+        _lib().dwconv3d(ops._dt(x_cl), 0, x_cl.data_ptr(), w32.data_ptr(), ops._p(bias.float().contiguous() if bias is not None else None),
+                        y.data_ptr(), B, D, H, W, C, k, mp, bs, fd, fh, fw, _s())
+        ctx.save_for_backward(x_cl, w32)
+        ctx.cfg = (mi, bs, k, weight.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, w32 = ctx.saved_tensors
+        mi, bs, k, wshape, has_bias = ctx.cfg
+        B, D, H, W, C = x_cl.shape
+        dy = dy.contiguous()
+        mp, fd, fh, fw = ops._mk(mi)
+        dx = torch.zeros_like(x_cl)
+        _lib().dwconv3d(ops._dt(x_cl), 1, dy.data_ptr(), w32.data_ptr(), None, dx.data_ptr(), B, D, H, W, C, k, mp, bs, fd, fh, fw, _s())
+        dw = torch.zeros(C, k ** 3, device=x_cl.device, dtype=torch.float32)
+        db = torch.zeros(C, device=x_cl.device, dtype=torch.float32) if has_bias else None
+        _lib().dwconv3d_wgrad(ops._dt(x_cl), x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), ops._p(db), B, D, H, W, C, k, mp, bs, fd, fh, fw, _s())
+        return dx, dw.view(wshape), db, None
+
+
+class _ConvFn(torch.autograd.Function):
+    """channel-mixing convolution k in {1, 3}, stride in {1, 2} on the matrix cores (am_conv3d / am_conv3d_wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, k, stride):
+        mi = current_mask(x_cl.device)
+        B, Di, Hi, Wi, Cin = x_cl.shape
+        so = tuple((v + 2 * (k // 2) - k) // stride + 1 for v in (Di, Hi, Wi))
+        bi, bo = _bshift(mi, Di), _bshift(mi, so[0])
+        wp = ops.pack_weight(weight.detach().float(), x_cl.dtype, False, False)
+        y = torch.zeros(B, *so, weight.shape[0], device=x_cl.device, dtype=x_cl.dtype)
+        ops.conv3d(ops.CONV_FWD, x_cl, wp, bias.float().contiguous() if bias is not None else None, so, k, stride, in_mask=mi, in_bshift=bi,
+                   out_mask=mi, out_bshift=bo, out=y)
+        ctx.save_for_backward(x_cl, weight)
+        ctx.cfg = (mi, bi, bo, k, stride, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, weight = ctx.saved_tensors
+        mi, bi, bo, k, stride, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        B, Di, Hi, Wi, Cin = x_cl.shape
+        wpd = ops.pack_weight(weight.detach().float(), x_cl.dtype, False, True)
+        dx = torch.zeros_like(x_cl)
+        ops.conv3d(ops.CONV_DGRAD, dy, wpd, None, (Di, Hi, Wi), k, stride, in_mask=mi, in_bshift=bo, out_mask=mi, out_bshift=bi, out=dx)
+        dwp = ops.conv3d_wgrad(ops.CONV_FWD, x_cl, dy, k, stride, x_mask=mi, x_bshift=bi, y_mask=mi, y_bshift=bo)
+        dw = torch.zeros(weight.shape, device=x_cl.device, dtype=torch.float32)
+        ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+        db = None
+        if has_bias:
+            db = torch.zeros(weight.shape[0], device=x_cl.device, dtype=torch.float32)
+            ops.chan_sum(dy, mi, bo, db)
+        return dx, dw, db, None, None
+
+
+class SparseConv3d(nn.Conv3d):
+    """encoder3D.py:27-28 (sp_conv_forward :12-15): Conv3d, output masked.  Supported: 'same' padding k//2, dilation 1, zero padding;
+    groups == 1 with k in {1, 3}, stride in {1, 2} (matrix cores) or depthwise (groups == in == out) with k in {3, 5, 7}, stride 1."""
+
+    def forward(self, x):
+        k, s, p = _one(self.kernel_size), _one(self.stride), _one(self.padding)
+        if _one(self.dilation) != 1 or self.padding_mode != "zeros" or p != k // 2:
+            raise NotImplementedError("SparseConv3d: dilation 1, zero 'same' padding only")
+        if self.groups == 1 and k in (1, 3) and s in (1, 2) and self.in_channels % 8 == 0 and self.out_channels % 8 == 0:
+            return _nc(_ConvFn.apply(_cl(x), self.weight, self.bias, k, s))
+        if self.groups == self.in_channels == self.out_channels and k in (3, 5, 7) and s == 1:
+            return _nc(_DwConvFn.apply(_cl(x), self.weight, self.bias, k))
+        raise NotImplementedError(f"SparseConv3d: groups={self.groups} k={k} stride={s} C={self.in_channels}->{self.out_channels} has no kernel")
+
+
+# ------------------------------------------------------------------ ConvNeXt block
+class _GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_cl):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        _check_list(mi)
+        y = torch.zeros_like(x_cl)
+        _lib().gelu(ops._dt(x_cl), x_cl.data_ptr(), None, y.data_ptr(), B, D, H, W, C, ops._mk(mi)[0], bs, *_al(mi), _s())
+        ctx.save_for_backward(x_cl)
+        ctx.cfg = (mi, bs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x_cl,) = ctx.saved_tensors
+        mi, bs = ctx.cfg
+        B, D, H, W, C = x_cl.shape
+        dx = torch.zeros_like(x_cl)
+        _lib().gelu(ops._dt(x_cl), x_cl.data_ptr(), dy.contiguous().data_ptr(), dx.data_ptr(), B, D, H, W, C, ops._mk(mi)[0], bs, *_al(mi), _s())
+        return dx
+
+
+class _ScaleResidualFn(torch.autograd.Function):
+    """y = res + gamma * x on active voxels, res elsewhere (encoder3D.py:266-275: gamma * x, masked, input + drop_path(x))."""
+
+    @staticmethod
+    def forward(ctx, x_cl, res_cl, gamma):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        _check_list(mi)
+        y = res_cl.clone()
+        g32 = gamma.float().contiguous() if gamma is not None else None
+        _lib().scale_residual(ops._dt(x_cl), 0, x_cl.data_ptr(), res_cl.data_ptr(), ops._p(g32), y.data_ptr(), None, B, D, H, W, C, ops._mk(mi)[0], bs,
+                              *_al(mi), _s())
+        ctx.save_for_backward(x_cl, g32 if g32 is not None else torch.empty(0))
+        ctx.cfg = (mi, bs, gamma is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, g32 = ctx.saved_tensors
+        mi, bs, has_g = ctx.cfg
+        B, D, H, W, C = x_cl.shape
+        dy = dy.contiguous()
+        dx = torch.zeros_like(x_cl)
+        dg = torch.zeros(C, device=x_cl.device, dtype=torch.float32) if has_g else None
+        _lib().scale_residual(ops._dt(x_cl), 1, x_cl.data_ptr(), dy.data_ptr(), g32.data_ptr() if has_g else None, dx.data_ptr(), ops._p(dg), B, D, H, W,
+                              C, ops._mk(mi)[0], bs, *_al(mi), _s())
+        return dx, dy, dg
+
+
+class _PointwiseLinear(nn.Linear):
+    """nn.Linear applied over the channel axis of a channels-last volume == a 1x1x1 convolution on the matrix cores."""
+
+    def forward(self, x_cl):
+        return _ConvFn.apply(x_cl, self.weight[:, :, None, None, None], self.bias, 1, 1)
+
+
+class SparseConvNeXtBlock(nn.Module):
+    """encoder3D.py:235-276.  drop_path > 0 is not supported (the reference's pretraining scripts build their backbones with 0)."""
+
+    def __init__(self, dim, drop_path=0., layer_scale_init_value=1e-6, sparse=True, ks=7):
+        super().__init__()
+        if drop_path > 0.:
+            raise NotImplementedError("SparseConvNeXtBlock: drop_path > 0")
+        self.dwconv = SparseConv3d(dim, dim, kernel_size=ks, padding=ks // 2, groups=dim)
+        self.norm = SparseConvNeXtLayerNorm(dim, eps=1e-6, sparse=sparse)
+        self.pwconv1 = _PointwiseLinear(dim, 4 * dim)
+        self.act = nn.GELU()
+        self.pwconv2 = _PointwiseLinear(4 * dim, dim)
+        self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((dim)), requires_grad=True) if layer_scale_init_value > 0 else None
+        self.drop_path = nn.Identity()
+        self.sparse = sparse
+
+    def forward(self, x):
+        if not self.sparse:
+            raise NotImplementedError("SparseConvNeXtBlock: sparse=True only")
+        inp = _cl(x)
+        k = _one(self.dwconv.kernel_size)
+        h = _DwConvFn.apply(inp, self.dwconv.weight, self.dwconv.bias, k)
+        h = self.norm(h)                                  # channels-last LayerNorm
+        h = self.pwconv1(h)
+        h = _GeluFn.apply(h)
+        h = self.pwconv2(h)
+        return _nc(_ScaleResidualFn.apply(h, inp, self.gamma))
+
+
+# ------------------------------------------------------------------ converter
+def dense_model_to_sparse(m: nn.Module, verbose=False, sbn=False):
+    """SparseEncoder.dense_model_to_sparse (encoder3D.py:300-364): recursive swap of a dense model's layers for the sparse ones,
+    copying parameters and buffers."""
+    oup = m
+    if isinstance(m, nn.Conv3d) and not isinstance(m, SparseConv3d):
+        if not getattr(m, "skip_sparse_conversion", False):
+            bias = m.bias is not None
+            oup = SparseConv3d(m.in_channels, m.out_channels, kernel_size=m.kernel_size, stride=m.stride, padding=m.padding, dilation=m.dilation,
+                               groups=m.groups, bias=bias, padding_mode=m.padding_mode)
+            oup.weight.data.copy_(m.weight.data)
+            if bias:
+                oup.bias.data.copy_(m.bias.data)
+    elif isinstance(m, nn.MaxPool3d) and not isinstance(m, SparseMaxPooling):
+        oup = SparseMaxPooling(m.kernel_size, stride=m.stride, padding=m.padding, dilation=m.dilation, return_indices=m.return_indices,
+                               ceil_mode=m.ceil_mode)
+    elif isinstance(m, nn.AvgPool3d) and not isinstance(m, SparseAvgPooling):
+        oup = SparseAvgPooling(m.kernel_size, m.stride, m.padding, ceil_mode=m.ceil_mode, count_include_pad=m.count_include_pad,
+                               divisor_override=m.divisor_override)
+    elif isinstance(m, nn.GroupNorm) and not isinstance(m, SparseGroupNorm):
+        oup = SparseGroupNorm(m.num_groups, m.num_channels, eps=m.eps)         # (the reference does not copy the affine parameters either)
+    elif isinstance(m, nn.AdaptiveAvgPool3d) and not isinstance(m, SparseAdaptiveAvgPooling):
+        oup = SparseAdaptiveAvgPooling(output_size=(1, 1, 1))
+    elif isinstance(m, (nn.BatchNorm3d, nn.SyncBatchNorm)):
+        oup = (SparseSyncBatchNorm3d if sbn else SparseBatchNorm3d)(m.weight.shape[0], eps=m.eps, momentum=m.momentum, affine=m.affine,
+                                                                    track_running_stats=m.track_running_stats)
+        oup.weight.data.copy_(m.weight.data); oup.bias.data.copy_(m.bias.data)
+        oup.running_mean.data.copy_(m.running_mean.data); oup.running_var.data.copy_(m.running_var.data)
+        oup.num_batches_tracked.data.copy_(m.num_batches_tracked.data)
+    elif isinstance(m, nn.LayerNorm) and not isinstance(m, SparseConvNeXtLayerNorm):
+        oup = SparseConvNeXtLayerNorm(m.weight.shape[0], eps=m.eps)
+        oup.weight.data.copy_(m.weight.data); oup.bias.data.copy_(m.bias.data)
+    elif isinstance(m, nn.Conv1d):
+        raise NotImplementedError
+    for name, child in m.named_children():
+        oup.add_module(name, dense_model_to_sparse(child, verbose=verbose, sbn=sbn))
+    del m
+    return oup

@@ -200,6 +200,58 @@ int am_spline_prefilter(float* vol, int D, int H, int W, void* stream);
 int am_resample_affine(const float* src, int Ds, int Hs, int Ws, float* dst, int D, int H, int W, const float* affine_host12, int order,
                        float cval, void* stream);
 
+/* ---- sparse layer zoo of the SparK encoder for other backbones (P/encoder3D.py = nnunetv2/training/nnUNetTrainer/
+ * variants/pretrain/encoder3D.py).  Same tensors as above: channels-last [B][D][H][W][C] + uint8 patch mask (fd, fh, fw) + block shift;
+ * inactive voxels hold don't-care bits, are read as zeros (the reference keeps explicit zeros there) and are never written.  The
+ * streaming kernels walk the ACTIVE voxels through the active-patch list (am_mask_compact): mask != NULL requires it (else -2).
+ * mask == NULL: dense tensor. */
+
+/* Per-voxel normalisation over channel groups.  kind 0: y = (x - mean_g) * rsqrt(var_g + eps) * gamma_c + beta_c with the statistics
+ * of the voxel's own channel group (biased variance) -- SparseConvNeXtLayerNorm (encoder3D.py:181-232; groups = 1) and SparseGroupNorm
+ * (:47-78: nn.GroupNorm applied to the (N, C) matrix of active voxels, hence per voxel).  kind 1: SparseGRN's sparse branch
+ * (:116-127): G = ||x||_2 over C, y = gamma_c * x * G / (G + 1e-6) + beta_c (beta may be NULL).  C / groups must be a multiple of the
+ * 16-byte chunk (8 bf16 / 4 f32 channels) or divide it.  bwd recomputes the statistics; dgamma / dbeta are ACCUMULATED (fp32 atomics). */
+int am_voxel_norm_fwd(int dtype, int kind, const void* x, void* y, int B, int D, int H, int W, int C, int groups, const float* gamma,
+                      const float* beta, float eps, const uint8_t* mask, int bshift, const int32_t* active_list, int n_active, void* stream);
+int am_voxel_norm_bwd(int dtype, int kind, const void* x, const void* dy, void* dx, int B, int D, int H, int W, int C, int groups,
+                      const float* gamma, float eps, float* dgamma_accum, float* dbeta_accum, const uint8_t* mask, int bshift,
+                      const int32_t* active_list, int n_active, void* stream);
+
+/* SparseMaxPooling / SparseAvgPooling (encoder3D.py:31-36): nn.MaxPool3d / nn.AvgPool3d (cubic kernel, dilation 1, no ceil_mode) of
+ * the zero-filled tensor, output written at active output voxels.  op 0 = max (argmax: int32 [.. Do Ho Wo C] input voxel index inside
+ * the sample, first maximum in scan order like torch; needed by the backward), 1 = average.  The mask is shared: in_bshift /
+ * out_bshift are the block shifts at the input / output resolution.  bwd is a gather over the windows covering each active INPUT voxel
+ * (no atomics). */
+int am_pool3d_fwd(int dtype, int op, const void* x, void* y, int32_t* argmax, int B, int Di, int Hi, int Wi, int C, int ksize, int stride,
+                  int pad, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift, int fd, int fh,
+                  int fw, const int32_t* active_list, int n_active, void* stream);
+int am_pool3d_bwd(int dtype, int op, const void* dy, const int32_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int C, int ksize,
+                  int stride, int pad, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift,
+                  int fd, int fh, int fw, const int32_t* active_list, int n_active, void* stream);
+
+/* Depthwise convolution k in {3, 5, 7}, stride 1, padding k/2 (SparseConvNeXtBlock.dwconv encoder3D.py:247 under sp_conv_forward
+ * :12-15; MedNeXt blocks): w fp32 [C][k^3] (torch (C,1,k,k,k)).  data_grad = 1: the data gradient (x = dy, taps mirrored, no bias).
+ * am_dwconv3d_wgrad ACCUMULATES dw [C][k^3] and db [C] (db may be NULL). */
+int am_dwconv3d(int dtype, int data_grad, const void* x, const float* w, const float* bias, void* y, int B, int D, int H, int W, int C,
+                int ksize, const uint8_t* mask, int bshift, int fd, int fh, int fw, void* stream);
+int am_dwconv3d_wgrad(int dtype, const void* x, const void* dy, float* dw_accum, float* db_accum, int B, int D, int H, int W, int C, int ksize,
+                      const uint8_t* mask, int bshift, int fd, int fh, int fw, void* stream);
+
+/* Pointwise tail of SparseConvNeXtBlock.forward (encoder3D.py:262-275).  am_gelu: dy == NULL: out = GELU(x) (erf form, nn.GELU());
+ * else out = dy * GELU'(x).  am_scale_residual: backward == 0: out = other + gamma_c * x (layer scale + residual; gamma NULL = 1);
+ * backward == 1: out = gamma_c * other (other = dy) and dgamma_accum[c] += sum_v other * x. */
+int am_gelu(int dtype, const void* x, const void* dy, void* out, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift,
+            const int32_t* active_list, int n_active, void* stream);
+int am_scale_residual(int dtype, int backward, const void* x, const void* other, const float* gamma, void* out, float* dgamma_accum, int B, int D,
+                      int H, int W, int C, const uint8_t* mask, int bshift, const int32_t* active_list, int n_active, void* stream);
+
+/* SparseAdaptiveAvgPooling (encoder3D.py:171-179): mean[b][c] = sum over the active voxels of sample b / (their number + 1e-6).
+ * bwd: dx = dmean[b][c] / (count[b] + 1e-6) on the active voxels; count: fp32 [B] active voxels per sample. */
+int am_masked_mean_fwd(int dtype, const void* x, float* mean, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
+                       int fw, void* stream);
+int am_masked_mean_bwd(int dtype, const float* dmean, const float* count, void* dx, int B, int D, int H, int W, int C, const uint8_t* mask,
+                       int bshift, const int32_t* active_list, int n_active, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,171 @@
+"""GPU: the HIP sparse layer zoo (anatomask_amd/sparse_layers.py on csrc/layer_ops.hip) against (1) the golden vectors of the
+reference's own classes (tests/golden/layers_tiny.npz, fp32, tight) and (2) the pinned CPU oracle on larger seeded cases (fp32 and
+bf16 storage)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "layers_tiny.npz"))
+
+
+@pytest.fixture(scope="module")
+def SL():
+    from anatomask_amd import modules, sparse_layers
+    yield sparse_layers
+    modules._cur_active = None
+
+
+def t(name):
+    return torch.from_numpy(G[name])
+
+
+def set_active(active):
+    from anatomask_amd import modules
+    modules._cur_active = active.to(DEV)
+
+
+def up(active, size):
+    from oracle import layers_oracle as LO
+    return LO.up(active, size)
+
+
+def load_params(module, name):
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            p.copy_(t(f"{name}.p.{n}").view_as(p))
+    return module.to(DEV)
+
+
+def run_fixture(name, module, cl=False, tol=2e-5, gtol=1e-4, train=True):
+    """forward + backward of `module` on the fixture's x / g; compares y, dx (active voxels) and the parameter gradients."""
+    active = t("active")
+    set_active(active)
+    module.train(train)
+    x = t(name + ".x").to(DEV).requires_grad_(True)
+    y = module(x)
+    want = t(name + ".y")
+    assert y.shape == want.shape, (y.shape, want.shape)
+    err = (y.detach().cpu().float() - want).abs().max().item()
+    assert err <= tol * max(1.0, want.abs().max().item()), (name, "y", err)
+    (y * t(name + ".g").to(DEV)).sum().backward()
+    m = up(active, x.shape[1:4] if cl else x.shape[2:]).float()
+    m = m.permute(0, 2, 3, 4, 1) if cl else m
+    wdx = t(name + ".dx")
+    err = ((x.grad.cpu() - wdx) * m).abs().max().item()
+    assert err <= gtol * max(1.0, wdx.abs().max().item()), (name, "dx", err)
+    for n, p in module.named_parameters():
+        key = f"{name}.d.{n}"
+        if key in G.files:
+            w = t(key).view_as(p)
+            err = (p.grad.cpu().float() - w).abs().max().item()
+            assert err <= gtol * max(1.0, w.abs().max().item()), (name, n, err)
+    return module
+
+
+@pytest.mark.parametrize("name,k,s,p", [("maxpool_k2", 2, 2, 0), ("maxpool_k3s2p1", 3, 2, 1)])
+def test_max_pool_fixture(SL, name, k, s, p):
+    run_fixture(name, SL.SparseMaxPooling(k, s, p))
+
+
+@pytest.mark.parametrize("name,k,s,p,cip", [("avgpool_k2", 2, 2, 0, True), ("avgpool_k3s2p1", 3, 2, 1, True), ("avgpool_k3s2p1_nopad", 3, 2, 1, False)])
+def test_avg_pool_fixture(SL, name, k, s, p, cip):
+    run_fixture(name, SL.SparseAvgPooling(k, s, p, count_include_pad=cip))
+
+
+def test_batch_norm_fixture(SL):
+    bn = load_params(SL.SparseBatchNorm3d(16), "bn_train")
+    run_fixture("bn_train", bn)
+    assert torch.allclose(bn.running_mean.cpu(), t("bn_train.b.running_mean"), atol=1e-5)
+    assert torch.allclose(bn.running_var.cpu(), t("bn_train.b.running_var"), atol=1e-5)
+    assert int(bn.num_batches_tracked) == int(G["bn_train.b.num_batches_tracked"])
+    bn.zero_grad()
+    active = t("active"); set_active(active)
+    bn.eval()
+    with torch.no_grad():
+        y = bn(t("bn_eval.x").to(DEV))
+    assert (y.cpu() - t("bn_eval.y")).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("name,groups", [("gn_g2", 2), ("gn_gC", 16)])
+def test_group_norm_fixture(SL, name, groups):
+    # one channel per group: (x - mean) is exactly 0, the reference's fused x * (rstd * gamma) + (beta - mean * rstd * gamma) form leaves
+    # rounding noise amplified by rstd = 1 / sqrt(eps) = 1000 around beta
+    run_fixture(name, load_params(SL.SparseGroupNorm(groups, 16), name), tol=2e-5 if groups == 2 else 1e-3, gtol=1e-4 if groups == 2 else 1e-3)
+
+
+def test_layer_norm_fixture(SL):
+    run_fixture("ln_cf", load_params(SL.SparseConvNeXtLayerNorm(16, data_format="channels_first"), "ln_cf"))
+    run_fixture("ln_cl", load_params(SL.SparseConvNeXtLayerNorm(16), "ln_cl"), cl=True)
+
+
+def test_grn_fixture(SL):
+    run_fixture("grn", load_params(SL.SparseGRN(8), "grn"), cl=True)
+
+
+def test_adaptive_avg_pool_fixture(SL):
+    run_fixture("adaptive_avg", SL.SparseAdaptiveAvgPooling((1, 1, 1)))
+
+
+@pytest.mark.parametrize("name,args", [("dwconv7", dict(kernel_size=7, padding=3, groups=16)), ("dwconv3", dict(kernel_size=3, padding=1, groups=16)),
+                                       ("conv3s2", dict(kernel_size=3, stride=2, padding=1))])
+def test_sparse_conv_fixture(SL, name, args):
+    cout = 24 if name == "conv3s2" else 16
+    run_fixture(name, load_params(SL.SparseConv3d(16, cout, **args), name), tol=5e-5, gtol=2e-4)
+
+
+def test_convnext_block_fixture(SL):
+    run_fixture("convnext", load_params(SL.SparseConvNeXtBlock(16, layer_scale_init_value=0.5, ks=7), "convnext"), tol=5e-5, gtol=3e-4)
+
+
+def test_converter_swaps_layers_and_copies_state(SL):
+    import torch.nn as nn
+    dense = nn.Sequential(nn.Conv3d(16, 16, 3, padding=1), nn.BatchNorm3d(16), nn.MaxPool3d(2, 2), nn.GroupNorm(2, 16), nn.AvgPool3d(2, 2),
+                          nn.LayerNorm(16), nn.AdaptiveAvgPool3d(1))
+    dense[1].running_mean.fill_(0.3)
+    sp = SL.dense_model_to_sparse(dense)
+    kinds = [type(m).__name__ for m in sp]
+    assert kinds == ["SparseConv3d", "SparseBatchNorm3d", "SparseMaxPooling", "SparseGroupNorm", "SparseAvgPooling", "SparseConvNeXtLayerNorm",
+                     "SparseAdaptiveAvgPooling"], kinds
+    assert torch.equal(sp[0].weight, dense[0].weight) and torch.equal(sp[1].running_mean, dense[1].running_mean)
+    assert set(sp.state_dict()) == set(dense.state_dict())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_at_scale_against_the_oracle(SL, dtype):
+    """BN + ConvNeXt block (depthwise 7^3 -> LN -> 1x1 -> GELU -> 1x1 -> scale -> residual) + max pool on a 32^3 x 32-channel volume with a
+    4^3 mask grid: HIP (fp32 / bf16 storage) vs the pinned CPU oracle, forward and all gradients."""
+    from oracle import layers_oracle as LO
+    rs = np.random.RandomState(5)
+    B, f, S, C = 2, 4, 32, 32
+    active = torch.from_numpy(rs.rand(B, 1, f, f, f) < 0.4)
+    active.view(B, -1)[:, 0] = True
+    set_active(active)
+    x = torch.from_numpy(rs.standard_normal((B, C, S, S, S)).astype(np.float32)) * LO.up(active, (S, S, S)).float()
+    blk = SL.SparseConvNeXtBlock(C, layer_scale_init_value=0.5, ks=7)
+    with torch.no_grad():
+        blk.dwconv.weight.mul_(3.0); blk.gamma.add_(torch.from_numpy(rs.standard_normal(C).astype(np.float32)) * 0.2)
+    pool, bn = SL.SparseMaxPooling(2, 2), SL.SparseBatchNorm3d(C)
+    params = {n: p.detach().clone().requires_grad_(True) for n, p in blk.named_parameters()}
+    bw, bb = bn.weight.detach().clone().requires_grad_(True), bn.bias.detach().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = LO.sparse_max_pool(LO.convnext_block(LO.sparse_batch_norm(xr, active, bw, bb, None, None, True), active, params), active, 2, 2)
+    g = torch.from_numpy(rs.standard_normal(tuple(yr.shape)).astype(np.float32))
+    (yr * g).sum().backward()
+    blk, bn = blk.to(DEV), bn.to(DEV)
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    y = pool(blk(bn(xd)))
+    (y.float() * g.to(DEV)).sum().backward()
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+
+    def rel(a, b):
+        return ((a.cpu().float() - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(y.detach(), yr.detach()) <= tol, rel(y.detach(), yr.detach())
+    m = LO.up(active, (S, S, S)).float()
+    assert rel(xd.grad * m.to(DEV), xr.grad * m) <= tol * 2
+    for n, p in blk.named_parameters():
+        assert rel(p.grad, params[n].grad) <= tol * 3, (n, rel(p.grad, params[n].grad))
+    assert rel(bn.weight.grad, bw.grad) <= tol * 2 and rel(bn.bias.grad, bb.grad) <= tol * 2
