@@ -16,6 +16,16 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <typename T> __device__ __forceinline__ void chunk_to_f2(const u32x4& c, f32x2* f);
+template <> __device__ __forceinline__ void chunk_to_f2<float>(const u32x4& c, f32x2* f) {
+  f[0] = f32x2{__uint_as_float(c[0]), __uint_as_float(c[1])}; f[1] = f32x2{__uint_as_float(c[2]), __uint_as_float(c[3])};
+}
+template <> __device__ __forceinline__ void chunk_to_f2<bf16_t>(const u32x4& c, f32x2* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) f[i] = f32x2{__uint_as_float(c[i] << 16), __uint_as_float(c[i] & 0xffff0000u)};
+}
+
 // ---- enumeration of the ACTIVE voxels of a tensor: active-patch list x the voxels of a mask cell (w fastest), or all voxels (dense)
 struct VoxGeo {
   int B, D, H, W, C;
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256) void voxel_norm_bwd_kernel(const T* __restrict
       for (int j = 0; j < EPC; ++j) {
         float s = 0.f;
         for (int q = 0; q < NV; ++q) s += red[(q * CPV + tid) * 8 + j];
-        atomicAdd(&dst[tid * EPC + j], s);
+        atomicAdd(&dst[(size_t)(blockIdx.x % AM_LAYER_REP) * g.C + tid * EPC + j], s);
       }
     }
   }
@@ -301,6 +311,33 @@ __global__ __launch_bounds__(256) void pool3d_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// Branch-free staging of a haloed brick of one 16-byte channel chunk: every thread computes the addresses of all its rows, issues all
+// patch-mask bytes, then all data loads (clamped to a valid address), and only then selects -- two global round trips per workgroup
+// instead of two per row (a conditional load inside the loop serialises its latency).
+template <typename T, int ED, int EH, int EW, int P>
+__device__ __forceinline__ void stage_brick(u32x4* __restrict__ xb, const T* __restrict__ x, int b, int d0, int h0, int w0, int D, int H, int W, int C,
+                                            int c0, const MaskView& mask, int tid) {
+  constexpr int NE = ED * EH * EW, NIT = (NE + 255) / 256;
+  uint8_t mb[NIT]; bool inr[NIT]; size_t off[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + it * 256;
+    const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
+    const int id = d0 + ez - P, ih = h0 + ey - P, iw = w0 + ex - P;
+    inr[it] = e < NE && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    mb[it] = mask.m ? mask.peek(b, id, ih, iw, inr[it]) : (uint8_t)1;
+    off[it] = inr[it] ? ((((size_t)b * D + id) * H + ih) * W + iw) * C + c0 : (size_t)c0;
+  }
+  u32x4 v[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) v[it] = *(const u32x4*)(x + off[it]);
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + it * 256;
+    if (e < NE) xb[e] = (inr[it] && mb[it]) ? v[it] : u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
 // ---- depthwise k^3 convolution, stride 1, padding k/2.  One workgroup = one 8x8x16 brick x one 16-byte channel chunk: the haloed
 // brick of that chunk is staged once in LDS (bounds and the patch mask applied), a thread owns 4 consecutive w outputs and per
 // (td, th) row reads 4 + k - 1 chunks for 4 k multiply-adds per channel.  Weights of the chunk live in LDS as [tap][EPC] floats
@@ -314,9 +351,15 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   u32x4* xb = (u32x4*)lds;                                    // [ED][EH][EW] chunks
   float* wl = (float*)(lds + (size_t)ED * EH * EW * 16);      // [NT][EPC]
-  const int tid = threadIdx.x, c0 = blockIdx.y * EPC;
+  // workgroup id -> (brick, channel chunk): the chunks of one brick get ids that differ by 8, i.e. the same XCD under round-robin
+  // dispatch and neighbouring dispatch slots: they share the brick's cache lines in that XCD's L2 (each reads 16 of a voxel's C*2
+  // bytes; brick-major order with the chunk in blockIdx.y re-read the whole tensor from HBM once per chunk)
+  const int tid = threadIdx.x, nchunk = C / EPC;
   const int nbw = (W + DWW - 1) / DWW, nbh = (H + DWH - 1) / DWH, nbd = (D + DWD - 1) / DWD;
-  int bid = blockIdx.x;
+  const int t_ = blockIdx.x >> 3;
+  const int c0 = (t_ % nchunk) * EPC;
+  int bid = (t_ / nchunk) * 8 + (blockIdx.x & 7);
+  if (bid >= B * nbd * nbh * nbw) return;
   const int bw_ = bid % nbw; bid /= nbw;
   const int bh_ = bid % nbh; bid /= nbh;
   const int bd_ = bid % nbd; const int b = bid / nbd;
@@ -338,72 +381,78 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
     const int t = i / EPC, j = i % EPC;
     wl[i] = w[(size_t)(c0 + j) * NT + (flip ? NT - 1 - t : t)];
   }
-  for (int e = tid; e < ED * EH * EW; e += 256) {
-    const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
-    const int id = d0 + ez - P, ih = h0 + ey - P, iw = w0 + ex - P;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && mask.active(b, id, ih, iw))
-      v = *(const u32x4*)(x + ((((size_t)b * D + id) * H + ih) * W + iw) * C + c0);
-    xb[e] = v;
-  }
+  stage_brick<T, ED, EH, EW, P>(xb, x, b, d0, h0, w0, D, H, W, C, c0, mask, tid);
   __syncthreads();
   const int lw0 = (tid & 3) * 4, lh = (tid >> 2) & 7, ld = tid >> 5;      // 4 w-quads x 8 h x 8 d
-  float acc[4][EPC];
+  // two channels per register pair: the multiply-adds compile to v_pk_fma_f32 (the packed rate is the 157 TFLOP/s vector peak)
+  f32x2 acc[4][EPC / 2];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) acc[q][j] = (bias && !flip) ? bias[c0 + j] : 0.f;
+    for (int j = 0; j < EPC / 2; ++j) acc[q][j] = (bias && !flip) ? f32x2{bias[c0 + 2 * j], bias[c0 + 2 * j + 1]} : f32x2{0.f, 0.f};
 #pragma unroll 1
   for (int td = 0; td < K; ++td)
 #pragma unroll 1
     for (int th = 0; th < K; ++th) {
       const u32x4* row = xb + ((ld + td) * EH + lh + th) * EW + lw0;
-      float xr[4 + K - 1][EPC];
+      f32x2 xr[4 + K - 1][EPC / 2];
 #pragma unroll
-      for (int i = 0; i < 4 + K - 1; ++i) chunk_to_f<T>(row[i], xr[i]);
-      const float* wr = wl + (td * K + th) * K * EPC;
+      for (int i = 0; i < 4 + K - 1; ++i) chunk_to_f2<T>(row[i], xr[i]);
+      const f32x4* wr = (const f32x4*)(wl + (td * K + th) * K * EPC);
 #pragma unroll
       for (int tw = 0; tw < K; ++tw) {
-        float wv[EPC];
 #pragma unroll
-        for (int j = 0; j < EPC; ++j) wv[j] = wr[tw * EPC + j];
+        for (int j4 = 0; j4 < EPC / 4; ++j4) {
+          const f32x4 w4 = wr[tw * (EPC / 4) + j4];              // one 16-byte broadcast read = 4 channels of this tap
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const f32x2 wv = h2 ? f32x2{w4[2], w4[3]} : f32x2{w4[0], w4[1]};
+            const int j = j4 * 2 + h2;
 #pragma unroll
-          for (int j = 0; j < EPC; ++j) acc[q][j] += wv[j] * xr[q + tw][j];
+            for (int q = 0; q < 4; ++q) acc[q][j] = __builtin_elementwise_fma(wv, xr[q + tw][j], acc[q][j]);
+          }
+        }
       }
     }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int od = d0 + ld, oh = h0 + lh, ow = w0 + lw0 + q;
+    float o[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC / 2; ++j) { o[2 * j] = acc[q][j][0]; o[2 * j + 1] = acc[q][j][1]; }
     if (od < D && oh < H && ow < W && mask.active(b, od, oh, ow))
-      *(u32x4*)(y + ((((size_t)b * D + od) * H + oh) * W + ow) * C + c0) = f_to_chunk<T>(acc[q]);
+      *(u32x4*)(y + ((((size_t)b * D + od) * H + oh) * W + ow) * C + c0) = f_to_chunk<T>(o);
   }
 }
 
-// weight gradient: dw[c][t] += sum_v dy[v][c] * xm[v + t - P][c].  Lane = one (td, th) row of taps (K*K <= 49 of the 64 lanes),
-// holding K x EPC partial sums across ALL bricks of its workgroup; the 4 waves split the (d, h) rows of a brick.  Per group of 4
-// consecutive w voxels a lane reads 4 dy chunks (broadcast) and 4 + K - 1 x chunks of its own row.  One atomic flush per workgroup.
+// weight gradient: dw[c][t] += sum_v dy[v][c] * xm[v + t - P][c].  Lane = (one (td, th) row of taps, one of NSUB = 64 / K^2 interleaved
+// subsets of the brick's w-quads), holding K x EPC partial sums across ALL bricks of its workgroup; the 4 waves split the (d, h)
+// rows of a brick.  Per group of 4 consecutive w voxels a lane reads 4 dy chunks and 4 + K - 1 x chunks of its own row.  One atomic
+// flush per workgroup.  Workgroup id -> (slot, chunk) as in dwconv_kernel (the chunks of a brick share an XCD's L2).
 template <typename T, int K>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
-                                                           float* __restrict__ db, int B, int D, int H, int W, int C, MaskView mask) {
-  constexpr int EPC = TT<T>::EPC, P = K / 2, NT = K * K * K;
+                                                           float* __restrict__ db, int B, int D, int H, int W, int C, MaskView mask, int nslot) {
+  constexpr int EPC = TT<T>::EPC, P = K / 2, NT = K * K * K, KK = K * K, NSUB = 64 / KK;
   constexpr int ED = DWD + K - 1, EH = DWH + K - 1, EW = DWW + K - 1;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   u32x4* xb = (u32x4*)lds;
   u32x4* yb = xb + ED * EH * EW;                              // [DWD][DWH][DWW] chunks of dy
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c0 = blockIdx.y * EPC;
-  const int tl = lane < K * K ? lane : K * K - 1, td = tl / K, th = tl % K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nchunk = C / EPC;
+  const int t_ = blockIdx.x >> 3;
+  const int c0 = (t_ % nchunk) * EPC, slot = (t_ / nchunk) * 8 + (blockIdx.x & 7);
+  const bool live = lane < KK * NSUB;
+  const int sub = live ? lane / KK : 0, tl = lane % KK, td = tl / K, th = tl % K;
   const int nbw = (W + DWW - 1) / DWW, nbh = (H + DWH - 1) / DWH, nbd = (D + DWD - 1) / DWD;
   const int nbrick = B * nbd * nbh * nbw;
-  float acc[K][EPC], sb[EPC];
+  f32x2 acc[K][EPC / 2];
+  float sb[EPC];
 #pragma unroll
   for (int t = 0; t < K; ++t)
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) acc[t][j] = 0.f;
+    for (int j = 0; j < EPC / 2; ++j) acc[t][j] = f32x2{0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < EPC; ++j) sb[j] = 0.f;
-  for (int brick = blockIdx.x; brick < nbrick; brick += gridDim.x) {
+  for (int brick = slot; brick < nbrick; brick += nslot) {
     int bid = brick;
     const int bw_ = bid % nbw; bid /= nbw;
     const int bh_ = bid % nbh; bid /= nbh;
@@ -411,74 +460,81 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
     const int d0 = bd_ * DWD, h0 = bh_ * DWH, w0 = bw_ * DWW;
     __syncthreads();                                          // previous brick's reads are done
     int any = 0;
-    for (int e = tid; e < DWD * DWH * DWW; e += 256) {
-      const int lw = e % DWW, lh = (e / DWW) % DWH, ld = e / (DWW * DWH);
-      const int od = d0 + ld, oh = h0 + lh, ow = w0 + lw;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (od < D && oh < H && ow < W && mask.active(b, od, oh, ow)) { v = *(const u32x4*)(dy + ((((size_t)b * D + od) * H + oh) * W + ow) * C + c0); any = 1; }
-      yb[e] = v;
+    {
+      constexpr int NY = DWD * DWH * DWW / 256;
+      uint8_t mb[NY]; bool inr[NY]; size_t off[NY];
+#pragma unroll
+      for (int it = 0; it < NY; ++it) {
+        const int e = tid + it * 256;
+        const int od = d0 + e / (DWW * DWH), oh = h0 + (e / DWW) % DWH, ow = w0 + e % DWW;
+        inr[it] = od < D && oh < H && ow < W;
+        mb[it] = mask.m ? mask.peek(b, od, oh, ow, inr[it]) : (uint8_t)1;
+        off[it] = inr[it] ? ((((size_t)b * D + od) * H + oh) * W + ow) * C + c0 : (size_t)c0;
+      }
+      u32x4 v[NY];
+#pragma unroll
+      for (int it = 0; it < NY; ++it) v[it] = *(const u32x4*)(dy + off[it]);
+#pragma unroll
+      for (int it = 0; it < NY; ++it) {
+        const bool on = inr[it] && mb[it];
+        yb[tid + it * 256] = on ? v[it] : u32x4{0u, 0u, 0u, 0u};
+        any |= on ? 1 : 0;
+      }
     }
     if (!__syncthreads_or(any)) continue;                     // no active voxel: dy == 0 on the whole brick
-    for (int e = tid; e < ED * EH * EW; e += 256) {
-      const int ex = e % EW, ey = (e / EW) % EH, ez = e / (EW * EH);
-      const int id = d0 + ez - P, ih = h0 + ey - P, iw = w0 + ex - P;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && mask.active(b, id, ih, iw))
-        v = *(const u32x4*)(x + ((((size_t)b * D + id) * H + ih) * W + iw) * C + c0);
-      xb[e] = v;
-    }
+    stage_brick<T, ED, EH, EW, P>(xb, x, b, d0, h0, w0, D, H, W, C, c0, mask, tid);
     __syncthreads();
-    for (int r = wave; r < DWD * DWH; r += 4) {               // (d, h) rows of the brick
-      const int ld = r / DWH, lh = r % DWH;
-      const u32x4* xrow = xb + ((ld + td) * EH + lh + th) * EW;
-      const u32x4* yrow = yb + (ld * DWH + lh) * DWW;
+    // this wave's (d, h) rows r = wave, wave + 4, ...; a row has DWW / 4 w-quads; work item i = (row index, quad), lane takes i % NSUB == sub
+    constexpr int NQ = DWW / 4, NITEM = (DWD * DWH / 4) * NQ;
 #pragma unroll 1
-      for (int wq = 0; wq < DWW; wq += 4) {
-        float gy[4][EPC], xr[4 + K - 1][EPC];
+    for (int i = sub; i < NITEM; i += NSUB) {
+      const int r = wave + 4 * (i / NQ), wq = (i % NQ) * 4;
+      const int ld = r / DWH, lh = r % DWH;
+      const u32x4* xrow = xb + ((ld + td) * EH + lh + th) * EW + wq;
+      const u32x4* yrow = yb + (ld * DWH + lh) * DWW + wq;
+      f32x2 gy[4][EPC / 2], xr[4 + K - 1][EPC / 2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) chunk_to_f<T>(yrow[wq + q], gy[q]);
+      for (int q = 0; q < 4; ++q) chunk_to_f2<T>(yrow[q], gy[q]);
 #pragma unroll
-        for (int i = 0; i < 4 + K - 1; ++i) chunk_to_f<T>(xrow[wq + i], xr[i]);
+      for (int q = 0; q < 4 + K - 1; ++q) chunk_to_f2<T>(xrow[q], xr[q]);
 #pragma unroll
-        for (int t = 0; t < K; ++t)
+      for (int t = 0; t < K; ++t)
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < EPC; ++j) acc[t][j] += gy[q][j] * xr[q + t][j];
-        if (lane == 0) {
+          for (int j = 0; j < EPC / 2; ++j) acc[t][j] = __builtin_elementwise_fma(gy[q][j], xr[q + t][j], acc[t][j]);
+      if (tl == 0) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < EPC; ++j) sb[j] += gy[q][j];
-        }
+          for (int j = 0; j < EPC / 2; ++j) { sb[2 * j] += gy[q][j][0]; sb[2 * j + 1] += gy[q][j][1]; }
       }
     }
   }
-  // fold the 4 waves (fixed order), then one atomic per workgroup and (channel, tap)
+  // fold the 4 waves x NSUB subsets (fixed order), then one atomic per workgroup and (channel, tap)
   __syncthreads();
-  float* red = (float*)lds;                                   // [4][K*K][K][EPC] (+ [4][EPC] bias sums)
-  if (lane < K * K) {
+  float* red = (float*)lds;                                   // [4][64][K][EPC], then [4][NSUB][EPC] bias sums
+  if (live) {
 #pragma unroll
     for (int t = 0; t < K; ++t)
 #pragma unroll
-      for (int j = 0; j < EPC; ++j) red[((wave * K * K + lane) * K + t) * EPC + j] = acc[t][j];
-  }
-  if (lane == 0) {
+      for (int j = 0; j < EPC; ++j) red[((wave * 64 + lane) * K + t) * EPC + j] = acc[t][j / 2][j & 1];
+    if (tl == 0) {
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) red[4 * NT * EPC + wave * EPC + j] = sb[j];
+      for (int j = 0; j < EPC; ++j) red[4 * 64 * K * EPC + (wave * NSUB + sub) * EPC + j] = sb[j];
+    }
   }
   __syncthreads();
   for (int i = tid; i < NT * EPC; i += 256) {
-    const int j = i % EPC, t = i / EPC;                       // t = (td*K + th)*K + tw
+    const int j = i % EPC, t = i / EPC, tw = t % K, row = t / K;    // t = (td*K + th)*K + tw
     float s = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < 4; ++wv) s += red[(wv * NT + t) * EPC + j];
+    for (int wv = 0; wv < 4; ++wv)
+      for (int sb_ = 0; sb_ < NSUB; ++sb_) s += red[((wv * 64 + sb_ * KK + row) * K + tw) * EPC + j];
     if (s != 0.f) atomicAdd(&dw[(size_t)(c0 + j) * NT + t], s);
   }
   if (db && tid < EPC) {
     float s = 0.f;
-#pragma unroll
-    for (int wv = 0; wv < 4; ++wv) s += red[4 * NT * EPC + wv * EPC + tid];
+    for (int q = 0; q < 4 * NSUB; ++q) s += red[4 * 64 * K * EPC + q * EPC + tid];
     if (s != 0.f) atomicAdd(&db[c0 + tid], s);
   }
 }
@@ -549,7 +605,7 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const T* __restrict
       for (int j = 0; j < EPC; ++j) {
         float s = 0.f;
         for (int q = 0; q < NV; ++q) s += red[(q * CPV + tid) * 8 + j];
-        atomicAdd(&dgamma[tid * EPC + j], s);
+        atomicAdd(&dgamma[(size_t)(blockIdx.x % AM_LAYER_REP) * g.C + tid * EPC + j], s);
       }
     }
   }
@@ -723,7 +779,7 @@ int launch_dw(const void* x, const float* w, const float* bias, void* y, int B, 
   const size_t sm = (size_t)(DWD + K - 1) * (DWH + K - 1) * (DWW + K - 1) * 16 + (size_t)K * K * K * EPC * 4;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int nbrick = B * ((D + DWD - 1) / DWD) * ((H + DWH - 1) / DWH) * ((W + DWW - 1) / DWW);
-  AM_LAUNCH(kern, dim3(nbrick, C / EPC), dim3(256), sm, st, (const T*)x, w, bias, (T*)y, B, D, H, W, C, mv, flip);
+  AM_LAUNCH(kern, dim3((unsigned)((nbrick + 7) / 8 * 8 * (C / EPC))), dim3(256), sm, st, (const T*)x, w, bias, (T*)y, B, D, H, W, C, mv, flip);
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -732,14 +788,14 @@ int launch_dw_wgrad(const void* x, const void* dy, float* dw, float* db, int B, 
   constexpr int EPC = TT<T>::EPC;
   auto kern = dwconv_wgrad_kernel<T, K>;
   size_t sm = ((size_t)(DWD + K - 1) * (DWH + K - 1) * (DWW + K - 1) + (size_t)DWD * DWH * DWW) * 16;
-  const size_t fold = (size_t)(4 * K * K * K * EPC + 4 * EPC) * 4;
+  const size_t fold = (size_t)(4 * 64 * K * EPC + 4 * (64 / (K * K)) * EPC) * 4;
   if (sm < fold) sm = fold;
   (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int nbrick = B * ((D + DWD - 1) / DWD) * ((H + DWH - 1) / DWH) * ((W + DWW - 1) / DWW);
-  int per_chunk = 512 / (C / EPC);                            // ~two workgroups per CU over all channel chunks
-  if (per_chunk < 1) per_chunk = 1;
-  if (per_chunk > nbrick) per_chunk = nbrick;
-  AM_LAUNCH(kern, dim3(per_chunk, C / EPC), dim3(256), sm, st, (const T*)x, (const T*)dy, dw, db, B, D, H, W, C, mv);
+  int nslot = 1024 / (C / EPC) / 8 * 8;                       // ~four workgroups per CU over all channel chunks, a multiple of 8
+  if (nslot < 8) nslot = 8;
+  if (nslot > (nbrick + 7) / 8 * 8) nslot = (nbrick + 7) / 8 * 8;
+  AM_LAUNCH(kern, dim3((unsigned)(nslot * (C / EPC))), dim3(256), sm, st, (const T*)x, (const T*)dy, dw, db, B, D, H, W, C, mv, nslot);
   AM_CHECK_LAUNCH();
   return 0;
 }

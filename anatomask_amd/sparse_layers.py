@@ -31,6 +31,7 @@ from .hip import lib as _lib
 
 
 # ------------------------------------------------------------------ plumbing
+LAYER_REP = 64   # AM_LAYER_REP: replicated rows of the per-channel gradient accumulators
 _MASK_CACHE = {"key": None, "mi": None}
 
 
@@ -104,11 +105,11 @@ class _VoxelNormFn(torch.autograd.Function):
         B, D, H, W, C = x_cl.shape
         dy = dy.contiguous()
         dx = torch.zeros_like(x_cl)
-        dg = torch.zeros(C, device=x_cl.device, dtype=torch.float32)
-        db = torch.zeros(C, device=x_cl.device, dtype=torch.float32)
+        dg = torch.zeros(LAYER_REP, C, device=x_cl.device, dtype=torch.float32)
+        db = torch.zeros(LAYER_REP, C, device=x_cl.device, dtype=torch.float32)
         _lib().voxel_norm_bwd(ops._dt(x_cl), kind, x_cl.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, D, H, W, C, groups, g32.data_ptr(), float(eps),
                               dg.data_ptr(), db.data_ptr(), ops._mk(mi)[0], bs, *_al(mi), _s())
-        return dx, dg.view(gshape), (db.view(bshape) if bshape is not None else None), None, None, None
+        return dx, dg.sum(0).view(gshape), (db.sum(0).view(bshape) if bshape is not None else None), None, None, None
 
 
 class SparseGroupNorm(nn.GroupNorm):
@@ -455,10 +456,10 @@ class _ScaleResidualFn(torch.autograd.Function):
         B, D, H, W, C = x_cl.shape
         dy = dy.contiguous()
         dx = torch.zeros_like(x_cl)
-        dg = torch.zeros(C, device=x_cl.device, dtype=torch.float32) if has_g else None
+        dg = torch.zeros(LAYER_REP, C, device=x_cl.device, dtype=torch.float32) if has_g else None
         _lib().scale_residual(ops._dt(x_cl), 1, x_cl.data_ptr(), dy.data_ptr(), g32.data_ptr() if has_g else None, dx.data_ptr(), ops._p(dg), B, D, H, W,
                               C, ops._mk(mi)[0], bs, *_al(mi), _s())
-        return dx, dy, dg
+        return dx, dy, (dg.sum(0) if has_g else None)
 
 
 class _PointwiseLinear(nn.Linear):

@@ -210,7 +210,10 @@ int am_resample_affine(const float* src, int Ds, int Hs, int Ws, float* dst, int
  * of the voxel's own channel group (biased variance) -- SparseConvNeXtLayerNorm (encoder3D.py:181-232; groups = 1) and SparseGroupNorm
  * (:47-78: nn.GroupNorm applied to the (N, C) matrix of active voxels, hence per voxel).  kind 1: SparseGRN's sparse branch
  * (:116-127): G = ||x||_2 over C, y = gamma_c * x * G / (G + 1e-6) + beta_c (beta may be NULL).  C / groups must be a multiple of the
- * 16-byte chunk (8 bf16 / 4 f32 channels) or divide it.  bwd recomputes the statistics; dgamma / dbeta are ACCUMULATED (fp32 atomics). */
+ * 16-byte chunk (8 bf16 / 4 f32 channels) or divide it.  bwd recomputes the statistics; dgamma / dbeta are ACCUMULATED with fp32
+ * atomics into AM_LAYER_REP replicated rows [AM_LAYER_REP][C] that the caller zeroes and sums (a thousand workgroups adding into the
+ * same two cache lines serialise in L2: 278 us -> 40 us for a 54 MB tensor). */
+#define AM_LAYER_REP 64
 int am_voxel_norm_fwd(int dtype, int kind, const void* x, void* y, int B, int D, int H, int W, int C, int groups, const float* gamma,
                       const float* beta, float eps, const uint8_t* mask, int bshift, const int32_t* active_list, int n_active, void* stream);
 int am_voxel_norm_bwd(int dtype, int kind, const void* x, const void* dy, void* dx, int B, int D, int H, int W, int C, int groups,
@@ -239,7 +242,7 @@ int am_dwconv3d_wgrad(int dtype, const void* x, const void* dy, float* dw_accum,
 
 /* Pointwise tail of SparseConvNeXtBlock.forward (encoder3D.py:262-275).  am_gelu: dy == NULL: out = GELU(x) (erf form, nn.GELU());
  * else out = dy * GELU'(x).  am_scale_residual: backward == 0: out = other + gamma_c * x (layer scale + residual; gamma NULL = 1);
- * backward == 1: out = gamma_c * other (other = dy) and dgamma_accum[c] += sum_v other * x. */
+ * backward == 1: out = gamma_c * other (other = dy) and dgamma_accum[r][c] += sum_v other * x (AM_LAYER_REP rows, as above). */
 int am_gelu(int dtype, const void* x, const void* dy, void* out, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift,
             const int32_t* active_list, int n_active, void* stream);
 int am_scale_residual(int dtype, int backward, const void* x, const void* other, const float* gamma, void* out, float* dgamma_accum, int B, int D,
