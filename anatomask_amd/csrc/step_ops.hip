@@ -162,7 +162,8 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, double* out) {
 __global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  float* __restrict__ ema, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
                                  float bc2_sqrt, const double* __restrict__ sumsq, float max_norm, float ema_decay,
-                                 float grad_scale, float* __restrict__ gnorm_out) {
+                                 float grad_scale, float* __restrict__ gnorm_out, const float* __restrict__ dyn) {
+  if (dyn) { lr = dyn[0]; bc1 = dyn[1]; bc2_sqrt = dyn[2]; ema_decay = dyn[3]; }   // hipGraph replays: the per-step scalars live in device memory
   // grad_scale: g holds the SUM of the ranks' gradients; the 1/world of DDP's mean is folded in here (norm and update see g*scale)
   const float total = sumsq ? (float)sqrt(sumsq[0]) * grad_scale : 0.f;
   float coef = sumsq ? max_norm / (total + 1e-6f) : 1.f;
@@ -239,12 +240,12 @@ int am_sumsq(const float* g, long n, double* out, void* stream) {
 
 int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, double lr, double beta1, double beta2, double eps,
                  double weight_decay, int step, const double* sumsq, double max_norm, double ema_decay, double grad_scale,
-                 float* gnorm_out, void* stream) {
+                 float* gnorm_out, const float* dyn_scalars, void* stream) {
   if (n % 4) return -1;
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);   // as torch: python doubles
   int nb = (int)((n / 4 + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
   AM_LAUNCH(adamw_ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, (float)lr, (float)beta1, (float)beta2,
-                     (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2), sumsq, (float)max_norm, (float)ema_decay, (float)grad_scale, gnorm_out);
+                     (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2), sumsq, (float)max_norm, (float)ema_decay, (float)grad_scale, gnorm_out, dyn_scalars);
   AM_CHECK_LAUNCH();
   return 0;
 }

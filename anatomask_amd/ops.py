@@ -464,9 +464,15 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
     hip.lib().sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream())
 
 
-def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, ema_decay, gnorm_out, grad_scale: float = 1.0):
+def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, ema_decay, gnorm_out, grad_scale: float = 1.0, dyn=None):
     hip.lib().adamw_ema(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(ema), n, lr, betas[0], betas[1], eps, wd, step,
-                        _p(sumsq_t), max_norm, ema_decay, grad_scale, _p(gnorm_out), _stream())
+                        _p(sumsq_t), max_norm, ema_decay, grad_scale, _p(gnorm_out), _p(dyn), _stream())
+
+
+def adam_dyn_scalars(lr: float, betas, step: int, ema_decay: float):
+    """the float[4] am_adamw_ema reads from device memory in graph replays (same roundings as its by-value path)."""
+    import math
+    return [float(lr), 1.0 - betas[0] ** step, math.sqrt(1.0 - betas[1] ** step), float(ema_decay)]
 
 
 def ema(ema_t: torch.Tensor, p: torch.Tensor, decay: float):

@@ -21,6 +21,7 @@ class AnatoMaskTrainer:
                  clip: float = 12.0, ema_decay: float = 0.999, total_epochs: int = 1000, guide: bool = True, seed: int = 4321,
                  process_group=None, distributed: Optional[bool] = None, self_distill: bool = True, deterministic_wgrad: bool = False):
         self.model = model
+        self._capturing, self._graph, self._graph_key = False, None, None
         if deterministic_wgrad:
             # convolution weight gradients as per-slot partial sums folded in a fixed order instead of fp32 atomics (am_conv3d_wgrad's
             # det_workspace; +3 % step time).  Process-wide, like torch.use_deterministic_algorithms.  The per-channel norm statistics
@@ -134,13 +135,18 @@ class AnatoMaskTrainer:
         del tape
         self._finish_exchange()
         # 6. clip + AdamW + EMA (:437-440), one pass over the live parameters
-        self.step_count += 1
         n = m._live_end
         decay = self.teacher.decay if ema_decay is None else ema_decay
         ops.sumsq(m._gflat[:n], self.sumsq)
+        dyn = None
+        if self._capturing:                                       # graphed_step: step count / lr arrive through device memory at replay
+            self._dyn_dev.copy_(self._dyn_host, non_blocking=True)
+            dyn = self._dyn_dev
+        else:
+            self.step_count += 1
         ops.adamw_ema(m._flat, m._gflat, self.m, self.v, t._flat if self.self_distill else None, n, self.lr if lr is None else lr,
-                      self.betas, self.eps, self.wd, self.step_count, self.sumsq, self.clip, decay, self.gnorm,
-                      grad_scale=self.grad_scale)
+                      self.betas, self.eps, self.wd, max(self.step_count, 1), self.sumsq, self.clip, decay, self.gnorm,
+                      grad_scale=self.grad_scale, dyn=dyn)
         if not self.self_distill:
             m.weights_changed()
             return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": None, "rec_loss": l2m}
@@ -152,6 +158,45 @@ class AnatoMaskTrainer:
                 e.copy_(e * decay + (1. - decay) * s_)
         m.weights_changed(); t.weights_changed()
         return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": recon, "rec_loss": l2m}
+
+    # ------------------------------------------------------------------ hipGraph replay of the step (launch-bound configurations)
+    def graphed_step(self, inp_bchwd: torch.Tensor, epoch: int = 0):
+        """step() captured once into a hipGraph (torch.cuda.CUDAGraph over the HIP stream capture: every am_* launch, the side-stream
+        weight gradients and torch's few glue ops become graph nodes) and replayed: one host call per step instead of ~600 launches.
+        For small volumes the step is launch-bound (STUNet-S 48^3: 5.9 ms eager, all of it host time).  The shapes, the epoch-dependent
+        host scalars (hard-mask quota, EMA decay) and the learning rate are baked into the graph: a change re-captures.  AdamW's step
+        count and lr reach the optimizer kernel through device memory (am_adamw_ema dyn_scalars), the mask draws through the
+        graph-registered generator.  Single-process only (no gradient exchange inside a graph).  The first two calls run eagerly
+        (one-time kernel attribute calls and workspace allocations must not happen under capture)."""
+        if self.distributed and self.world > 1:
+            raise RuntimeError("graphed_step: the gradient exchange is not captured; use step() under DDP")
+        m = self.model
+        L = m.spec.fmap[0] * m.spec.fmap[1] * m.spec.fmap[2]
+        key = (tuple(inp_bchwd.shape), m.len_loss_for(L, m.len_keep, epoch, self.total_epochs - 1, self.guide), self.teacher.decay, self.lr)
+        self._eager_calls = getattr(self, "_eager_calls", 0)
+        if self._eager_calls < 2:
+            self._eager_calls += 1
+            return self.step(inp_bchwd, epoch=epoch)
+        if self._graph_key != key:
+            dev = inp_bchwd.device
+            self._g_inp = inp_bchwd.clone()
+            self._dyn_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+            self._dyn_dev = torch.zeros(4, device=dev, dtype=torch.float32)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            g.register_generator_state(self.gen)
+            self._capturing = True
+            try:
+                with torch.cuda.graph(g):
+                    self._g_out = self.step(self._g_inp, epoch=epoch)
+            finally:
+                self._capturing = False
+            self._graph, self._graph_key = g, key
+        self._g_inp.copy_(inp_bchwd)
+        self.step_count += 1
+        self._dyn_host.copy_(torch.tensor(ops.adam_dyn_scalars(self.lr, self.betas, self.step_count, self.teacher.decay), dtype=torch.float32))
+        self._graph.replay()
+        return self._g_out
 
     @torch.no_grad()
     def eval_loss(self, inp_bchwd: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -187,7 +187,10 @@ int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema /* may
                  double beta2, double eps, double weight_decay, int step, const double* sumsq /* NULL: no clipping */,
                  double max_norm, double ema_decay, double grad_scale /* g is multiplied by it before the norm and the update: 1/world
                  when g holds the all-reduced SUM (DDP's gradient mean, P/pretrain_AnatoMask_DDP.py:239-240), else 1 */,
-                 float* gnorm_out, void* stream);
+                 float* gnorm_out,
+                 const float* dyn_scalars /* NULL, or DEVICE float[4] = {lr, 1 - beta1^step, sqrt(1 - beta2^step), ema_decay} that override
+                 the by-value arguments: a step captured in a hipGraph replays with per-step values the host writes before each launch */,
+                 void* stream);
 int am_ema(float* ema, const float* p, long n, double decay, void* stream);
 
 /* Device-side spatial augmentation of the data feed: batchgenerators' SpatialTransform (rotation, isotropic scale,
