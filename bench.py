@@ -99,7 +99,7 @@ def dominant_kernel_roofline(B, dev, tr, x):
     traffic = (605.5e6 + 536.9e6) * B / 2
     return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4,11,3,true> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
-            "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic.md (rocprofv3 --pmc, scaled from B=2)",
+            "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1.06 x algorithmic at B=2, scaled to the bench batch)",
             "algorithmic_bytes": (2 * 128 ** 3 * C * 2 * B) + 27 * C * C * 2, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops,
             "launch_ms_in_step": None if in_step is None else round(in_step, 4),
             "frac_in_step": None if in_step is None else round(flops / (in_step * 1e-3) / MFMA_BF16_PEAK, 4)}
