@@ -75,6 +75,19 @@ template <> __device__ __forceinline__ f32x4 mma_chunk<float>(const u32x4& a, co
   return acc;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane of the row: 4 v_add_f32 with DPP operands
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror).  __shfl_xor compiles to ds_bpermute_b32 -- an LDS instruction per step;
+// the statistics epilogue of conv_igemm issued 128 of them per lane (12 % of the dominant launch).
+__device__ __forceinline__ float row16_sum(float v) {
+#define AM_DPP_ADD(CTRL) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true))
+  AM_DPP_ADD(0xB1);    // quad_perm [1,0,3,2]
+  AM_DPP_ADD(0x4E);    // quad_perm [2,3,0,1]
+  AM_DPP_ADD(0x141);   // row_half_mirror
+  AM_DPP_ADD(0x140);   // row_mirror
+#undef AM_DPP_ADD
+  return v;
+}
+
 __device__ __forceinline__ float warp_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -333,8 +333,7 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
         float s1 = 0.f, s2 = 0.f;                        // sums over this lane's VS voxels of the STORED values
 #pragma unroll
         for (int j = 0; j < VS; ++j) { const float o = acc[i][j][r]; s1 += o; s2 += o * o; }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
         if (r16 == 0) {
           const int c = (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r;
           red[(wave * 16 * NS + c) * 2] = s1; red[(wave * 16 * NS + c) * 2 + 1] = s2;

@@ -363,8 +363,7 @@ _Pragma("unroll") \
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float s1 = s1a[i][q], s2 = s2a[i][q];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        s1 = row16_sum(s1); s2 = row16_sum(s2);
         if (r16 == 0) {
           const int c = (i >> 1) * 32 + g * 8 + (i & 1) * 4 + q;
           red[(wave * 16 * NS + c) * 2] = s1; red[(wave * 16 * NS + c) * 2 + 1] = s2;

@@ -1010,8 +1010,7 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __rest
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float a1 = s1[i][c], a2 = s2[i][c];
-#pragma unroll
-        for (int o_ = 8; o_ > 0; o_ >>= 1) { a1 += __shfl_xor(a1, o_, 64); a2 += __shfl_xor(a2, o_, 64); }
+        a1 = row16_sum(a1); a2 = row16_sum(a2);
         if (r16 == 0) {
           const int ch = (i >> 1) * 32 + g * 8 + (i & 1) * 4 + c;
           red[(wave * 16 * NS + ch) * 2] = a1; red[(wave * 16 * NS + ch) * 2 + 1] = a2;

