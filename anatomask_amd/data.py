@@ -35,6 +35,25 @@ class PreprocessedDataset:
     def __len__(self):
         return len(self.cases)
 
+    def unpack(self, overwrite: bool = False) -> int:
+        """nnunetv2.training.dataloading.utils.unpack_dataset: write `<case>.npy` / `<case>_seg.npy` next to every `<case>.npz` ONCE, so
+        that load_case memory-maps the volume instead of inflating the whole archive for every sampled patch.  Returns the number of
+        cases unpacked.  (Atomic per file: written under a temporary name, then renamed.)"""
+        n = 0
+        for key in self.cases:
+            base = os.path.join(self.folder, key)
+            if not os.path.isfile(base + ".npz") or (os.path.isfile(base + ".npy") and not overwrite):
+                continue
+            z = np.load(base + ".npz")
+            for name, arr in (("", z["data"]), ("_seg", z["seg"] if "seg" in z.files else None)):
+                if arr is None:
+                    continue
+                tmp = f"{base}{name}.tmp.npy"
+                np.save(tmp, arr)
+                os.replace(tmp, f"{base}{name}.npy")
+            n += 1
+        return n
+
     def load_case(self, key: str):
         base = os.path.join(self.folder, key)
         with open(base + ".pkl", "rb") as f:

@@ -129,6 +129,12 @@ def main(argv=None):
     lrs = linear_warmup_cosine_lrs(a.epochs, a.lr, a.warmup, 1e-6)                    # :359
     feed = val_feed = None
     if a.data:
+        if rank == 0:                                  # nnU-Net's unpack_dataset: .npz -> .npy once, then memory-mapped reads
+            n_unpacked = PreprocessedDataset(a.data).unpack()
+            if n_unpacked:
+                print(f"unpacked {n_unpacked} .npz cases to .npy", flush=True)
+        if world > 1:
+            dist.barrier()
         tr_keys, val_keys = split_cases(PreprocessedDataset(a.data).keys()) if a.plain_spark else (PreprocessedDataset(a.data).keys(), [])
         feed = Feed(a.data, tr_keys, a.batch_size, a.input_size, dev, rank, a.workers, not a.no_augment, seed=1000)
         if a.plain_spark and val_keys:

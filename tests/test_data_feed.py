@@ -117,3 +117,16 @@ def test_prefetch_loader_threads(tmp_path):
         assert len({tuple(b["keys"]) for b in bs}) > 1
     finally:
         pf.close()
+
+
+def test_unpack_dataset_once_and_same_batches(tmp_path):
+    """nnU-Net's unpack_dataset step: .npz -> .npy once (then memory-mapped reads); the sampled batches do not change."""
+    make_synthetic_folder(str(tmp_path), 7)
+    ds = PreprocessedDataset(str(tmp_path))
+    before = [next(PatchLoader3D(ds, 2, (16, 24, 16), seed=5))["data"].clone() for _ in range(1)]
+    assert ds.unpack() == 2 and ds.unpack() == 0                 # case_b / case_e had no .npy; a second call does nothing
+    assert os.path.isfile(os.path.join(str(tmp_path), "case_b.npy")) and os.path.isfile(os.path.join(str(tmp_path), "case_e_seg.npy"))
+    data, seg, _ = ds.load_case("case_b")
+    assert isinstance(data, np.memmap) and data.shape == (1, 20, 70, 33)
+    after = [next(PatchLoader3D(ds, 2, (16, 24, 16), seed=5))["data"] for _ in range(1)]
+    assert all(torch.equal(a, b) for a, b in zip(before, after))
