@@ -1550,7 +1550,7 @@ int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, c
                   int fw, double* sums, const int32_t* active_list, int n_active, void* stream) {
   CHK_C(C);
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
-  if (mask && !geo_ok(B, D, H, W)) return -4;
+  const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
   hipStream_t st = (hipStream_t)stream;
   hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * NREP, st);
   RowGeo rg;
@@ -1560,6 +1560,7 @@ int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, c
     AM_CHECK_LAUNCH();
     return 0;
   }
+  if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype, AM_LAUNCH(chan_stats_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, sums),
              AM_LAUNCH(chan_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, sums));
@@ -1603,7 +1604,7 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
                   void* stream) {
   CHK_C(C);
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
-  if (mask && !geo_ok(B, D, H, W)) return -4;
+  const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
   hipStream_t st = (hipStream_t)stream;
   RowGeo rg;
   if (mask && !fill && !(res && stem_x) && mkrows(rg, dtype, false, B, D, H, W, C, bshift, active_list, n_active)) {
@@ -1623,6 +1624,7 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
     AM_CHECK_LAUNCH();
     return 0;
   }
+  if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,
@@ -1641,7 +1643,7 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
-  if (mask && !geo_ok(B, D, H, W)) return -4;
+  const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
   hipStream_t st = (hipStream_t)stream;
   BwdFin fin{};
   if (k0) {                                  // fused finalize: bsum is a zero workspace [AM_NREP][C][3] doubles + one ticket word, left zero
@@ -1662,6 +1664,7 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
     AM_CHECK_LAUNCH();
     return 0;
   }
+  if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
              AM_LAUNCH(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
@@ -1689,10 +1692,11 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
-  if (mask && !geo_ok(B, D, H, W)) return -4;
+  const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
   hipStream_t st = (hipStream_t)stream;
   RowGeo rg;
   const bool rows = mask && mkrows(rg, dtype, false, B, D, H, W, C, bshift, active_list, n_active);
+  if (!rows && geo_bad) return -4;
   const int nb = rows ? rows_blocks(rg) : nblk((long)B * D * H * W, g.vpw);
   // bias-gradient sums: every workgroup adds C floats; on ONE accumulator 2048 workgroups serialise (measured 400 us on an
   // 8 MB tensor), so they go to AM_DXREP replicas that a 1-block kernel folds afterwards
@@ -1751,7 +1755,7 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
-  if (mask && !geo_ok(B, D, H, W)) return -4;
+  const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
   hipStream_t st = (hipStream_t)stream;
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;      // stage-0 tensor: 16^3 patches
   if (partial_rows_written) *partial_rows_written = B * (D / SBD) * (H / SBH) * (W / SBW);
@@ -1764,6 +1768,7 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
     if (partial_rows_written) *partial_rows_written = n_active;
     return 0;
   }
+  if (geo_bad) return -4;
   const int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
   const int pad_ = ksize / 2;
   size_t fl = (size_t)C * ksize * ksize * ksize;
@@ -1786,7 +1791,7 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
-  if (mask && !geo_ok(B, D, H, W)) return -4;
+  const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
   hipStream_t st = (hipStream_t)stream;
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;
   if (dtype == AM_DT_BF16 && active_list && n_active > 0 && (C == 32 || C == 64 || C == 96) && B <= 255 && fd <= 255 && fh <= 255 && fw <= 255) {
@@ -1806,6 +1811,7 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
     AM_CHECK_LAUNCH();
     return 0;
   }
+  if (geo_bad) return -4;
   int nb = B * (D / SBD) * (H / SBH) * (W / SBW);
   if (nb > 1024) nb = 1024;                                   // persistent workgroups: one atomic flush each
   const int pad_ = ksize / 2;

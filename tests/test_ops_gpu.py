@@ -655,3 +655,31 @@ def test_conv_rw_k3_s2_level1(ops, case, sparse):
     ops.chan_stats(y, mi, 3 if sparse else 0, st_b)
     ref = st_b.sums.cpu().sum(0)
     assert (st_a.sums.cpu()[0] - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_row_walk_kernels_beyond_the_linear_decode_limit(ops):
+    """B * D * H * W * max(D, H, W) >= 2^32 (batch 16 at 128^3): the linear kernels' reciprocal-multiply voxel decode stops being exact
+    there and they refuse (-4), but the row-walk kernels (active-patch list) have no such limit -- the norm passes of a block-sparse
+    tensor must work (bench.py's default batch).  Reference: torch on the same device, a thin 8-channel tensor."""
+    B, C, S, f = 16, 8, 128, 8
+    g = torch.Generator().manual_seed(0)
+    mask = torch.zeros(B, f ** 3, dtype=torch.bool)
+    for b in range(B):
+        mask[b, torch.randperm(f ** 3, generator=g)[:205]] = True
+    mask = mask.view(B, 1, f, f, f)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    x = torch.randn(B, S, S, S, C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).to(torch.bfloat16)
+    mf = mask.to(DEV).repeat_interleave(16, 2).repeat_interleave(16, 3).repeat_interleave(16, 4)[:, 0, ..., None]     # (B,S,S,S,1)
+    st = ops.NormStats(C, DEV)
+    ops.chan_stats(x, mi, 4, st)
+    st.count_host = float(B * 205 * 4096)
+    gam, bet = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    ops.norm_finalize(st, gam, bet, 1e-5)
+    y = ops.norm_apply(x, st, ops.ACT_LRELU, mi, 4)
+    xa = x.float()[mf.expand_as(x)].view(-1, C)
+    mean, var = xa.mean(0), xa.var(0, unbiased=False)
+    want = torch.nn.functional.leaky_relu((x.float() - mean) * torch.rsqrt(var + 1e-5) * gam + bet, 0.01)
+    err = torch.where(mf.expand_as(y), (y.float() - want).abs(), torch.zeros((), device=DEV)).max().item()     # inactive voxels: don't-care bits
+    assert err <= 2e-2 * want.abs().max().item(), err
+    with pytest.raises(RuntimeError, match="am_chan_sum failed with code -4"):      # a linear-walk kernel still refuses
+        ops.chan_sum(x, mi, 4, torch.zeros(C, device=DEV))

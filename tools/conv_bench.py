@@ -11,7 +11,7 @@ from anatomask_amd import ops  # noqa: E402
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = "cuda:0"
-B, C, S = int(os.environ.get("AM_CB_BATCH", "2")), 64, 128      # AM_CB_BATCH=8: the launch bench.py times for `roofline`
+B, C, S = int(os.environ.get("AM_CB_BATCH", "2")), 64, 128      # AM_CB_BATCH=16: the launch bench.py times for `roofline` (its default batch)
 x = torch.randn(B, S, S, S, C, device=dev).to(torch.bfloat16)
 dy = torch.randn(B, S, S, S, C, device=dev).to(torch.bfloat16)
 w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.02

@@ -9,12 +9,12 @@ cd $root
 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 python3 tools/stream_bench.py > $out/stream_bench.txt 2>&1
 python3 tools/layer_bench.py > $out/layer_bench.txt 2>&1
-python3 tools/conv_census.py > $out/conv_census.txt 2>&1
+python3 tools/conv_census.py 16 > $out/conv_census.txt 2>&1
 python3 tools/small_steps.py > $out/small_steps.txt 2>&1
-AM_CB_BATCH=8 python3 tools/conv_bench.py all 20 > $out/conv_bench_b8.txt 2>&1
+AM_CB_BATCH=16 python3 tools/conv_bench.py all 20 > $out/conv_bench_b16.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/step -- python3 $root/bench.py --steps 20 --warmup 5 > $out/bench_under_rocprof.json 2> $out/step.err
-AM_CB_BATCH=8 rocprofv3 --kernel-trace --stats --output-format csv -d $out/conv_b8 -- python3 $root/tools/conv_bench.py all 20 > $out/conv_b8.log 2>&1
+AM_CB_BATCH=16 rocprofv3 --kernel-trace --stats --output-format csv -d $out/conv_b16 -- python3 $root/tools/conv_bench.py all 20 > $out/conv_b16.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/conv_b2 -- python3 $root/tools/conv_bench.py all 10 > $out/conv_b2.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/tools/conv_bench.py all 3 > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/tools/conv_bench.py all 3 > $out/pmc_write.log 2>&1
