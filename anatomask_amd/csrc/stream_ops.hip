@@ -1077,20 +1077,24 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
         v = x[((size_t)(b * D + id) * H + ih) * W + iw];
       xl[e] = f2bf(v);
     }
-    for (int dz = 0; dz < 16; ++dz) {
-      u32x4 ld[NLD];
+    u32x4 ld[NLD];
+    auto load_plane = [&](int dz) {
 #pragma unroll
       for (int it = 0; it < NLD; ++it) {
         const int idx = tid + it * 256, vox = idx / CPV, ch = idx % CPV;
         const size_t gv = ((size_t)(b * D + d0 + dz) * H + h0 + (vox >> 4)) * W + w0 + (vox & 15);
         ld[it] = *(const u32x4*)(dy + gv * C + ch * 8);
       }
+    };
+    load_plane(0);
+    for (int dz = 0; dz < 16; ++dz) {
       __syncthreads();                                           // previous plane's fragment reads are done (first plane: xl is published below)
 #pragma unroll
       for (int it = 0; it < NLD; ++it) {
         const int idx = tid + it * 256, vox = idx / CPV, ch = idx % CPV;
         *(u32x4*)(yl + vox * RS + ch * 16) = ld[it];
       }
+      load_plane(dz < 15 ? dz + 1 : 15);                         // the next plane's loads fly during this plane's MFMAs (the last one re-loads: branch-free)
       __syncthreads();
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -1796,7 +1800,7 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;
   if (dtype == AM_DT_BF16 && active_list && n_active > 0 && (C == 32 || C == 64 || C == 96) && B <= 255 && fd <= 255 && fh <= 255 && fw <= 255) {
     const MaskView mv{mask, fd, fh, fw, bshift};
-    const int nwg = n_active < 512 ? n_active : 512;            // persistent: two workgroups per CU, one atomic flush each
+    const int nwg = n_active < 1024 ? n_active : 1024;          // persistent: four workgroups per CU, one atomic flush each
     const size_t sm = (size_t)(18 * 18 * 18 + 8) * 2 + (size_t)256 * (2 * C + 32);
 #define AM_STEM_WG(NS_, K_)                                                                                                           \
     {                                                                                                                                 \
