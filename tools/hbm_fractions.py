@@ -1,7 +1,7 @@
 """profiles/<name>.md: per-kernel HBM fractions of the streaming kernels of the bench step, from a committed rocprofv3
 `--kernel-trace --stats` CSV:  algorithmic bytes per launch / average launch duration / 8 TB/s.
 
-    python tools/hbm_fractions.py profiles/r02_b_step_kernel_stats_b8.csv [B=16] > profiles/r02_b_kernel_hbm_fractions.md
+    python tools/hbm_fractions.py profiles/r02_c_step_kernel_stats_b16.csv [B=16] > profiles/r02_c_kernel_hbm_fractions.md
 
 Only kernels that are launched on ONE shape per step are listed from the step CSV (the norm kernels run on a dozen shapes per step:
 their fractions come from the single-shape tools/stream_bench.py run, profiles/*stream_bench*).  Workload: STUNet-B, 128^3, mask 0.6,
