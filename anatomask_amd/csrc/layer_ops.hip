@@ -539,6 +539,99 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
   }
 }
 
+// ---- depthwise k^3 convolution with stride 2 (MedNeXtDownBlock.conv1, P/MedNeXt_head.py:335-341): the down blocks touch 1/8 of the
+// voxels of the stride-1 blocks around them and an input voxel is shared by only ~(k/2)^3 outputs, so these are direct kernels: one
+// thread per (active voxel, 16-byte channel chunk), the k^3 taps read through L1 / L2, the chunk's weights in LDS.
+// MODE 0: forward  y[o] = b + sum_t w[t] xm[2o + t - P];  MODE 1: data gradient  dx[i] = sum_{t : (i + P - t) even} w[t] dym[(i + P - t) / 2].
+template <typename T, int K, int MODE>
+__global__ __launch_bounds__(256) void dwconv_s2_kernel(const T* __restrict__ src, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        T* __restrict__ dst, VoxGeo g, int Ds, int Hs, int Ws, MaskView msrc) {
+  constexpr int EPC = TT<T>::EPC, P = K / 2, NT = K * K * K;
+  __shared__ float wl[NT * 8];
+  const int c0 = blockIdx.y * EPC;
+  for (int i = threadIdx.x; i < NT * EPC; i += 256) wl[i] = w[(size_t)(c0 + i % EPC) * NT + i / EPC];
+  __syncthreads();
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < g.nvox; e += (long)gridDim.x * 256) {
+    int b, d, h, wv;
+    const long v = g.vox(e, b, d, h, wv);
+    float acc[EPC];
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) acc[j] = (MODE == 0 && bias) ? bias[c0 + j] : 0.f;
+    if (MODE == 0) {
+      for (int td = 0; td < K; ++td) for (int th = 0; th < K; ++th) for (int tw = 0; tw < K; ++tw) {
+        const int id = 2 * d + td - P, ih = 2 * h + th - P, iw = 2 * wv + tw - P;
+        if ((unsigned)id >= (unsigned)Ds || (unsigned)ih >= (unsigned)Hs || (unsigned)iw >= (unsigned)Ws || !msrc.active(b, id, ih, iw)) continue;
+        float f[EPC];
+        chunk_to_f<T>(*(const u32x4*)(src + ((((size_t)b * Ds + id) * Hs + ih) * Ws + iw) * g.C + c0), f);
+        const float* wt = wl + ((td * K + th) * K + tw) * EPC;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[j] += wt[j] * f[j];
+      }
+    } else {
+      for (int td = (d + P) & 1; td < K; td += 2) for (int th = (h + P) & 1; th < K; th += 2) for (int tw = (wv + P) & 1; tw < K; tw += 2) {
+        const int od = (d + P - td) / 2, oh = (h + P - th) / 2, ow = (wv + P - tw) / 2;      // numerators are even and may be negative only by -? no: checked below
+        if (d + P - td < 0 || h + P - th < 0 || wv + P - tw < 0 || od >= Ds || oh >= Hs || ow >= Ws || !msrc.active(b, od, oh, ow)) continue;
+        float f[EPC];
+        chunk_to_f<T>(*(const u32x4*)(src + ((((size_t)b * Ds + od) * Hs + oh) * Ws + ow) * g.C + c0), f);
+        const float* wt = wl + ((td * K + th) * K + tw) * EPC;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) acc[j] += wt[j] * f[j];
+      }
+    }
+    *(u32x4*)(dst + v * g.C + c0) = f_to_chunk<T>(acc);
+  }
+}
+
+// weight gradient of the stride-2 depthwise convolution: dw[c][t] += sum_o dy[o][c] * xm[2o + t - P][c].  One workgroup = one channel
+// chunk x a strided share of the active output voxels; thread t owns taps t and t + 256 (k = 7: 343 taps) with EPC partial sums each,
+// every thread reads the same dy chunk (broadcast) and its own x chunk.  One atomic flush per workgroup.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_s2_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw,
+                                                              float* __restrict__ db, VoxGeo go, int Dx, int Hx, int Wx, MaskView mx) {
+  constexpr int EPC = TT<T>::EPC, P = K / 2, NT = K * K * K, TPT = (NT + 255) / 256;
+  const int c0 = blockIdx.y * EPC, tid = threadIdx.x;
+  float acc[TPT][EPC], sb[EPC];
+#pragma unroll
+  for (int q = 0; q < TPT; ++q)
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) acc[q][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) sb[j] = 0.f;
+  for (long e = blockIdx.x; e < go.nvox; e += gridDim.x) {
+    int b, od, oh, ow;
+    const long vo = go.vox(e, b, od, oh, ow);
+    float gy[EPC];
+    chunk_to_f<T>(*(const u32x4*)(dy + vo * go.C + c0), gy);
+    if (tid == 0) {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) sb[j] += gy[j];
+    }
+#pragma unroll
+    for (int q = 0; q < TPT; ++q) {
+      const int t = tid + q * 256;
+      if (t >= NT) continue;
+      const int id = 2 * od + t / (K * K) - P, ih = 2 * oh + (t / K) % K - P, iw = 2 * ow + t % K - P;
+      if ((unsigned)id >= (unsigned)Dx || (unsigned)ih >= (unsigned)Hx || (unsigned)iw >= (unsigned)Wx || !mx.active(b, id, ih, iw)) continue;
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + ((((size_t)b * Dx + id) * Hx + ih) * Wx + iw) * go.C + c0), f);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) acc[q][j] += gy[j] * f[j];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < TPT; ++q) {
+    const int t = tid + q * 256;
+    if (t < NT) {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) if (acc[q][j] != 0.f) atomicAdd(&dw[(size_t)(c0 + j) * NT + t], acc[q][j]);
+    }
+  }
+  if (db && tid == 0) {
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) if (sb[j] != 0.f) atomicAdd(&db[c0 + j], sb[j]);
+  }
+}
+
 // ---- pointwise tail of the ConvNeXt block
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_d(float v) {
@@ -829,6 +922,55 @@ int am_dwconv3d_wgrad(int dtype, const void* x, const void* dy, float* dw_accum,
     case 7: return bf ? launch_dw_wgrad<bf16_t, 7>(x, dy, dw_accum, db_accum, B, D, H, W, C, mv, st) : launch_dw_wgrad<float, 7>(x, dy, dw_accum, db_accum, B, D, H, W, C, mv, st);
     default: return -2;
   }
+}
+
+int am_dwconv3d_s2(int dtype, int data_grad, const void* src, const float* w, const float* bias, void* dst, int B, int Df, int Hf, int Wf,
+                   int C, int ksize, const uint8_t* mask, int fine_bshift, int fd, int fh, int fw, const int32_t* active_list, int n_active,
+                   void* stream) {
+  CHK_C(C);
+  if (Df % 2 || Hf % 2 || Wf % 2 || (mask && fine_bshift < 1)) return -2;
+  if (!list_ok(mask, active_list, n_active)) return -2;
+  const int Dc = Df / 2, Hc = Hf / 2, Wc = Wf / 2;
+  // forward walks the active COARSE (output) voxels and reads the fine tensor; the data gradient walks the active FINE voxels and reads dy
+  const VoxGeo g = data_grad ? mkvox(B, Df, Hf, Wf, C, mask ? active_list : nullptr, n_active, fine_bshift)
+                             : mkvox(B, Dc, Hc, Wc, C, mask ? active_list : nullptr, n_active, fine_bshift - 1);
+  if (g.nvox == 0) return 0;
+  const MaskView ms{mask, fd, fh, fw, data_grad ? fine_bshift - 1 : fine_bshift};
+  const int epc = dtype == AM_DT_BF16 ? 8 : 4;
+  const dim3 grid(nblocks(g.nvox), C / epc);
+  hipStream_t st = (hipStream_t)stream;
+  const int sd = data_grad ? Dc : Df, sh = data_grad ? Hc : Hf, sw = data_grad ? Wc : Wf;
+#define AM_S2(KK)                                                                                                                                   \
+  if (data_grad) DISPATCH_T(dtype, AM_LAUNCH((dwconv_s2_kernel<float, KK, 1>), grid, dim3(256), 0, st, (const float*)src, w, bias, (float*)dst, g, sd, sh, sw, ms), \
+                            AM_LAUNCH((dwconv_s2_kernel<bf16_t, KK, 1>), grid, dim3(256), 0, st, (const bf16_t*)src, w, bias, (bf16_t*)dst, g, sd, sh, sw, ms));     \
+  else DISPATCH_T(dtype, AM_LAUNCH((dwconv_s2_kernel<float, KK, 0>), grid, dim3(256), 0, st, (const float*)src, w, bias, (float*)dst, g, sd, sh, sw, ms),            \
+                  AM_LAUNCH((dwconv_s2_kernel<bf16_t, KK, 0>), grid, dim3(256), 0, st, (const bf16_t*)src, w, bias, (bf16_t*)dst, g, sd, sh, sw, ms))
+  if (ksize == 3) { AM_S2(3); } else if (ksize == 5) { AM_S2(5); } else if (ksize == 7) { AM_S2(7); } else return -2;
+#undef AM_S2
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_dwconv3d_s2_wgrad(int dtype, const void* x, const void* dy, float* dw_accum, float* db_accum, int B, int Df, int Hf, int Wf, int C,
+                         int ksize, const uint8_t* mask, int fine_bshift, int fd, int fh, int fw, const int32_t* active_list, int n_active,
+                         void* stream) {
+  CHK_C(C);
+  if (Df % 2 || Hf % 2 || Wf % 2 || (mask && fine_bshift < 1)) return -2;
+  if (!list_ok(mask, active_list, n_active)) return -2;
+  const VoxGeo go = mkvox(B, Df / 2, Hf / 2, Wf / 2, C, mask ? active_list : nullptr, n_active, fine_bshift - 1);
+  if (go.nvox == 0) return 0;
+  const MaskView mx{mask, fd, fh, fw, fine_bshift};
+  const int epc = dtype == AM_DT_BF16 ? 8 : 4;
+  long per = 2048 / (C / epc); if (per < 1) per = 1; if (per > go.nvox) per = go.nvox;
+  const dim3 grid((unsigned)per, C / epc);
+  hipStream_t st = (hipStream_t)stream;
+#define AM_S2W(KK)                                                                                                                                   \
+  DISPATCH_T(dtype, AM_LAUNCH((dwconv_s2_wgrad_kernel<float, KK>), grid, dim3(256), 0, st, (const float*)x, (const float*)dy, dw_accum, db_accum, go, Df, Hf, Wf, mx), \
+             AM_LAUNCH((dwconv_s2_wgrad_kernel<bf16_t, KK>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)dy, dw_accum, db_accum, go, Df, Hf, Wf, mx))
+  if (ksize == 3) { AM_S2W(3); } else if (ksize == 5) { AM_S2W(5); } else if (ksize == 7) { AM_S2W(7); } else return -2;
+#undef AM_S2W
+  AM_CHECK_LAUNCH();
+  return 0;
 }
 
 int am_gelu(int dtype, const void* x, const void* dy, void* out, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift,

@@ -243,11 +243,11 @@ def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, strid
 
 
 def stem_conv_fwd(x_b1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mask: Optional[MaskInfo], bshift: int,
-                  dtype: torch.dtype, want_partials: bool = False):
+                  dtype: torch.dtype, want_partials: bool = False, out: Optional[torch.Tensor] = None):
     """x_b1: fp32 [B,D,H,W]; w: (C,1,k,k,k) fp32.  want_partials: also return the (sum, sumsq) rows for the norm that follows."""
     B, D, H, W = x_b1.shape
     Cc, k = w.shape[0], w.shape[2]
-    y = torch.empty(B, D, H, W, Cc, device=x_b1.device, dtype=dtype)
+    y = torch.empty(B, D, H, W, Cc, device=x_b1.device, dtype=dtype) if out is None else out
     mp, fd, fh, fw = _mk(mask)
     part = None
     if want_partials:

@@ -32,6 +32,7 @@ from .hip import lib as _lib
 
 # ------------------------------------------------------------------ plumbing
 LAYER_REP = 64   # AM_LAYER_REP: replicated rows of the per-channel gradient accumulators
+COMPUTE_DTYPE = torch.float32   # activation dtype a Cin = 1 stem produces from the fp32 image (torch.bfloat16: bf16 storage downstream)
 _MASK_CACHE = {"key": None, "mi": None}
 
 
@@ -357,6 +358,69 @@ class _DwConvFn(torch.autograd.Function):
         return dx, dw.view(wshape), db, None
 
 
+class _DwConvS2Fn(torch.autograd.Function):
+    """depthwise convolution with stride 2 (MedNeXtDownBlock.conv1): am_dwconv3d_s2 / am_dwconv3d_s2_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, k):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        _check_list(mi)
+        if mi is not None and bs < 1:
+            raise RuntimeError("strided sparse conv at the mask-grid resolution: the output would be finer than the patch mask")
+        w32 = weight.float().contiguous().view(C, -1)
+        y = torch.zeros(B, D // 2, H // 2, W // 2, C, device=x_cl.device, dtype=x_cl.dtype)
+        mp, fd, fh, fw = ops._mk(mi)
+        _lib().dwconv3d_s2(ops._dt(x_cl), 0, x_cl.data_ptr(), w32.data_ptr(), ops._p(bias.float().contiguous() if bias is not None else None),
+                           y.data_ptr(), B, D, H, W, C, k, mp, bs, fd, fh, fw, *_al(mi), _s())
+        ctx.save_for_backward(x_cl, w32)
+        ctx.cfg = (mi, bs, k, weight.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, w32 = ctx.saved_tensors
+        mi, bs, k, wshape, has_bias = ctx.cfg
+        B, D, H, W, C = x_cl.shape
+        dy = dy.contiguous()
+        mp, fd, fh, fw = ops._mk(mi)
+        dx = torch.zeros_like(x_cl)
+        _lib().dwconv3d_s2(ops._dt(x_cl), 1, dy.data_ptr(), w32.data_ptr(), None, dx.data_ptr(), B, D, H, W, C, k, mp, bs, fd, fh, fw, *_al(mi), _s())
+        dw = torch.zeros(C, k ** 3, device=x_cl.device, dtype=torch.float32)
+        db = torch.zeros(C, device=x_cl.device, dtype=torch.float32) if has_bias else None
+        _lib().dwconv3d_s2_wgrad(ops._dt(x_cl), x_cl.data_ptr(), dy.data_ptr(), dw.data_ptr(), ops._p(db), B, D, H, W, C, k, mp, bs, fd, fh, fw,
+                                 *_al(mi), _s())
+        return dx, dw.view(wshape), db, None
+
+
+class _StemConvFn(torch.autograd.Function):
+    """Cin = 1 convolution k in {1, 3}, stride 1, on the stage-0 tensor (16^3 patches): am_stem_conv_fwd / am_stem_conv_wgrad.  The
+    input is the (masked) image: no data gradient is produced."""
+
+    @staticmethod
+    def forward(ctx, x_b1, weight, bias, k, dtype):
+        mi = current_mask(x_b1.device)
+        if mi is None or _bshift(mi, x_b1.shape[1]) != 4:
+            raise NotImplementedError("Cin = 1 sparse conv: the stem kernels need the patch mask at 16^3-voxel patches")
+        B, D, H, W = x_b1.shape
+        y = torch.zeros(B, D, H, W, weight.shape[0], device=x_b1.device, dtype=dtype)           # zeros at inactive voxels, like every layer here
+        ops.stem_conv_fwd(x_b1, weight.detach().float().contiguous(), bias.detach().float().contiguous() if bias is not None else None, mi, 4, dtype, out=y)
+        ctx.save_for_backward(x_b1)
+        ctx.cfg = (mi, k, weight.shape, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x_b1,) = ctx.saved_tensors
+        mi, k, wshape, has_bias = ctx.cfg
+        C = dy.shape[-1]
+        dw = torch.zeros(C, k ** 3, device=dy.device, dtype=torch.float32)
+        db = torch.zeros(C, device=dy.device, dtype=torch.float32) if has_bias else None
+        ops.stem_conv_wgrad(x_b1, dy.contiguous(), k, mi, 4, dw, db)
+        return None, dw.view(wshape), db, None, None
+
+
 class _ConvFn(torch.autograd.Function):
     """channel-mixing convolution k in {1, 3}, stride in {1, 2} on the matrix cores (am_conv3d / am_conv3d_wgrad)."""
 
@@ -395,7 +459,8 @@ class _ConvFn(torch.autograd.Function):
 
 class SparseConv3d(nn.Conv3d):
     """encoder3D.py:27-28 (sp_conv_forward :12-15): Conv3d, output masked.  Supported: 'same' padding k//2, dilation 1, zero padding;
-    groups == 1 with k in {1, 3}, stride in {1, 2} (matrix cores) or depthwise (groups == in == out) with k in {3, 5, 7}, stride 1."""
+    groups == 1 with k in {1, 3}, stride in {1, 2} (matrix cores); depthwise (groups == in == out) with k in {3, 5, 7}, stride 1 or 2;
+    Cin = 1 stems k in {1, 3} (output dtype = sparse_layers.COMPUTE_DTYPE: the image itself stays fp32)."""
 
     def forward(self, x):
         k, s, p = _one(self.kernel_size), _one(self.stride), _one(self.padding)
@@ -405,6 +470,10 @@ class SparseConv3d(nn.Conv3d):
             return _nc(_ConvFn.apply(_cl(x), self.weight, self.bias, k, s))
         if self.groups == self.in_channels == self.out_channels and k in (3, 5, 7) and s == 1:
             return _nc(_DwConvFn.apply(_cl(x), self.weight, self.bias, k))
+        if self.groups == self.in_channels == self.out_channels and k in (3, 5, 7) and s == 2 and self.in_channels % 8 == 0:
+            return _nc(_DwConvS2Fn.apply(_cl(x), self.weight, self.bias, k))
+        if self.in_channels == 1 and self.groups == 1 and k in (1, 3) and s == 1 and self.out_channels % 8 == 0:
+            return _nc(_StemConvFn.apply(x[:, 0].float().contiguous(), self.weight, self.bias, k, COMPUTE_DTYPE))
         raise NotImplementedError(f"SparseConv3d: groups={self.groups} k={k} stride={s} C={self.in_channels}->{self.out_channels} has no kernel")
 
 
@@ -460,6 +529,16 @@ class _ScaleResidualFn(torch.autograd.Function):
         _lib().scale_residual(ops._dt(x_cl), 1, x_cl.data_ptr(), dy.data_ptr(), g32.data_ptr() if has_g else None, dx.data_ptr(), ops._p(dg), B, D, H, W,
                               C, ops._mk(mi)[0], bs, *_al(mi), _s())
         return dx, dy, (dg.sum(0) if has_g else None)
+
+
+class SparseGELU(nn.GELU):
+    """nn.GELU() of the dense backbones (P/MedNeXt_head.py:291, encoder3D.py:250) on the active voxels only -- GELU(0) = 0, so the
+    reference leaves the dense module in place (encoder3D.py:264); here it runs on the HIP kernel like everything else."""
+
+    def forward(self, x):
+        if self.approximate != "none":
+            raise NotImplementedError("SparseGELU: the erf form only")
+        return _nc(_GeluFn.apply(_cl(x)))
 
 
 class _PointwiseLinear(nn.Linear):
@@ -530,6 +609,8 @@ def dense_model_to_sparse(m: nn.Module, verbose=False, sbn=False):
     elif isinstance(m, nn.LayerNorm) and not isinstance(m, SparseConvNeXtLayerNorm):
         oup = SparseConvNeXtLayerNorm(m.weight.shape[0], eps=m.eps)
         oup.weight.data.copy_(m.weight.data); oup.bias.data.copy_(m.bias.data)
+    elif isinstance(m, nn.GELU) and not isinstance(m, SparseGELU):
+        oup = SparseGELU()
     elif isinstance(m, nn.Conv1d):
         raise NotImplementedError
     for name, child in m.named_children():

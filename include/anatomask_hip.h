@@ -243,6 +243,16 @@ int am_dwconv3d(int dtype, int data_grad, const void* x, const float* w, const f
 int am_dwconv3d_wgrad(int dtype, const void* x, const void* dy, float* dw_accum, float* db_accum, int B, int D, int H, int W, int C, int ksize,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, void* stream);
 
+/* The same with stride 2 (MedNeXtDownBlock.conv1, P/MedNeXt_head.py:335-341; even fine extents Df, Hf, Wf; output Df/2 ...): direct
+ * kernels over the active voxels.  data_grad = 0: src = x (fine), dst = y (coarse); 1: src = dy (coarse), dst = dx (fine).
+ * fine_bshift: the mask's block shift at the FINE resolution (>= 1). */
+int am_dwconv3d_s2(int dtype, int data_grad, const void* src, const float* w, const float* bias, void* dst, int B, int Df, int Hf, int Wf,
+                   int C, int ksize, const uint8_t* mask, int fine_bshift, int fd, int fh, int fw, const int32_t* active_list, int n_active,
+                   void* stream);
+int am_dwconv3d_s2_wgrad(int dtype, const void* x, const void* dy, float* dw_accum, float* db_accum, int B, int Df, int Hf, int Wf, int C,
+                         int ksize, const uint8_t* mask, int fine_bshift, int fd, int fh, int fw, const int32_t* active_list, int n_active,
+                         void* stream);
+
 /* Pointwise tail of SparseConvNeXtBlock.forward (encoder3D.py:262-275).  am_gelu: dy == NULL: out = GELU(x) (erf form, nn.GELU());
  * else out = dy * GELU'(x).  am_scale_residual: backward == 0: out = other + gamma_c * x (layer scale + residual; gamma NULL = 1);
  * backward == 1: out = gamma_c * other (other = dy) and dgamma_accum[r][c] += sum_v other * x (AM_LAYER_REP rows, as above). */

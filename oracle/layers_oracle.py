@@ -90,3 +90,30 @@ def convnext_block(x, active, p, ks=7):
         h = p["gamma"] * h
     h = h.permute(0, 4, 1, 2, 3) * up(active, x.shape[2:])
     return x + h
+
+
+def mednext_block(x, active, p, pre, stride=1, res_conv=False):
+    """MedNeXtBlock.forward P/MedNeXt_head.py:301-309 / MedNeXtDownBlock.forward :343-351 under the converter (every Conv3d a SparseConv3d,
+    the GroupNorm(num_groups = C) a SparseGroupNorm with eps 1e-5 -- nn.GroupNorm's default, which the converter passes on :318-320)."""
+    C = x.shape[1]
+    h = sparse_conv3d(x, active, p[pre + "conv1.weight"], p[pre + "conv1.bias"], stride=stride, groups=C)
+    h = sparse_group_norm(h, active, C, p[pre + "norm.weight"], p[pre + "norm.bias"], 1e-5)
+    h = F.gelu(sparse_conv3d(h, active, p[pre + "conv2.weight"], p[pre + "conv2.bias"]))
+    h = sparse_conv3d(h, active, p[pre + "conv3.weight"], p[pre + "conv3.bias"])
+    if stride == 1:
+        return x + h                                        # do_res (:307-308)
+    if res_conv:
+        h = h + sparse_conv3d(x, active, p[pre + "res_conv.weight"], p[pre + "res_conv.bias"], stride=2)   # :347-349 (k1, padding 0 == k // 2)
+    return h
+
+
+def mednext_encoder(x, active, p):
+    """MedNeXt.forward(x, hierarchical=True) P/MedNeXt_head.py:200-233 for block_counts = 1, do_res = do_res_up_down = True."""
+    maps = []
+    h = sparse_conv3d(x, active, p["stem.weight"], p["stem.bias"])
+    for i in range(4):
+        h = mednext_block(h, active, p, f"enc_block_{i}.0.")
+        maps.append(h)
+        h = mednext_block(h, active, p, f"down_{i}.", stride=2, res_conv=True)
+    maps.append(mednext_block(h, active, p, "bottleneck.0."))
+    return maps

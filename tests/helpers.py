@@ -91,3 +91,48 @@ def make_synthetic_folder(folder, seed=7):
             np.save(os.path.join(folder, name + ".npy"), data); np.save(os.path.join(folder, name + "_seg.npy"), seg)
         with open(os.path.join(folder, name + ".pkl"), "wb") as f:
             pickle.dump({"class_locations": locs, "spacing": [1.0, 1.0, 1.0]}, f)
+
+
+def tiny_mednext(n_channels=8, exp_r=2, k=3):
+    """A dense torch model with the layer structure and parameter names of the reference's MedNeXt encoder (P/MedNeXt_head.py:11-233,
+    block_counts = 1, do_res = do_res_up_down = True) written from plain torch.nn layers, for the sparse-layer converter to swap:
+    the GPU box has no reference to import.  forward(x, hierarchical=True) -> the 5 stage maps."""
+    import torch.nn as nn
+
+    class Block(nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.stride = stride
+            self.conv1 = nn.Conv3d(cin, cin, k, stride=stride, padding=k // 2, groups=cin)
+            self.norm = nn.GroupNorm(num_groups=cin, num_channels=cin)
+            self.conv2 = nn.Conv3d(cin, exp_r * cin, 1)
+            self.act = nn.GELU()
+            self.conv3 = nn.Conv3d(exp_r * cin, cout, 1)
+            if stride == 2:
+                self.res_conv = nn.Conv3d(cin, cout, 1, stride=2)
+
+        def forward(self, x):
+            h = self.conv3(self.act(self.conv2(self.norm(self.conv1(x)))))
+            return x + h if self.stride == 1 else h + self.res_conv(x)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            c = n_channels
+            self.stem = nn.Conv3d(1, c, 1)
+            for i in range(4):
+                setattr(self, f"enc_block_{i}", nn.Sequential(Block(c << i, c << i, 1)))
+                setattr(self, f"down_{i}", Block(c << i, c << (i + 1), 2))
+            self.bottleneck = nn.Sequential(Block(c << 4, c << 4, 1))
+
+        def forward(self, x, hierarchical=True):
+            maps = []
+            h = self.stem(x)
+            for i in range(4):
+                h = getattr(self, f"enc_block_{i}")(h)
+                maps.append(h)
+                h = getattr(self, f"down_{i}")(h)
+            maps.append(self.bottleneck(h))
+            return maps if hierarchical else maps[-1]
+
+    return Net()

@@ -13,7 +13,18 @@ ACTIVE = torch.from_numpy(G["active"])
 
 
 def t(name):
-    return torch.from_numpy(G[name])
+    """a fixture array; the common input x and the cotangents g are regenerated from their seeds (tests/golden/make_layer_fixtures.py)."""
+    if name in G.files:
+        return torch.from_numpy(G[name])
+    import zlib
+    case, kind = name.rsplit(".", 1)
+    if kind == "x":
+        from oracle import layers_oracle as LO
+        x = torch.from_numpy(np.random.RandomState(1).standard_normal((2, 16, 8, 8, 8)).astype(np.float32))
+        return x * LO.up(torch.from_numpy(G["active"]), (8, 8, 8)).float()
+    if kind == "g":
+        return torch.from_numpy(np.random.RandomState(zlib.crc32(case.encode()) % 1000 + 7).standard_normal(G[case + ".y"].shape).astype(np.float32))
+    raise KeyError(name)
 
 
 def check(name, fn, params=(), tol=2e-6, cl=False):
@@ -76,3 +87,28 @@ def test_sparse_conv(name, stride, groups):
 def test_convnext_block():
     names = ("dwconv.weight", "dwconv.bias", "norm.weight", "norm.bias", "pwconv1.weight", "pwconv1.bias", "pwconv2.weight", "pwconv2.bias", "gamma")
     check("convnext", lambda x, ps: LO.convnext_block(x, ACTIVE, ps), names, tol=1e-5)
+
+
+@pytest.mark.parametrize("name,k", [("dwconv7s2", 7), ("dwconv3s2", 3)])
+def test_strided_depthwise_conv(name, k):
+    check(name, lambda x, ps: LO.sparse_conv3d(x, ACTIVE, ps["weight"], ps["bias"], 2, 16), ("weight", "bias"), tol=1e-5)
+
+
+def mednext_inputs():
+    act = torch.from_numpy(G["mednext.active"])
+    x = torch.from_numpy(np.random.RandomState(3).standard_normal((1, 1, 32, 32, 32)).astype(np.float32)) * LO.up(act, (32, 32, 32)).float()
+    gs = [torch.from_numpy(np.random.RandomState(50 + i).standard_normal(G[f"mednext.map{i}"].shape).astype(np.float32)) for i in range(5)]
+    return act, x, gs
+
+
+def test_mednext_encoder_under_spark():
+    """a tiny MedNeXt (P/MedNeXt_head.py) converted by the reference's SparseEncoder: 5 hierarchical maps and all 82 parameter gradients."""
+    act, x, gs = mednext_inputs()
+    p = {k[len("mednext.p."):]: t(k).clone().requires_grad_(True) for k in G.files if k.startswith("mednext.p.") and "dummy" not in k}
+    maps = LO.mednext_encoder(x, act, p)
+    for i, m in enumerate(maps):
+        assert torch.allclose(m, t(f"mednext.map{i}"), rtol=1e-4, atol=2e-5), (i, (m - t(f"mednext.map{i}")).abs().max())
+    sum((m * g).sum() for m, g in zip(maps, gs)).backward()
+    for k, v in p.items():
+        want = t("mednext.d." + k)
+        assert torch.allclose(v.grad, want, rtol=1e-3, atol=2e-4 * max(1.0, want.abs().max().item())), (k, (v.grad - want).abs().max())
