@@ -230,12 +230,18 @@ class SparseEncoder(nn.Module):
 
     def __init__(self, cnn, input_size, sbn=False, verbose=False):
         super().__init__()
-        self.sp_cnn = cnn
+        self.sp_cnn = SparseEncoder.dense_model_to_sparse(cnn, verbose=verbose, sbn=sbn)
         self.input_size, self.downsample_ratio, self.enc_feat_map_chs = input_size, cnn.get_downsample_ratio(), cnn.get_feature_map_channels()
 
     @staticmethod
     def dense_model_to_sparse(m: nn.Module, verbose=False, sbn=False):
-        return m
+        """This package's STUNet needs no rewrite (its engine takes the patch mask as a kernel argument).  Any OTHER dense backbone
+        (MedNeXt, ConvNeXt ...: plain torch.nn layers) is rewritten layer by layer as the reference does (P/encoder3D.py:300-364), onto
+        the HIP sparse layers of anatomask_amd.sparse_layers; it then runs stand-alone (`forward`), outside the fused STUNet trainer."""
+        if isinstance(m, STUNet):
+            return m
+        from .sparse_layers import dense_model_to_sparse
+        return dense_model_to_sparse(m, verbose=verbose, sbn=sbn)
 
     def forward(self, x):
         """P/encoder3D.py:366-367: `self.sp_cnn(x, hierarchical=True)` -> the 5 feature maps (fine -> coarse)."""

@@ -226,3 +226,25 @@ def test_mednext_encoder_under_spark_fixture(SL, dtype, tol):
     errs = {n: rel(p.grad, t("mednext.d." + n)) for n, p in net.named_parameters() if not dead(n)}
     worst = max(errs, key=errs.get)
     assert len(errs) == 82 - 27 and errs[worst] <= 4 * tol, (worst, errs[worst])
+
+
+def test_sparse_encoder_accepts_a_non_stunet_backbone(SL):
+    """SparseEncoder(cnn, input_size) of the reference's API with a dense MedNeXt-shaped backbone: converted on construction, forward =
+    sp_cnn(x, hierarchical=True) under modules._cur_active."""
+    from anatomask_amd import modules as M
+    from tests.helpers import tiny_mednext
+    dense = tiny_mednext()
+    dense.get_downsample_ratio = lambda: 16
+    dense.get_feature_map_channels = lambda: [8, 16, 32, 64, 128]
+    enc = M.SparseEncoder(dense, input_size=(32, 32, 32))
+    with torch.no_grad():                                   # after the conversion: like the reference's, the converter does not carry GroupNorm affines over
+        for n, p in enc.sp_cnn.named_parameters():
+            p.copy_(t("mednext.p." + n))
+    enc = enc.to(DEV)
+    assert type(enc.sp_cnn.stem).__name__ == "SparseConv3d" and enc.downsample_ratio == 16 and enc.enc_feat_map_chs == [8, 16, 32, 64, 128]
+    act = torch.from_numpy(G["mednext.active"])
+    set_active(act)
+    x = torch.from_numpy(np.random.RandomState(3).standard_normal((1, 1, 32, 32, 32)).astype(np.float32)) * up(act, (32, 32, 32)).float()
+    maps = enc(x.to(DEV))
+    for i, m in enumerate(maps):
+        assert (m.cpu() - t(f"mednext.map{i}")).norm().item() <= 3e-4 * t(f"mednext.map{i}").norm().item()
