@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
             for (int th = 0; th < 3; ++th) {
               u32x4 af[NS];
 #pragma unroll
-              for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + (tr * 3 + th) * NT * ROWB + aoff[i]);
+              for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + (tr * 3 + ((AM_DBG(a, 64) && th == 1) ? 0 : th)) * NT * ROWB + aoff[i]);
 #pragma unroll
               for (int j = 0; j < VS; ++j)
 #pragma unroll
