@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
         // a conditional load makes hipcc drain vmcnt at the join)
         AM_WLOAD(wr, more ? gi + 1 : 0, more ? kc : kc + KC, more || more_slabs);
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);                     // the MFMA cluster of a weight group issues ahead of the other wave's staging / address work (+1.5-3.5 %)
         // straight-line over the TG taps of the group (padding taps multiply zero weights): no per-tap branch, so the
         // fragment reads of tap t+1 can be scheduled under the MFMAs of tap t
         if constexpr (HR) {
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
           }
         }
         }
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (more) { if (!AM_DBG(a, 32)) { AM_WSTORE(wr, buf ^ 1); } if (!AM_DBG(a, 16)) __syncthreads(); }
       }

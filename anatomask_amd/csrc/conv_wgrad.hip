@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     __syncthreads();
 
     // ---- contract over the brick's voxels ----
+    if (!AM_DBG(a, 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     for (int ks = wk; ks < (AM_DBG(a, 2) ? 0 : MV / KSTEP); ks += KS) {
       if constexpr (sizeof(T) == 2) {
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
           for (int i = 0; i < MI; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[t], acc[t][i], 0, 0, 0);
       }
     }
+    if (!AM_DBG(a, 32)) __builtin_amdgcn_s_setprio(0);
   }
 
   // ---- flush: D row = cy 4g+r, col = cx r16 ----
