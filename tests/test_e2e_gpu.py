@@ -566,6 +566,9 @@ def test_two_ranks_on_one_gpu_stay_in_sync():
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("weights identical across ranks: True; teacher identical: True") == 2, r.stdout[-2000:]
+    # ... and what was exchanged IS the mean of the two ranks' local gradients (recomputed through the module API on each rank's
+    # own input and mask from the common start weights), global norm included
+    assert r.stdout.count("mean-of-gradients ok: True") == 2, r.stdout[-2000:]
 
 
 # ------------------------------------------------------------------------------------------------------------------------
