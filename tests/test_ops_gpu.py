@@ -442,6 +442,25 @@ def test_patch_loss_fwd_bwd(ops, normalized):
         close(drec.cpu(), rec.grad[:, 0], 1e-5, "drec")
 
 
+def test_patch_loss_teacher_path_skips_visible_patches(ops):
+    """want_loss=False (the teacher pass, pmean / prstd NULL): the kernel must not touch the VISIBLE patches at all -- their l2 is 0 by
+    definition and their rec voxels may never have been written (the teacher's last decoder conv only produces the masked patches).
+    NaN-filled visible patches must not leak into the result."""
+    cfg = O.Config([8] * 6, [1] * 6, 8, (32, 48, 32))
+    B = 2
+    mask = mk_mask(B, cfg.fmap, cfg.len_keep)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    inp = rnd(B, 1, *cfg.input_size, seed=1) * 1.7 + 0.3
+    rec = rnd(B, 1, *cfg.input_size, seed=2)
+    rl = O.teacher_patch_loss(O.patchify(cfg, inp), O.patchify(cfg, rec), mask)
+    vis = O.upsample_mask(mask, cfg.input_size)                  # True = visible
+    rec_nan = torch.where(vis, torch.full_like(rec, float("nan")), rec)
+    l2m, pm, pr, info = ops.patch_loss_fwd(inp[:, 0].contiguous().to(DEV), rec_nan[:, 0].contiguous().to(DEV), mi, False, want_loss=False)
+    assert pm is None and pr is None and info is None
+    assert torch.isfinite(l2m).all()
+    close(l2m.cpu(), rl, 1e-5, "teacher per-patch l2 with unwritten visible patches")
+
+
 def test_mask_sampler_golden_and_invariants(ops):
     f = load("forward_tiny.npz")
     cfg = tiny_cfg(f)
