@@ -1433,31 +1433,40 @@ __global__ __launch_bounds__(256) void partials_finalize_kernel(const float* __r
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                 float* mean, float* rstd, float* scale, float* shift, float* run_mean,
                                                                 float* run_var, float momentum, long* nbt, float* sum_accum) {
-  __shared__ double sh1[256], sh2[256];
+  // The rows are a real stream (a 128^3 conv at batch 16 leaves 131 072 rows x 64 channels x 8 B = 67 MB): up to 2048 workgroups, a
+  // thread reads 16 bytes = (sum, sumsq) of TWO channels per row, four rows in flight, and the per-workgroup sums go to one of
+  // AM_FIN_REP replicas (two thousand workgroups adding into the same cache lines serialise in L2).  The first version (256
+  // workgroups, one 8-byte load in flight per thread, one accumulator row) ran at 0.3 TB/s: 133 us per call, 4.9 ms per step.
+  __shared__ double sh[256][4];
   __shared__ unsigned ticket_s;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, CP = C >> 1;                      // channel pairs
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  const float2* __restrict__ p2 = (const float2*)part;
-  double* sums = ws;                                           // [C][2]
-  unsigned* ticket = (unsigned*)(ws + 2 * (size_t)C);
-  if (C <= 256) {
-    const int rstep = 256 / C;
-    double s1 = 0.0, s2 = 0.0;
-    if (t < rstep * C) {
-      const int c = t % C;
-      for (int r = r0 + t / C; r < r1; r += rstep) { const float2 v = p2[(size_t)r * C + c]; s1 += v.x; s2 += v.y; }
+  const f32x4* __restrict__ p4 = (const f32x4*)part;
+  double* sums = ws + (size_t)(blockIdx.x % AM_FIN_REP) * 2 * C;   // this workgroup's replica [C][2]
+  unsigned* ticket = (unsigned*)(ws + (size_t)AM_FIN_REP * 2 * C);
+  const int rstep = CP <= 256 ? 256 / CP : 1;
+  for (int cp0 = 0; cp0 < CP; cp0 += 256) {                    // (one pass unless C > 512)
+    const int cp = cp0 + (CP <= 256 ? t % CP : t), lane_r = CP <= 256 ? t / CP : 0;
+    const bool live = cp < CP && lane_r < rstep;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (live) {
+      int r = r0 + lane_r;
+      for (; r + 3 * rstep < r1; r += 4 * rstep) {
+        const f32x4 v0 = p4[(size_t)r * CP + cp], v1 = p4[(size_t)(r + rstep) * CP + cp], v2 = p4[(size_t)(r + 2 * rstep) * CP + cp],
+                    v3 = p4[(size_t)(r + 3 * rstep) * CP + cp];
+        a0 += (double)v0[0] + (double)v1[0] + (double)v2[0] + (double)v3[0];
+        a1 += (double)v0[1] + (double)v1[1] + (double)v2[1] + (double)v3[1];
+        a2 += (double)v0[2] + (double)v1[2] + (double)v2[2] + (double)v3[2];
+        a3 += (double)v0[3] + (double)v1[3] + (double)v2[3] + (double)v3[3];
+      }
+      for (; r < r1; r += rstep) { const f32x4 v = p4[(size_t)r * CP + cp]; a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3]; }
     }
-    sh1[t] = s1; sh2[t] = s2;
     __syncthreads();
-    if (t < C) {
-      for (int k = 1; k < rstep; ++k) { s1 += sh1[k * C + t]; s2 += sh2[k * C + t]; }
-      atomicAdd(&sums[2 * t], s1); atomicAdd(&sums[2 * t + 1], s2);
-    }
-  } else {
-    for (int c = t; c < C; c += 256) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int r = r0; r < r1; ++r) { const float2 v = p2[(size_t)r * C + c]; s1 += v.x; s2 += v.y; }
-      atomicAdd(&sums[2 * c], s1); atomicAdd(&sums[2 * c + 1], s2);
+    sh[t][0] = a0; sh[t][1] = a1; sh[t][2] = a2; sh[t][3] = a3;
+    __syncthreads();
+    if (live && lane_r == 0) {
+      for (int k = 1; k < rstep; ++k) { a0 += sh[k * CP + t][0]; a1 += sh[k * CP + t][1]; a2 += sh[k * CP + t][2]; a3 += sh[k * CP + t][3]; }
+      atomicAdd(&sums[4 * cp], a0); atomicAdd(&sums[4 * cp + 1], a1); atomicAdd(&sums[4 * cp + 2], a2); atomicAdd(&sums[4 * cp + 3], a3);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the sums are memory-side atomics: acknowledged is visible
@@ -1468,8 +1477,11 @@ __global__ __launch_bounds__(256) void partials_finalize_kernel(const float* __r
   // ---- last workgroup: finalize
   const double n = count_ptr ? count_ptr[0] : count_host;
   for (int c = t; c < C; c += 256) {
-    const double q1 = __longlong_as_double(atomicExch((unsigned long long*)&sums[2 * c], 0ull));       // read + re-zero at the memory side
-    const double q2 = __longlong_as_double(atomicExch((unsigned long long*)&sums[2 * c + 1], 0ull));
+    double q1 = 0.0, q2 = 0.0;
+    for (int r = 0; r < AM_FIN_REP; ++r) {                     // read + re-zero at the memory side, fixed order
+      q1 += __longlong_as_double(atomicExch((unsigned long long*)&ws[(size_t)r * 2 * C + 2 * c], 0ull));
+      q2 += __longlong_as_double(atomicExch((unsigned long long*)&ws[(size_t)r * 2 * C + 2 * c + 1], 0ull));
+    }
     if (sum_accum) sum_accum[c] += (float)q1;
     if (!gamma) continue;
     const double m = q1 / n;
@@ -1872,8 +1884,9 @@ int am_partials_finalize(const float* partials, int rows, int C, double* workspa
                          float* run_mean, float* run_var, float momentum, long* num_batches_tracked, float* sum_accum, void* stream) {
   if (C <= 0 || C > 4096 || rows <= 0 || !workspace) return -1;
   if (gamma && (!beta || !mean || !rstd || !scale || !shift)) return -1;
-  const int rstep = C <= 256 ? 256 / C : 1;
-  int nb = rows / (rstep * 16); nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  if (C % 2) return -1;
+  const int cp = C / 2, rstep = cp <= 256 ? 256 / cp : 1;
+  int nb = rows / (rstep * 8); nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
   const int rpb = ((rows + nb - 1) / nb + rstep - 1) / rstep * rstep;
   nb = (rows + rpb - 1) / rpb;
   AM_LAUNCH(partials_finalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, partials, rows, C, rpb, workspace, count_ptr, count_host,

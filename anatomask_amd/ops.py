@@ -110,12 +110,15 @@ class ConvPartials:
 _WS = {}
 
 
+FIN_REP = 16   # AM_FIN_REP
+
+
 def _stats_workspace(device, C: int) -> torch.Tensor:
     """zero-initialised scratch of am_partials_finalize (left zero by every call), one per (device, stream)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
-    if ws is None or ws.numel() < 2 * C + 2:
-        ws = _WS[key] = torch.zeros(2 * max(C, 2048) + 2, device=device, dtype=torch.float64)
+    if ws is None or ws.numel() < FIN_REP * 2 * C + 2:
+        ws = _WS[key] = torch.zeros(FIN_REP * 2 * max(C, 2048) + 2, device=device, dtype=torch.float64)
     return ws
 
 

@@ -121,8 +121,10 @@ int am_norm_finalize(const double* sums, int nrep /* AM_NREP after am_chan_stats
                      float* run_mean /* NULL or BN running stats, updated */, float* run_var, float momentum, void* stream);
 /* The statistics plumbing of one norm in ONE launch: conv partials [rows][C][2] -> per-channel sums -> (last workgroup) mean /
  * rstd / folded scale+shift, BatchNorm running-stat update and num_batches_tracked += 1 (nn.BatchNorm3d in train mode,
- * P/decoder3D.py:21-22).  gamma == NULL: only sum_accum[c] += sum (a bias gradient).  workspace: 2*C + 1 doubles that are ZERO on
- * entry and are left ZERO on exit (allocate once, zero once, share between consecutive calls on one stream). */
+ * P/decoder3D.py:21-22).  gamma == NULL: only sum_accum[c] += sum (a bias gradient).  workspace: AM_FIN_REP*2*C + 1 doubles
+ * (replicated accumulators + a ticket) that are ZERO on entry and are left ZERO on exit (allocate once, zero once, share between
+ * consecutive calls on one stream). */
+#define AM_FIN_REP 16
 int am_partials_finalize(const float* partials, int rows, int C, double* workspace, const double* count_ptr, double count_host,
                          const float* gamma, const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                          float* run_mean, float* run_var, float momentum, long* num_batches_tracked, float* sum_accum, void* stream);
