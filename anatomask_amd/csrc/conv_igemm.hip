@@ -325,8 +325,8 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
       }
     }
   }
-  if (part) {                                            // per-workgroup per-channel partials (no atomics, deterministic)
-    __syncthreads();
+  if (part && !AM_DBG(a, 512)) {                         // per-workgroup per-channel partials (no atomics, deterministic)
+    if (!AM_DBG(a, 1024)) __syncthreads();
     float* red = (float*)lds;                            // [4 waves][16*NS couts][2]
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -335,13 +335,13 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
         float s1 = 0.f, s2 = 0.f;                        // sums over this lane's VS voxels of the STORED values
 #pragma unroll
         for (int j = 0; j < VS; ++j) { const float o = acc[i][j][r]; s1 += o; s2 += o * o; }
-        s1 = row16_sum(s1); s2 = row16_sum(s2);
+        if (!AM_DBG(a, 2048)) { s1 = row16_sum(s1); s2 = row16_sum(s2); }
         if (r16 == 0) {
           const int c = (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r;
           red[(wave * 16 * NS + c) * 2] = s1; red[(wave * 16 * NS + c) * 2 + 1] = s2;
         }
       }
-    __syncthreads();
+    if (!AM_DBG(a, 1024)) __syncthreads();
     if (tid < 16 * NS && co0 + tid < a.Cout) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll

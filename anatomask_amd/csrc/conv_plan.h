@@ -27,7 +27,7 @@ struct ConvArgs {
   int hreuse;                 // taps ordered in h-runs of 3 (see build_plan): the HR kernel variant shares fragment rows across a run
   int nt_store;               // non-temporal output stores (outputs far larger than the 256 MB Infinity Cache)
 #ifdef AM_ABLATE
-  int dbg;                    // tools-only build (-DAM_ABLATE): AM_CV_DBG ablation bits, 1 no stores, 2 no source loads, 4 no weight loads, 64 a third of the weight-fragment LDS reads skipped
+  int dbg;                    // tools-only build (-DAM_ABLATE): AM_CV_DBG ablation bits, 1 no stores, 2 no source loads, 4 no weight loads, 64 a third of the weight-fragment LDS reads skipped, 512 no statistics epilogue, 1024 its barriers off, 2048 its DPP reductions off
 #endif
 };
 

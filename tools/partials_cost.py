@@ -6,6 +6,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from anatomask_amd import build as _build  # noqa: E402
+if os.environ.get("AM_PC_ABLATE"):
+    os.environ["AM_HIP_LIB"] = _build.build(verbose=False, ablate=True)
 from anatomask_amd import ops  # noqa: E402
 
 dev = "cuda:0"
@@ -26,6 +29,11 @@ def timed(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
+for dbg in [int(v) for v in os.environ.get("AM_PC_ABLATE", "0").split(",")]:
+    os.environ["AM_CV_DBG"] = str(dbg)
+    t = timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (S, S, S), 3, 1, out=y, want_partials=True))
+    print(f"AM_CV_DBG={dbg}: with partials {t:.3f} ms {fl / t / 1e9:.0f} TF", flush=True)
+os.environ["AM_CV_DBG"] = "0"
 for rep in range(3):
     a = timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (S, S, S), 3, 1, out=y))
     b = timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (S, S, S), 3, 1, out=y, want_partials=True))
