@@ -420,12 +420,20 @@ class SparK(nn.Module):
             self.densify_projs.append(proj)
             d_width //= 2
         cnn = sparse_encoder.sp_cnn
-        self.spec = Spec(cnn.dims, cnn.depth, dense_decoder.width, tuple(input_size), sync_bn=bool(getattr(dense_decoder, "sbn", False)))
         self.compute_dtype = compute_dtype
-        import weakref                       # sub-modules called on their own (model.sparse_encoder(x), model.dense_decoder(to_dec))
-        cnn.__dict__["_owner"] = dense_decoder.__dict__["_owner"] = weakref.ref(self)   # run on THIS model's flat buffers
         self._flat: Optional[torch.Tensor] = None
         self._after_group = None
+        # Any encoder other than this package's STUNet (a dense backbone rewritten by the sparse layer zoo, SparseEncoder.__init__) runs
+        # the GENERIC composition of P/AnatoMask.py:137-188 -- zoo encoder -> densify (pooled norm, mask tokens, projections) ->
+        # LightDecoder -- under torch autograd; the fused engine / trainer below are STUNet-only.
+        self._generic = not isinstance(cnn, STUNet)
+        if self._generic:
+            self.dense_decoder.compute_dtype = compute_dtype
+            self._dead = set()
+            return
+        self.spec = Spec(cnn.dims, cnn.depth, dense_decoder.width, tuple(input_size), sync_bn=bool(getattr(dense_decoder, "sbn", False)))
+        import weakref                       # sub-modules called on their own (model.sparse_encoder(x), model.dense_decoder(to_dec))
+        cnn.__dict__["_owner"] = dense_decoder.__dict__["_owner"] = weakref.ref(self)   # run on THIS model's flat buffers
         n_dec = len(self.spec.dec_chs) - 1
         self._dead = {f"{k}.{i}{sfx}" for i in range(n_dec, self.hierarchy) for k, sfx in
                       (("densify_norms", ".weight"), ("densify_norms", ".bias"), ("densify_projs", ".weight"),
@@ -435,6 +443,8 @@ class SparK(nn.Module):
     def _ensure_flat(self):
         """(Re)bind every parameter to a view of ONE flat fp32 buffer [live | dead], gradients likewise,
         BN running stats to a second one: the optimizer / EMA / all-reduce kernels stream over these."""
+        if self._generic:
+            raise RuntimeError("the flat-buffer engine path (fused trainer, STUNet sub-module forwards) needs this package's STUNet encoder")
         named = list(self.named_parameters())
         dev = named[0][1].device
         if dev.type != "cuda":
@@ -482,8 +492,37 @@ class SparK(nn.Module):
 
     def weights_changed(self):
         """Tell the model its fp32 master weights were modified (optimizer step / load): drops packed copies."""
+        if self._generic:
+            sa = self.dense_decoder.__dict__.get("_sa")
+            if sa is not None:
+                sa.pack.invalidate()
+            return
         if self._flat is not None:
             self._pack.invalidate()
+
+    def _forward_generic(self, inp_bchwd: torch.Tensor, active_b1ff: torch.Tensor):
+        """P/AnatoMask.py:144-170 for a zoo-converted encoder: rec volume (B,1,H,W,D), autograd through the zoo's Functions, the pooled
+        norm of the engine (am_chan_stats / am_norm_*), the matrix-core convs and LightDecoder's engine node."""
+        from . import sparse_layers as SL
+        p = self.downsample_ratio
+        act = active_b1ff.to(inp_bchwd.device)
+        act_ex = act.repeat_interleave(p, 2).repeat_interleave(p, 3).repeat_interleave(p, 4)
+        SL.COMPUTE_DTYPE = self.compute_dtype
+        fea = list(self.sparse_encoder(inp_bchwd * act_ex))          # fine -> coarse
+        fea.reverse()
+        cur = act
+        to_dec = []
+        for i, f in enumerate(fea):
+            if f is not None and i < len(self.dense_decoder.dec):    # (levels past the decoder's blocks are never read, :170 + decoder3D.py:56-60)
+                n_ = self.densify_norms[i]
+                f = SL._nc(SL._SparseBNFn.apply(SL._cl(f), n_.weight, n_.bias, None, None, None, True, 0.0, n_.eps, False))   # pooled sparse IN
+                f = torch.where(cur.expand_as(f), f, self.mask_tokens[i].to(f.dtype).expand_as(f))
+                pr = self.densify_projs[i]
+                if not isinstance(pr, nn.Identity):
+                    f = SL.dense_conv(f, pr.weight, pr.bias, pr.kernel_size[0])
+                to_dec.append(f)
+            cur = cur.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
+        return self.dense_decoder(to_dec)
 
     # ---------------------------------------------------------------- masks
     def mask(self, B: int, device, generator=None):
@@ -524,7 +563,12 @@ class SparK(nn.Module):
             active_b1ff = self.mask(inp_bchwd.shape[0], inp_bchwd.device)
         global _cur_active
         _cur_active = active_b1ff                                  # P/AnatoMask.py:143 (kept for code that reads the side channel)
-        rec_bchwd = self.reconstruct(inp_bchwd, active_b1ff)
+        if self._generic:
+            if return_feat:
+                raise NotImplementedError("return_feat with a non-STUNet encoder")
+            rec_bchwd = self._forward_generic(inp_bchwd, active_b1ff)
+        else:
+            rec_bchwd = self.reconstruct(inp_bchwd, active_b1ff)
         inp, rec = self.patchify(inp_bchwd), self.patchify(rec_bchwd)
         if return_feat:                                            # P/AnatoMask.py:172-173: to_dec[0].flatten(2).permute(0, 2, 1)
             d0 = self._last_dec0                                   # (no caller of the reference differentiates through it)

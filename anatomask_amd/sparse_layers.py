@@ -457,6 +457,17 @@ class _ConvFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def dense_conv(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], k: int) -> torch.Tensor:
+    """plain dense k in {1, 3} stride-1 convolution of an NCDHW tensor on the matrix cores (SparK's densify projections,
+    P/AnatoMask.py:63-65): the patch mask of the side channel is ignored."""
+    saved = _M._cur_active
+    _M._cur_active = None
+    try:
+        return _nc(_ConvFn.apply(_cl(x), weight, bias, k, 1))
+    finally:
+        _M._cur_active = saved
+
+
 class SparseConv3d(nn.Conv3d):
     """encoder3D.py:27-28 (sp_conv_forward :12-15): Conv3d, output masked.  Supported: 'same' padding k//2, dilation 1, zero padding;
     groups == 1 with k in {1, 3}, stride in {1, 2} (matrix cores); depthwise (groups == in == out) with k in {3, 5, 7}, stride 1 or 2;

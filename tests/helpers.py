@@ -136,3 +136,25 @@ def tiny_mednext(n_channels=8, exp_r=2, k=3):
             return maps if hierarchical else maps[-1]
 
     return Net()
+
+
+def seeded_params(model):
+    """Overwrite every parameter of `model` with a draw that depends only on its NAME and shape (legacy RandomState, stable across
+    numpy versions): convolution / linear weights ~ N(0, 1 / fan_in), transposed-conv weights ~ N(0, 1 / (Cout * k^3 / 8)), norm
+    weights 1 + 0.1 N, biases 0.1 N, mask tokens 0.02 N.  The reference side (tests/golden/make_spark_mednext_fixture.py) and the
+    GPU test both call it, so no weights are stored."""
+    import zlib
+    import torch
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if "dummy" in n:
+                continue
+            r = torch.from_numpy(np.random.RandomState(zlib.crc32(n.encode()) & 0x7fffffff).standard_normal(tuple(p.shape)).astype(np.float32))
+            if "mask_tokens" in n:
+                p.copy_(0.02 * r)
+            elif p.dim() == 1:
+                p.copy_((1.0 if n.endswith("weight") else 0.0) + 0.1 * r)
+            elif "up_sample" in n:                       # ConvTranspose3d (Cin, Cout, 4, 4, 4): 8 of its 64 taps reach an output voxel
+                p.copy_(r / float(np.sqrt(p.shape[0] * 8)))
+            else:
+                p.copy_(r / float(np.sqrt(p[0].numel())))
