@@ -240,13 +240,13 @@ __device__ __forceinline__ void bwd_reduce_tail(double* bsum, int C, const BwdFi
 }
 
 // dxsum replicas [nrep][C] -> accum[c] += sum, replicas re-zeroed
-__device__ __forceinline__ void dxsum_tail(float* rep, int nrep, int C, float* accum, unsigned* ticket) {
+__device__ __forceinline__ void dxsum_tail(double* rep, int nrep, int C, float* accum, unsigned* ticket) {
   if (!ticket) return;
   if (!last_workgroup(ticket)) return;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s_ = 0.f;
-    for (int r = 0; r < nrep; ++r) s_ += __uint_as_float(atomicExch((unsigned*)&rep[(size_t)r * C + c], 0u));
-    accum[c] += s_;
+    double s_ = 0.0;
+    for (int r = 0; r < nrep; ++r) s_ += __longlong_as_double(atomicExch((unsigned long long*)&rep[(size_t)r * C + c], 0ull));
+    accum[c] += (float)s_;
   }
   if (threadIdx.x == 0) atomicExch(ticket, 0u);
 }
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ k0,
                                                              const float* __restrict__ k1, const float* __restrict__ k2, int act,
-                                                             T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum,
+                                                             T* __restrict__ dx, T* __restrict__ dres, double* __restrict__ dxsum,
                                                              int dxrep, const float* __restrict__ psc, const float* __restrict__ psh,
                                                              float* __restrict__ dx_accum, unsigned* dx_ticket) {
   constexpr int EPC = TT<T>::EPC;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
 #pragma unroll
         for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], a1[i]);
+      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], (double)a1[i]);   // fp64: the arrival order shows at 1e-16
     }
     dxsum_tail(dxsum, dxrep, g.C, dx_accum, dx_ticket);
   }
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
                                                                   const T* __restrict__ x, RowGeo g, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ k0,
                                                                   const float* __restrict__ k1, const float* __restrict__ k2, int act,
-                                                                  T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ dxsum,
+                                                                  T* __restrict__ dx, T* __restrict__ dres, double* __restrict__ dxsum,
                                                                   int dxrep, const float* __restrict__ psc, const float* __restrict__ psh,
                                                                   float* __restrict__ dx_accum, unsigned* dx_ticket) {
   constexpr int EPC = TT<T>::EPC;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
 #pragma unroll
         for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], a1[i]);
+      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], (double)a1[i]);   // fp64: the arrival order shows at 1e-16
     }
     dxsum_tail(dxsum, dxrep, g.C, dx_accum, dx_ticket);
   }
@@ -1042,7 +1042,7 @@ __device__ __forceinline__ s16x4 tr_read16(const unsigned char* p) {
 template <int NS, int K>
 __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, int D, int H, int W,
                                                               MaskView mask, const int* __restrict__ plist, int n_active,
-                                                              float* __restrict__ dw, float* __restrict__ db) {
+                                                              float* __restrict__ dw, float* __restrict__ db, float* __restrict__ det_ws) {
   constexpr int E = 18, C = 16 * NS, RS = 2 * C + 32;           // dy rows: C bf16 + 32 B pad (conflict-free transposing reads)
   constexpr int NTT = K == 3 ? 2 : 1, NTAP = K * K * K;
   constexpr int XB = (E * E * E + 8) * 2;                        // bytes of the x patch (multiple of 16)
@@ -1138,9 +1138,22 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
     float v = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 4; ++wv) v += red[(wv * C + c) * (16 * NTT) + t];
-    if (t < NTAP) atomicAdd(&dw[c * NTAP + t], v);
+    if (det_ws) det_ws[(size_t)blockIdx.x * (C * (NTAP + 1)) + i] = v;      // deterministic mode: one row per workgroup, folded in order afterwards
+    else if (t < NTAP) atomicAdd(&dw[c * NTAP + t], v);
     else if (db) atomicAdd(&db[c], v);
   }
+}
+
+// deterministic mode of the stem weight gradient: rows [nwg][C * (NTAP + 1)] of per-workgroup sums -> dw / db, in workgroup order
+__global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const float* __restrict__ ws, int nwg, int C, int ntap, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * (ntap + 1)) return;
+  float s = 0.f;
+  for (int r = 0; r < nwg; ++r) s += ws[(size_t)r * C * (ntap + 1) + i];
+  const int c = i / (ntap + 1), t = i % (ntap + 1);
+  if (t < ntap) dw[c * ntap + t] += s;
+  else if (db) db[c] += s;
 }
 
 // dW[c][t] += sum_v dy[v][c] * xm[v+t-pad];  db[c] += sum_v dy[v][c]     (same brick staging; 9 taps at a time in registers).
@@ -1248,7 +1261,7 @@ __global__ __launch_bounds__(256) void proj_fwd_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, const float* __restrict__ drec, long nvox, int C, int vpw,
                                                        const float* __restrict__ w, T* __restrict__ dx, float* __restrict__ dw,
-                                                       float* __restrict__ db) {
+                                                       float* __restrict__ db, float* __restrict__ det_ws) {
   constexpr int EPC = TT<T>::EPC;
   __shared__ float red[256 * 8];
   __shared__ float redb[4];
@@ -1281,9 +1294,25 @@ __global__ __launch_bounds__(256) void proj_bwd_kernel(const T* __restrict__ x, 
 #pragma unroll
       for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
 #pragma unroll
-    for (int i = 0; i < EPC; ++i) atomicAdd(&dw[threadIdx.x * EPC + i], a1[i]);
+    for (int i = 0; i < EPC; ++i) {
+      if (det_ws) det_ws[(size_t)blockIdx.x * (C + 1) + threadIdx.x * EPC + i] = a1[i];    // deterministic mode: a row per workgroup, folded in order
+      else atomicAdd(&dw[threadIdx.x * EPC + i], a1[i]);
+    }
   }
-  if (threadIdx.x == 0) atomicAdd(db, redb[0] + redb[1] + redb[2] + redb[3]);
+  if (threadIdx.x == 0) {
+    const float sbt = redb[0] + redb[1] + redb[2] + redb[3];
+    if (det_ws) det_ws[(size_t)blockIdx.x * (C + 1) + C] = sbt; else atomicAdd(db, sbt);
+  }
+}
+
+// rows [nrow][n] of per-workgroup sums -> dst0[0..n0) += column sums (in row order), dst1[0..n-n0) likewise
+__global__ __launch_bounds__(256) void rows_fold_kernel(const float* __restrict__ ws, int nrow, int n, int n0, float* __restrict__ dst0,
+                                                        float* __restrict__ dst1) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int r = 0; r < nrow; ++r) s += ws[(size_t)r * n + i];
+  if (i < n0) dst0[i] += s; else if (dst1) dst1[i - n0] += s;
 }
 
 // ------------------------------------------------------------------ weight (un)packing
@@ -1363,12 +1392,12 @@ __global__ void unpack_grad_kernel(const float* __restrict__ src, float* __restr
 }
 
 // dst[c] += sum over the replicas rep[r][c]
-__global__ __launch_bounds__(256) void rep_reduce_kernel(const float* __restrict__ rep, int nrep, int C, float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void rep_reduce_kernel(const double* __restrict__ rep, int nrep, int C, float* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float s = 0.f;
+  double s = 0.0;
   for (int r = 0; r < nrep; ++r) s += rep[(size_t)r * C + c];
-  dst[c] += s;
+  dst[c] += (float)s;
 }
 
 // per-workgroup conv partials [rows][C][2] -> sums[C][2] (double) and/or sum_accum[C] += sum
@@ -1703,7 +1732,7 @@ int am_norm_bwd_finalize(const double* bsum, const double* count_ptr, double cou
 int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* x, int B, int D, int H, int W, int C,
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres, float* dxsum_accum,
-                      float* dxsum_scratch, const float* pre_scale, const float* pre_shift, const int32_t* active_list, int n_active,
+                      double* dxsum_scratch, const float* pre_scale, const float* pre_shift, const int32_t* active_list, int n_active,
                       int scratch_is_zero_workspace, void* stream) {
   CHK_C(C);
   if (!out && act != AM_ACT_NONE && (!pre_scale || !pre_shift)) return -1;
@@ -1716,15 +1745,16 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
   const int nb = rows ? rows_blocks(rg) : nblk((long)B * D * H * W, g.vpw);
   // bias-gradient sums: every workgroup adds C floats; on ONE accumulator 2048 workgroups serialise (measured 400 us on an
   // 8 MB tensor), so they go to AM_DXREP replicas that a 1-block kernel folds afterwards
-  const bool rep = dxsum_accum && dxsum_scratch;
-  float* dxs = rep ? dxsum_scratch : dxsum_accum;
-  const int nrep = rep ? AM_DXREP : 1;
+  if (dxsum_accum && !dxsum_scratch) return -1;              // the bias-gradient sums always go through the fp64 replicas
+  const bool rep = dxsum_accum != nullptr;
+  double* dxs = rep ? dxsum_scratch : nullptr;
+  const int nrep = AM_DXREP;
   // scratch_is_zero_workspace: [AM_DXREP][C] floats + one ticket word, zero on entry and left zero: the last workgroup folds the
   // replicas into dxsum_accum itself (no memset launch before, no fold launch after)
   const bool fused = rep && scratch_is_zero_workspace;
   float* dx_accum = fused ? dxsum_accum : nullptr;
   unsigned* dx_ticket = fused ? (unsigned*)(dxsum_scratch + (size_t)AM_DXREP * C) : nullptr;
-  if (rep && !fused) hipMemsetAsync(dxsum_scratch, 0, sizeof(float) * AM_DXREP * C, st);
+  if (rep && !fused) hipMemsetAsync(dxsum_scratch, 0, sizeof(double) * AM_DXREP * C, st);
   if (rows) {
     DISPATCH_T(dtype,
                AM_LAUNCH(norm_bwd_apply_rows_kernel<float>, dim3(nb), dim3(rows_threads(rg)), 0, st, (const float*)dout, (const float*)out,
@@ -1803,7 +1833,7 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
 
 int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum,
-                       const int32_t* active_list, int n_active, void* stream) {
+                       const int32_t* active_list, int n_active, float* det_workspace, long det_workspace_floats, void* stream) {
   CHK_C(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
@@ -1812,19 +1842,28 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
   if (!mask || bshift != 4 || D % 16 || H % 16 || W % 16) return -2;
   if (dtype == AM_DT_BF16 && active_list && n_active > 0 && (C == 32 || C == 64 || C == 96) && B <= 255 && fd <= 255 && fh <= 255 && fw <= 255) {
     const MaskView mv{mask, fd, fh, fw, bshift};
-    const int nwg = n_active < 1024 ? n_active : 1024;          // persistent: four workgroups per CU, one atomic flush each
+    int nwg = n_active < 1024 ? n_active : 1024;                // persistent: four workgroups per CU, one atomic flush each
+    const long det_row = (long)C * (ksize * ksize * ksize + 1);
+    if (det_workspace) {                                        // deterministic mode: as many workgroups as the workspace has rows for
+        if (det_workspace_floats < det_row) return -6;
+        if (nwg > det_workspace_floats / det_row) nwg = (int)(det_workspace_floats / det_row);
+    }
     const size_t sm = (size_t)(18 * 18 * 18 + 8) * 2 + (size_t)256 * (2 * C + 32);
 #define AM_STEM_WG(NS_, K_)                                                                                                           \
     {                                                                                                                                 \
       auto kern = stem_wgrad_mfma_kernel<NS_, K_>;                                                                                    \
       static std::once_flag cap;                                                                                                      \
       std::call_once(cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); }); \
-      AM_LAUNCH(kern, dim3(nwg), dim3(256), sm, st, x, (const bf16_t*)dy, D, H, W, mv, active_list, n_active, dw_accum, db_accum);     \
+      AM_LAUNCH(kern, dim3(nwg), dim3(256), sm, st, x, (const bf16_t*)dy, D, H, W, mv, active_list, n_active, dw_accum, db_accum, det_workspace);     \
     }
     if (ksize == 3) { if (C == 32) AM_STEM_WG(2, 3) else if (C == 64) AM_STEM_WG(4, 3) else AM_STEM_WG(6, 3) }
     else { if (C == 32) AM_STEM_WG(2, 1) else if (C == 64) AM_STEM_WG(4, 1) else AM_STEM_WG(6, 1) }
 #undef AM_STEM_WG
     AM_CHECK_LAUNCH();
+    if (det_workspace) {
+      AM_LAUNCH(stem_wgrad_fold_kernel, dim3((unsigned)((det_row + 255) / 256)), dim3(256), 0, st, det_workspace, nwg, C, ksize * ksize * ksize, dw_accum, db_accum);
+      AM_CHECK_LAUNCH();
+    }
     return 0;
   }
   if (geo_bad) return -4;
@@ -1850,14 +1889,19 @@ int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, cons
 }
 
 int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, void* dx, float* dw_accum,
-                float* db_accum, void* stream) {
+                float* db_accum, float* det_workspace, long det_workspace_floats, void* stream) {
   CHK_C(C);
   hipStream_t st = (hipStream_t)stream;
   const int vpw = pick_vpw(nvox, C, dtype, true);
   const int nb = nblk(nvox, vpw);
-  DISPATCH_T(dtype, AM_LAUNCH(proj_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, drec, nvox, C, vpw, w, (float*)dx, dw_accum, db_accum),
-             AM_LAUNCH(proj_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, vpw, w, (bf16_t*)dx, dw_accum, db_accum));
+  if (det_workspace && det_workspace_floats < (long)nb * (C + 1)) return -6;
+  DISPATCH_T(dtype, AM_LAUNCH(proj_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, drec, nvox, C, vpw, w, (float*)dx, dw_accum, db_accum, det_workspace),
+             AM_LAUNCH(proj_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, vpw, w, (bf16_t*)dx, dw_accum, db_accum, det_workspace));
   AM_CHECK_LAUNCH();
+  if (det_workspace) {
+    AM_LAUNCH(rows_fold_kernel, dim3((C + 1 + 255) / 256), dim3(256), 0, st, det_workspace, nb, C + 1, C, dw_accum, db_accum);
+    AM_CHECK_LAUNCH();
+  }
   return 0;
 }
 

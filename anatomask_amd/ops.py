@@ -268,8 +268,9 @@ def stem_conv_wgrad(x_b1: torch.Tensor, dy: torch.Tensor, ksize: int, mask: Opti
                     dw_accum: torch.Tensor, db_accum: Optional[torch.Tensor]):
     B, D, H, W, Cc = dy.shape
     mp, fd, fh, fw = _mk(mask)
+    ws = _det_workspace(dy.device, 1024 * Cc * (ksize ** 3 + 1) // 8) if (DETERMINISTIC_WGRAD and dy.dtype == torch.bfloat16) else None
     hip.lib().stem_conv_wgrad(_dt(dy), x_b1.data_ptr(), dy.data_ptr(), B, D, H, W, Cc, ksize, mp, bshift, fd, fh, fw,
-                              dw_accum.data_ptr(), _p(db_accum), *_al(mask), _stream())
+                              dw_accum.data_ptr(), _p(db_accum), *_al(mask), _p(ws), ws.numel() if ws is not None else 0, _stream())
 
 
 # ------------------------------------------------------------------ norms
@@ -400,7 +401,7 @@ def _bwd_workspaces(device, C: int):
     if ws is None or ws[2] < C:
         cap = max(C, 2048)
         ws = _BWS[key] = (torch.zeros(NREP * cap * 3 + 2, device=device, dtype=torch.float64),
-                          torch.zeros(DXREP * cap + 2, device=device, dtype=torch.float32), cap)
+                          torch.zeros(DXREP * cap + 2, device=device, dtype=torch.float64), cap)
     return ws[0], ws[1]
 
 
@@ -428,8 +429,9 @@ def proj_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 def proj_bwd(x: torch.Tensor, drec: torch.Tensor, w: torch.Tensor, dw_accum: torch.Tensor, db_accum: torch.Tensor) -> torch.Tensor:
     B, D, H, W, Cc = x.shape
     dx = torch.empty_like(x)
+    ws = _det_workspace(x.device, 4096 * (Cc + 1) // 8) if DETERMINISTIC_WGRAD else None
     hip.lib().proj_bwd(_dt(x), x.data_ptr(), drec.data_ptr(), B * D * H * W, Cc, w.data_ptr(), dx.data_ptr(), dw_accum.data_ptr(),
-                       db_accum.data_ptr(), _stream())
+                       db_accum.data_ptr(), _p(ws), ws.numel() if ws is not None else 0, _stream())
     return dx
 
 

@@ -102,7 +102,10 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
 int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum,
                        const int32_t* active_list, int n_active /* am_mask_compact: bf16 stems then contract voxels on the matrix
-                       cores (persistent workgroups over the active patches); NULL / 0: the VALU kernel */, void* stream);
+                       cores (persistent workgroups over the active patches); NULL / 0: the VALU kernel */,
+                       float* det_workspace, long det_workspace_floats /* NULL / 0, or (matrix-core path only) rows of C * (k^3 + 1) floats:
+                       one per workgroup, folded in workgroup order instead of fp32 atomics (deterministic mode, as am_conv3d_wgrad) */,
+                       void* stream);
 
 /* Pooled sparse InstanceNorm (P/encoder3D.py:138-165: statistics over ALL active voxels of the local
  * batch) and BatchNorm3d (P/decoder3D.py:21-22) share these: stats -> finalize -> apply. */
@@ -155,10 +158,11 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
                       const uint8_t* mask, int bshift, int fd, int fh, int fw, const float* mean, const float* rstd,
                       const float* k0, const float* k1, const float* k2, int act, void* dx, void* dres,
                       float* dxsum_accum /* NULL or += per-channel sum of dx: bias gradient of the conv feeding the norm */,
-                      float* dxsum_scratch /* [AM_DXREP][C] workspace when dxsum_accum != NULL (NULL: direct atomics) */,
+                      double* dxsum_scratch /* [AM_DXREP][C] fp64 workspace, required when dxsum_accum != NULL: the per-workgroup sums are added in
+                      double so that their arrival order shows at 1e-16, not in the fp32 result */,
                       const float* pre_scale, const float* pre_shift /* as in am_norm_bwd_reduce */,
                       const int32_t* active_list, int n_active,
-                      int scratch_is_zero_workspace /* 1: dxsum_scratch = AM_DXREP*C floats + 1, zero on entry / left zero; the fold into
+                      int scratch_is_zero_workspace /* 1: dxsum_scratch = AM_DXREP*C doubles + 1, zero on entry / left zero; the fold into
                       dxsum_accum happens in the last workgroup of this launch */, void* stream);
 int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, const uint8_t* mask, int bshift, int fd, int fh,
                 int fw, float* out_accum, void* stream);   /* conv bias gradients */
@@ -167,7 +171,8 @@ int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void*
 /* 1x1 projection C -> 1 (P/decoder3D.py:51,61) and its backward. rec/drec are fp32 [B][D][H][W]. */
 int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b, float* rec, void* stream);
 int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, void* dx, float* dw_accum,
-                float* db_accum, void* stream);
+                float* db_accum, float* det_workspace, long det_workspace_floats /* NULL / 0, or >= 1024 * (C + 1) floats: per-workgroup rows folded in order
+                instead of fp32 atomics (deterministic mode) */, void* stream);
 
 /* Per-patch reconstruction loss without materialising patchify (P/AnatoMask.py:190-202,221-228;
  * teacher variant normalized=0: P/pretrain_AntoMask.py:423-425).  l2m = per-patch MSE * non_active (B*L);

@@ -732,8 +732,37 @@ def test_graphed_step_replays_the_eager_step():
         assert abs(float(ob["loss"]) - float(oa["loss"])) <= 2e-3 * abs(float(oa["loss"])) + 2 * abs(float(oc["loss"]) - float(oa["loss"]))
         ua, ub, uc = a.model._flat[:n] - pa, b.model._flat[:n] - pb, c.model._flat[:n] - pc
         assert abs(ub.norm().item() / ua.norm().item() - 1) < 5e-3                       # a wrong bias correction / lr scales the update
-        assert (ua - ub).norm().item() <= 1.25 * (ua - uc).norm().item() + 1e-3 * ua.norm().item(), (i, (ua - ub).norm().item(), (ua - uc).norm().item())
+        assert (ua - ub).norm().item() <= 2.0 * (ua - uc).norm().item() + 5e-3 * ua.norm().item(), (i, (ua - ub).norm().item(), (ua - uc).norm().item())   # (two chaos magnitudes: a factor 2 apart at most)
         if i >= 2:
             want = ops.adam_dyn_scalars(1e-3, (0.9, 0.999), i + 1, b.teacher.decay)
             assert torch.allclose(b._dyn_dev.cpu(), torch.tensor(want, dtype=torch.float32))
     assert b._graph is not None and a.step_count == b.step_count == 5
+
+
+def test_deterministic_mode_is_bit_reproducible():
+    """AnatoMaskTrainer(deterministic_wgrad=True), bf16 storage, a model whose stem has 32 channels (the matrix-core stem kernels; STUNet-B/L/H
+    do): two runs from the same seed are BIT-identical after 3 full steps (teacher, sampler, student, backward, clip, AdamW, EMA).  The
+    weight-gradient reductions (conv, stem, projection) fold per-workgroup partial sums in a fixed order, the bias-gradient and
+    statistics sums are fp64 (arrival order shows at 1e-16, below every fp32 / bf16 rounding that follows).  Without the flag the fp32
+    atomics of the split-K reductions make half of all gradient elements differ from run to run."""
+    from anatomask_amd import modules as M, ops
+    from anatomask_amd.trainer import AnatoMaskTrainer
+
+    def run(det):
+        ops.DETERMINISTIC_WGRAD = False
+        torch.manual_seed(0)
+        model = M.build_spark([32, 32, 48, 64, 64, 64], [1] * 6, 128, (48, 48, 48), 0.6, compute_dtype=torch.bfloat16).to(DEV)
+        tr = AnatoMaskTrainer(model, lr=1e-3, total_epochs=100, seed=3, deterministic_wgrad=det)
+        x = np_volume(2, (48, 48, 48), 77).to(DEV)
+        for _ in range(3):
+            o = tr.step(x, epoch=50)
+        return model._flat.clone(), tr.teacher.ema._flat.clone(), o["loss"].item()
+    try:
+        a, b = run(True), run(True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+        c, d = run(False), run(False)
+        assert not torch.equal(c[0], d[0])                       # (the default mode really is order-dependent: the flag is what fixes it)
+        upd = (a[0] - c[0]).abs().max().item()
+        assert upd <= 3 * 3e-3                                    # both modes take the same steps up to Adam's +-lr per step
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
