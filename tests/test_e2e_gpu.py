@@ -766,3 +766,41 @@ def test_deterministic_mode_is_bit_reproducible():
         assert upd <= 3 * 3e-3                                    # both modes take the same steps up to Adam's +-lr per step
     finally:
         ops.DETERMINISTIC_WGRAD = False
+
+
+def test_resume_is_bit_exact_in_deterministic_mode(tmp_path):
+    """4 steps straight vs 2 steps -> save_checkpoint -> a FRESH trainer -> load_checkpoint -> 2 steps, in the bit-reproducible mode
+    (bf16, 32-channel stem, deterministic_wgrad): weights, EMA teacher, AdamW moments and the sampler's next draws must be identical
+    bit for bit -- the checkpoint carries everything the step depends on (faithful resume)."""
+    from anatomask_amd import checkpoint, modules as M, ops
+    from anatomask_amd.trainer import AnatoMaskTrainer
+
+    def fresh():
+        torch.manual_seed(0)
+        model = M.build_spark([32, 32, 48, 64, 64, 64], [1] * 6, 128, (48, 48, 48), 0.6, compute_dtype=torch.bfloat16).to(DEV)
+        return AnatoMaskTrainer(model, lr=1e-3, total_epochs=100, seed=3, deterministic_wgrad=True)
+    xs = [np_volume(2, (48, 48, 48), 60 + i).to(DEV) for i in range(4)]
+    try:
+        a = fresh()
+        for x in xs:
+            oa = a.step(x, epoch=50)
+        b = fresh()
+        for x in xs[:2]:
+            b.step(x, epoch=50)
+        p = str(tmp_path / "latest.pt")
+        checkpoint.save_checkpoint(p, b, [1.0, 1.0], 49)
+        c = fresh()
+        with torch.no_grad():
+            for p_ in c.model.parameters():                      # (whatever the fresh trainer held must not survive the load)
+                p_.add_(0.123)
+        checkpoint.load_checkpoint(p, c)
+        for x in xs[2:]:
+            oc = c.step(x, epoch=50)
+        assert c.step_count == a.step_count == 4
+        assert torch.equal(oa["mask"], oc["mask"]) and oa["loss"].item() == oc["loss"].item()
+        n = a.model._live_end
+        assert torch.equal(a.model._flat, c.model._flat) and torch.equal(a.teacher.ema._flat, c.teacher.ema._flat)
+        assert torch.equal(a.m[:n], c.m[:n]) and torch.equal(a.v[:n], c.v[:n])
+        assert torch.equal(a.model._bflat, c.model._bflat)       # BatchNorm running statistics
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
