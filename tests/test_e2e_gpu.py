@@ -801,3 +801,48 @@ def test_resume_is_bit_exact_in_deterministic_mode(tmp_path):
         assert torch.equal(a.model._bflat, c.model._bflat)       # BatchNorm running statistics
     finally:
         ops.DETERMINISTIC_WGRAD = False
+
+
+def test_side_stream_schedule_does_not_change_a_bit():
+    """Race check for the two-stream backward: in the bit-reproducible mode the step with the weight gradients on the side HIP stream
+    (events: dy ready -> side stream; side stream joined before each parameter group is final and at the end of backward) must produce
+    exactly the bits of the fully serialised schedule.  A missing wait shows up as a difference (a wgrad reading a half-written dy, the
+    optimizer reading a gradient that is still being accumulated)."""
+    from anatomask_amd import engine, modules as M, ops
+    from anatomask_amd.trainer import AnatoMaskTrainer
+
+    def run(side):
+        engine._USE_SIDE = side
+        torch.manual_seed(0)
+        model = M.build_spark([32, 32, 48, 64, 64, 64], [1] * 6, 128, (48, 48, 48), 0.6, compute_dtype=torch.bfloat16).to(DEV)
+        tr = AnatoMaskTrainer(model, lr=1e-3, total_epochs=100, seed=5, deterministic_wgrad=True)
+        for i in range(4):
+            o = tr.step(np_volume(2, (48, 48, 48), 90 + i).to(DEV), epoch=50)
+        return model._flat.clone(), tr.teacher.ema._flat.clone(), o["loss"].item()
+    try:
+        a, b, c = run(True), run(False), run(True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
+        assert torch.equal(a[0], c[0])
+    finally:
+        engine._USE_SIDE = True
+        ops.DETERMINISTIC_WGRAD = False
+
+
+def test_recompute_mode_is_bit_identical_in_deterministic_mode():
+    """Activation recomputation (P/GC.py policy: encoder stages and decoder blocks re-run in backward) must change memory, not numbers: in
+    the bit-reproducible mode the recompute step produces exactly the weights of the plain step (BatchNorm running statistics updated once)."""
+    from anatomask_amd import modules as M, ops
+    from anatomask_amd.trainer import AnatoMaskTrainer
+
+    def run(recompute):
+        torch.manual_seed(0)
+        model = M.build_spark([32, 32, 48, 64, 64, 64], [1] * 6, 128, (48, 48, 48), 0.6, compute_dtype=torch.bfloat16, recompute=recompute).to(DEV)
+        tr = AnatoMaskTrainer(model, lr=1e-3, total_epochs=100, seed=5, deterministic_wgrad=True)
+        for i in range(3):
+            tr.step(np_volume(2, (48, 48, 48), 30 + i).to(DEV), epoch=50)
+        return model._flat.clone(), model._bflat.clone(), tr.teacher.ema._flat.clone()
+    try:
+        a, b = run(False), run(True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
