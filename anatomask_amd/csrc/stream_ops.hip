@@ -240,13 +240,17 @@ __device__ __forceinline__ void bwd_reduce_tail(double* bsum, int C, const BwdFi
 }
 
 // dxsum replicas [nrep][C] -> accum[c] += sum, replicas re-zeroed
+// The replicas hold FIXED-POINT sums (int64, 2^-36 units): these bias gradients are what is left of a sum that cancels analytically
+// (a conv bias under a norm), so even fp64 atomics leave the arrival order visible in the fp32 result (1e-16 of the partial sums
+// is 1e-7 of the remainder); integer addition is associative -- the result is the same bits whatever the order.
+constexpr double AM_DX_FIX = 68719476736.0;         // 2^36: resolution 1.5e-11, range +-1.3e8
 __device__ __forceinline__ void dxsum_tail(double* rep, int nrep, int C, float* accum, unsigned* ticket) {
   if (!ticket) return;
   if (!last_workgroup(ticket)) return;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s_ = 0.0;
-    for (int r = 0; r < nrep; ++r) s_ += __longlong_as_double(atomicExch((unsigned long long*)&rep[(size_t)r * C + c], 0ull));
-    accum[c] += (float)s_;
+    long long s_ = 0;
+    for (int r = 0; r < nrep; ++r) s_ += (long long)atomicExch((unsigned long long*)&rep[(size_t)r * C + c], 0ull);
+    accum[c] += (float)((double)s_ / AM_DX_FIX);
   }
   if (threadIdx.x == 0) atomicExch(ticket, 0u);
 }
@@ -411,7 +415,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
 #pragma unroll
         for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], (double)a1[i]);   // fp64: the arrival order shows at 1e-16
+      for (int i = 0; i < EPC; ++i)
+        atomicAdd((unsigned long long*)&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], (unsigned long long)__double2ll_rn((double)a1[i] * AM_DX_FIX));
     }
     dxsum_tail(dxsum, dxrep, g.C, dx_accum, dx_ticket);
   }
@@ -719,7 +724,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
 #pragma unroll
         for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) atomicAdd(&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], (double)a1[i]);   // fp64: the arrival order shows at 1e-16
+      for (int i = 0; i < EPC; ++i)
+        atomicAdd((unsigned long long*)&dxsum[(size_t)(blockIdx.x % dxrep) * g.C + threadIdx.x * EPC + i], (unsigned long long)__double2ll_rn((double)a1[i] * AM_DX_FIX));
     }
     dxsum_tail(dxsum, dxrep, g.C, dx_accum, dx_ticket);
   }
@@ -1395,9 +1401,9 @@ __global__ void unpack_grad_kernel(const float* __restrict__ src, float* __restr
 __global__ __launch_bounds__(256) void rep_reduce_kernel(const double* __restrict__ rep, int nrep, int C, float* __restrict__ dst) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  double s = 0.0;
-  for (int r = 0; r < nrep; ++r) s += rep[(size_t)r * C + c];
-  dst[c] += (float)s;
+  long long s = 0;
+  for (int r = 0; r < nrep; ++r) s += ((const long long*)rep)[(size_t)r * C + c];
+  dst[c] += (float)((double)s / AM_DX_FIX);
 }
 
 // per-workgroup conv partials [rows][C][2] -> sums[C][2] (double) and/or sum_accum[C] += sum
@@ -1778,6 +1784,9 @@ int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, con
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   if (mask && !geo_ok(B, D, H, W)) return -4;
   hipStream_t st = (hipStream_t)stream;
+  // small tensors (the densify projection of the coarsest level: its bias gradient): ONE workgroup, so the fp32 sum has a fixed order
+  // (with several workgroups the per-workgroup sums arrive as fp32 atomics in any order)
+  if ((long)B * D * H * W * C <= (4L << 20)) { g.vpw = (int)((long)B * D * H * W); const int vpp = 256 / (C / (dtype == AM_DT_BF16 ? 8 : 4)) > 0 ? 256 / (C / (dtype == AM_DT_BF16 ? 8 : 4)) : 1; g.vpw = (g.vpw + vpp - 1) / vpp * vpp; }
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype, AM_LAUNCH(chan_sum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, out_accum),
              AM_LAUNCH(chan_sum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, out_accum));
