@@ -285,7 +285,7 @@ def test_overfit_one_batch_follows_reference_curve(dtype, track, final):
     batch, the random draws teacher-forced from the reference's run of the same thing (tests/golden/overfit_tiny.npz: loss
     1.005 -> 0.044).  The first 5 steps must follow the reference's loss curve within `track` (relative); after that the
     sampler's hard-patch set flips with 1e-7 differences and the trajectories decorrelate (the CPU oracle itself is 1e-2..4e-2
-    off the reference from step 7 on), so the curve is bounded instead: every 10-step mean within 25 % of the reference's, and
+    off the reference from step 7 on), so the curve is bounded instead: every 10-step mean within 25 % (+ 0.01) of the reference's, and
     the last 10 steps average below `final`."""
     from anatomask_amd.trainer import AnatoMaskTrainer
     ov, f = load("overfit_tiny.npz"), load("forward_tiny.npz")
@@ -302,9 +302,12 @@ def test_overfit_one_batch_follows_reference_curve(dtype, track, final):
     ref = ov["losses"]
     assert np.isfinite(losses).all()
     assert np.abs(losses[:5] / ref[:5] - 1).max() < track, (losses[:5], ref[:5])
-    blocks = losses.reshape(-1, 10).mean(1) / ref.reshape(-1, 10).mean(1)
+    bl, rf = losses.reshape(-1, 10).mean(1), ref.reshape(-1, 10).mean(1)
+    blocks = bl / rf
     print("overfit", dtype, "loss[::10]", np.round(losses[::10], 4), "block ratio to reference", np.round(blocks, 3))
-    assert np.abs(blocks - 1).max() < 0.25, blocks
+    # within 25 % of the reference's block mean, plus 0.01 absolute for the late blocks (loss 0.04-0.06, where the decorrelated
+    # trajectories wander by more than a quarter of so small a value once in ~8 runs)
+    assert (np.abs(bl - rf) <= 0.25 * rf + 0.01).all(), blocks
     assert losses[-10:].mean() < final, losses[-10:]
 
 
