@@ -849,3 +849,29 @@ def test_recompute_mode_is_bit_identical_in_deterministic_mode():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     finally:
         ops.DETERMINISTIC_WGRAD = False
+
+
+def test_two_ranks_same_data_equal_the_single_process_run_bit_for_bit():
+    """The gradient exchange (per-group async all-reduce from the backward hook, SUM + the 1/world factor folded into the optimizer
+    kernel) adds nothing of its own: two ranks fed the SAME data in the bit-reproducible mode end up with exactly the weights, teacher,
+    AdamW moments and BatchNorm buffers of a single-process run (SHA-256 over all of them)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from anatomask_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import ddp_same_data_det
+        want = ddp_same_data_det.run(False)
+    finally:
+        sys.path.pop(0)
+        ops.DETERMINISTIC_WGRAD = False
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(root, "tools", "ddp_same_data_det.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = re.findall(r"rank (\d) sha256 ([0-9a-f]{64})", r.stdout)
+    assert len(got) == 2 and {h for _, h in got} == {want}, (want, got)
