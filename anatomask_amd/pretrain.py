@@ -109,6 +109,8 @@ def main(argv=None):
     ap.add_argument("--resume", default=None)
     ap.add_argument("--plain-spark", action="store_true", help="plain SparK baseline (P/pretrain.py): random mask, no teacher, validation + best ckpt")
     ap.add_argument("--sync-bn", action="store_true", help="SyncBatchNorm statistics in the decoder (P/pretrain_DDP.py:225)")
+    ap.add_argument("--deterministic", action="store_true",
+                    help="bit-reproducible steps: ordered folds instead of fp32 atomics in the weight-gradient reductions (+2 %% step time)")
     a = ap.parse_args(argv)
     if a.gpus > 1 and not launch.launched():
         sys.exit(launch.self_launch(a.gpus, "-m", ["anatomask_amd.pretrain", *(argv if argv is not None else sys.argv[1:])]))
@@ -124,7 +126,7 @@ def main(argv=None):
     model = build_spark(kw["dims"], kw["depth"], kw["width"], tuple(a.input_size), a.mask_ratio,
                         compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32, sbn=a.sync_bn).to(dev)
     trainer = AnatoMaskTrainer(model, lr=a.lr, weight_decay=a.weight_decay, clip=a.clip, total_epochs=a.epochs, seed=4321 + rank,
-                               self_distill=not a.plain_spark)
+                               self_distill=not a.plain_spark, deterministic_wgrad=a.deterministic)
     trainer.rank = rank
     lrs = linear_warmup_cosine_lrs(a.epochs, a.lr, a.warmup, 1e-6)                    # :359
     feed = val_feed = None
