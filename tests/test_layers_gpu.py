@@ -304,3 +304,38 @@ def test_spark_around_a_mednext_encoder_matches_the_reference(SL, dtype, tol):
         if k.startswith("buf.") and "num_batches" not in k:
             got = dict(model.named_buffers())[k[4:]].cpu().numpy()
             assert np.abs(got - F_[k]).max() <= 2 * tol * max(1.0, np.abs(F_[k]).max()), k
+
+
+@pytest.mark.parametrize("name", ["maxpool_k3s2p1", "avgpool_k3s2p1_nopad", "bn_train", "gn_g2", "ln_cf", "ln_cl", "grn", "adaptive_avg", "dwconv7",
+                                  "dwconv3s2", "conv3s2", "convnext"])
+def test_layers_in_bf16_storage(SL, name):
+    """Every zoo layer once more with bf16 activations (fp32 master parameters, fp32 accumulation inside the kernels): outputs and
+    gradients against the reference's fp32 golden vectors within bf16 storage noise (relative L2)."""
+    mk = {"maxpool_k3s2p1": lambda: SL.SparseMaxPooling(3, 2, 1), "avgpool_k3s2p1_nopad": lambda: SL.SparseAvgPooling(3, 2, 1, count_include_pad=False),
+          "bn_train": lambda: SL.SparseBatchNorm3d(16), "gn_g2": lambda: SL.SparseGroupNorm(2, 16), "ln_cf": lambda: SL.SparseConvNeXtLayerNorm(16, data_format="channels_first"),
+          "ln_cl": lambda: SL.SparseConvNeXtLayerNorm(16), "grn": lambda: SL.SparseGRN(8), "adaptive_avg": lambda: SL.SparseAdaptiveAvgPooling((1, 1, 1)),
+          "dwconv7": lambda: SL.SparseConv3d(16, 16, kernel_size=7, padding=3, groups=16), "dwconv3s2": lambda: SL.SparseConv3d(16, 16, kernel_size=3, stride=2, padding=1, groups=16),
+          "conv3s2": lambda: SL.SparseConv3d(16, 24, kernel_size=3, stride=2, padding=1), "convnext": lambda: SL.SparseConvNeXtBlock(16, layer_scale_init_value=0.5, ks=7)}
+    cl = name in ("ln_cl", "grn")
+    active = t("active")
+    set_active(active)
+    module = mk[name]()
+    if any(True for _ in module.parameters()):
+        load_params(module, name)
+    module = module.to(DEV).train()
+    x = t(name + ".x").to(DEV).to(torch.bfloat16).requires_grad_(True)
+    y = module(x)
+    assert y.dtype == torch.bfloat16
+
+    def rel(a, b):
+        return ((a.detach().cpu().float() - b).norm() / (b.norm() + 1e-12)).item()
+    assert rel(y, t(name + ".y")) <= 2e-2, (name, rel(y, t(name + ".y")))
+    (y.float() * t(name + ".g").to(DEV)).sum().backward()
+    m = up(active, x.shape[1:4] if cl else x.shape[2:]).float()
+    m = m.permute(0, 2, 3, 4, 1) if cl else m
+    # (max pooling: rounding x to bf16 moves the arg-max between near-equal window elements, which re-routes whole gradient entries)
+    assert rel(x.grad.float().cpu() * m, t(name + ".dx") * m) <= (8e-2 if name.startswith("maxpool") else 4e-2), (name, "dx", rel(x.grad.float().cpu() * m, t(name + ".dx") * m))
+    for n, p in module.named_parameters():
+        key = f"{name}.d.{n}"
+        if key in G.files and float(np.linalg.norm(G[key])) > 1e-4:
+            assert rel(p.grad, t(key).view_as(p)) <= 5e-2, (name, n, rel(p.grad, t(key).view_as(p)))
