@@ -37,6 +37,7 @@ struct WgArgs {
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
   int split;                  // brick-walk slots per (tile, group)
+  int walk, seg_len, nseg;    // walk 1: d-fastest segments of seg_len bricks, columns interleaved over the slots of an XCD (see the kernel)
   float* det_ws;              // deterministic mode: [split][k^3][Cy][Cx] per-slot partial sums (plain stores), folded in slot order
   long det_stride;            //   floats per slot
 #ifdef AM_ABLATE
@@ -147,8 +148,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const bool masked = a.x_mask.m != nullptr || a.y_mask.m != nullptr;
   const int Dy_ = a.Dy, Hy_ = a.Hy, Wy_ = a.Wy, Dx_ = a.Dx, Hx_ = a.Hx, Wx_ = a.Wx, OS_ = a.OS, GS_ = a.GS;
 
-  // a workgroup owns a CONTIGUOUS run of bricks (w fastest): the brick coordinates advance by increment-and-carry (no divisions
-  // in the loop) and consecutive bricks re-read each other's halo rows from L2
+  // Brick walk.  walk 0: a workgroup owns a CONTIGUOUS run of bricks (w fastest): the brick coordinates advance by increment-and-carry
+  // (no divisions in the loop) and consecutive bricks re-read each other's w-halo rows from L2.
+  // walk 1 (dense operands): d fastest.  The work unit is a (column (b, bh, bw), segment of seg_len d-bricks); XCD x owns a contiguous
+  // range of columns and its S8 slots take the units j, j + S8, ... of (segment-major, column-minor) order, so at any time the slots
+  // of an XCD walk S8 ADJACENT columns through the same d range: the d-halo planes of X are re-read one brick later by the same
+  // slot's tap groups and the h/w-halo rows by a neighbouring slot of the same L2 -- HBM sees X and dY about once
+  // (profiles/r02_pmc_traffic.md), instead of twice with walk 0.
   const int chunk = (nbrick + a.split - 1) / a.split;
   const int brick0 = slot * chunk, brick1 = brick0 + chunk < nbrick ? brick0 + chunk : nbrick;
   int bw_, bh_, bd_, b;
@@ -160,8 +166,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     bw_ -= 1;                                            // (pre-decrement: the loop increments first)
   }
   const int nbw_ = a.nbw, nbh_ = a.nbh, nbd_ = a.nbd;
-  for (int brick = brick0; brick < brick1; ++brick) {
-    if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
+  const int S8 = a.split >> 3, ncol = a.B * nbh_ * nbw_;
+  const int c0 = (int)((long)ncol * (slot & 7) / 8), ncx = (int)((long)ncol * ((slot & 7) + 1) / 8) - c0;
+  const int nu = ncx * a.nseg;
+  // (two nested counted loops: the flat `for (;;)` form of this walk made hipcc spill 120 VGPRs)
+  const int u_end = a.walk ? nu : (slot >> 3) + 1, u_inc = a.walk ? S8 : u_end;     // walk 0: exactly one pass (u_inc >= 1 always)
+  for (int u = slot >> 3; u < u_end; u += u_inc) {
+  int nstep = brick1 - brick0;
+  if (a.walk) {
+    const int seg = u / ncx, col = c0 + u % ncx;
+    bw_ = col % nbw_; bh_ = (col / nbw_) % nbh_; b = col / (nbw_ * nbh_);
+    bd_ = seg * a.seg_len - 1;
+    nstep = nbd_ - seg * a.seg_len < a.seg_len ? nbd_ - seg * a.seg_len : a.seg_len;
+  }
+  for (int step = 0; step < nstep; ++step) {
+    if (a.walk) ++bd_;
+    else if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
     // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
     const int i0d = (q0d + a.mind[grp]) * GS_ + upd, i0h = (q0h + a.minh[grp]) * GS_ + uph, i0w = (q0w + a.minw[grp]) * GS_ + upw;
@@ -301,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     }
     if (!AM_DBG(a, 32)) __builtin_amdgcn_s_setprio(0);
   }
+  }
 
   // ---- flush: D row = cy 4g+r, col = cx r16 ----
   const int cx = cx0 + 16 * wx + r16;
@@ -424,6 +445,26 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
   if (split > nbrick) split = nbrick;
   if (a.det_ws && split > det_slots) split = det_slots;     // (the caller checked det_slots >= 1)
   a.split = split;
+  // d-fastest interleaved walk for dense operands when the slots split evenly over the XCDs (segments of <= 16 d-bricks keep the
+  // slots of an XCD balanced to a segment; each segment start re-reads one d-halo)
+  // (measured slower on the transposed convolutions' 8 parity groups: only the one-plane bricks of dense k3 s1 take it)
+  a.walk = (BD == 1 && !a.x_mask.m && !a.y_mask.m && split % 8 == 0 && split >= 8) ? 1 : 0;
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_WALK"); if (e_ && !atoi(e_)) a.walk = 0; }
+#endif
+  // segments as long as the balance of the slots allows: >= 48 work units per slot (a unit more or less = 2 %) but at least 8
+  // bricks, since every segment start re-reads one d-halo (measured on 64->64 @128^3: profiles/r02_experiments.md)
+  {
+    const int ncx = (a.B * a.nbh * a.nbw + 7) / 8, s8 = split / 8 > 0 ? split / 8 : 1;
+    int nseg = (48 * s8 + ncx - 1) / ncx;
+    if (nseg > a.nbd / 8) nseg = a.nbd / 8;
+    if (nseg < 1) nseg = 1;
+    a.seg_len = (a.nbd + nseg - 1) / nseg;
+    a.nseg = (a.nbd + a.seg_len - 1) / a.seg_len;
+  }
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_SEG"); if (e_ && atoi(e_) > 0) { a.seg_len = atoi(e_) < a.nbd ? atoi(e_) : a.nbd; a.nseg = (a.nbd + a.seg_len - 1) / a.seg_len; } }
+#endif
   dim3 grid(((split + 7) / 8) * 8 * a.ngroup, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a);
   AM_CHECK_LAUNCH();
@@ -474,6 +515,13 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   // share a CU and overlap each other's staging;  f32 (k-steps of 4): 2x8x8.
   int bd = 2, bh = 8, bw = 8;
   if (bf && Qw >= 16) { bh = 4; bw = 16; }
+  // dense k3 s1 with 64-wide tiles: one-plane 1x8x16 bricks -- the X brick of a tap group has no d-halo at all (10x18 voxels
+  // for 8x16: 1.41x, against 1.69x for 2x4x16) and the d-fastest walk re-reads each plane from L2
+  bool plane_brick = bf && Qw >= 16 && Qh >= 8 && mode == AM_CONV_FWD && k == 3 && stride == 1 && !x_mask && !y_mask && (Cx > 32 || Cy > 32);
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_PLANE"); if (e_ && !atoi(e_)) plane_brick = false; }
+#endif
+  if (plane_brick) { bd = 1; bh = 8; bw = 16; }
   // 32-channel operands: 32-wide tiles (MI = 2 cy tiles / NWX = 2 cx waves, the other waves split the voxels)
   int mi = 4, nwx = 4;
   if (bf && bw == 16 && mode == AM_CONV_FWD && (k == 3 || stride == 2)) {
@@ -528,7 +576,10 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     const int tiles = ((Cy + 16 * mi - 1) / (16 * mi)) * ((Cx + 16 * nwx - 1) / (16 * nwx)) * a.ngroup;
     int rc = -2;
 #define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, tiles, nbrick, det_slots, st)
-    if (bf && bw == 16 && (mi == 2 || nwx == 2)) {
+    if (bf && bd == 1 && ntap == 9 && (mi == 2 || nwx == 2)) {
+      if (mi == 2) rc = launch<bf16_t, 1, 8, 16, 9, 6, 2, 4>(a, maxvox, tiles, nbrick, det_slots, st);
+      else rc = launch<bf16_t, 1, 8, 16, 9, 3, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+    } else if (bf && bw == 16 && (mi == 2 || nwx == 2)) {
       if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 9 && mi == 2) rc = launch<bf16_t, 2, 4, 16, 9, 7, 2, 4>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 9) rc = launch<bf16_t, 2, 4, 16, 9, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
@@ -537,7 +588,8 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
       else if (ntap == 2) rc = launch<bf16_t, 2, 4, 16, 2, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
       else rc = launch<bf16_t, 2, 4, 16, 1, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
     } else if (bf && bw == 16) {
-      if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
+      if (ntap == 9 && bd == 1) rc = launch<bf16_t, 1, 8, 16, 9, 6>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
       else if (ntap == 2) WG_CASE(bf16_t, 4, 16, 2, 8); else WG_CASE(bf16_t, 4, 16, 1, 8);
     } else if (bf) {
       if (ntap == 9) WG_CASE(bf16_t, 8, 8, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 8, 8, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 8, 8, 4, 8);

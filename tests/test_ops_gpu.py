@@ -119,6 +119,28 @@ def test_conv_wgrad_narrow_channels_wide_grid(ops, case, sparse):
     close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (narrow channels)")
 
 
+@pytest.mark.parametrize("case", [(64, 64, (5, 20, 40), 3), (96, 64, (9, 8, 16), 1), (64, 32, (7, 12, 24), 2), (40, 72, (33, 9, 17), 1)])
+@pytest.mark.parametrize("det", [False, True])
+def test_conv_wgrad_plane_bricks_ragged(ops, case, det):
+    """Dense k3 s1 bf16 weight gradients walk one-plane 1x8x16 bricks d-fastest, columns interleaved over the slots of an XCD
+    (conv_wgrad.hip `walk 1`): ragged extents (partial bricks in every dimension, column counts that do not divide by 8, more
+    segments than slots) must still visit every brick exactly once."""
+    cin, cout, sp, B = case
+    dtype = torch.bfloat16
+    x = q(rnd(B, cin, *sp, seed=21), dtype)
+    dy = q(rnd(B, cout, *sp, seed=22), dtype)
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(x, w, None, padding=1).backward(dy)
+    ops.DETERMINISTIC_WGRAD = det
+    try:
+        dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dtype), to_cl(dy, dtype), 3, 1)
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
+    dw = torch.zeros(cout, cin, 3, 3, 3, device=DEV)
+    ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+    close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (plane bricks)")
+
+
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, False), (32, 32, 3, 1, True), (32, 64, 3, 2, True), (16, 24, 1, 2, False), (64, 64, 4, 2, False)])
 def test_conv_wgrad_deterministic_mode(ops, case):
     """det_workspace: per-slot partial sums folded in slot order instead of fp32 atomics -> bit-identical from run to run (the
