@@ -26,6 +26,7 @@ struct WgArgs {
   const void* x; const void* dy; float* dw;
   int B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy;
   int OS, GS, ngroup;         // dY stride (ConvT parity classes), global X stride (2: strided conv, X read per parity sub-lattice)
+  int QS;                     // X voxels per q step (= GS, except the full-resolution strided variant S2: GS = 1, QS = 2)
   int zmap[8];                // blockIdx.z -> unit (one launch handles the units that share a tap count)
   int upar[8];                // X parity of the unit when GS == 2
   int nbd, nbh, nbw;
@@ -37,6 +38,7 @@ struct WgArgs {
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
   int split;                  // brick-walk slots per (tile, group)
+  int mask_off, mask_n;       // block-sparse operands: LDS byte offset of the two cached patch-mask arrays (dY's, X's) of ONE sample, bytes each (0: not cached)
   int walk, seg_len, nseg;    // walk 1: d-fastest segments of seg_len bricks, columns interleaved over the slots of an XCD (see the kernel)
   float* det_ws;              // deterministic mode: [split][k^3][Cy][Cx] per-slot partial sums (plain stores), folded in slot order
   long det_stride;            //   floats per slot
@@ -64,7 +66,10 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
 // MI = 16-row cy tiles per wave (CT = 16*MI dY channels per workgroup); NWX = waves along cx (KT = 16*NWX X channels); the
 // remaining 4/NWX waves split the k-steps (voxels) of a brick.  64x64 tiles for the wide layers; 32-channel operands
 // (STUNet-B level 0, decoder output level) get 32-wide tiles instead of multiplying zero padding.
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4>
+// S2 (stride-2 conv k3, bf16): the X brick is staged at FULL resolution ((2 BH + 1) x (2 BW + 1) voxels of one plane) and the fragment
+// reads step two voxel rows per q -- the 9 (kh, kw) taps of a d-tap share one staged brick and one dY brick, instead of 8 parity
+// sub-lattice units that each re-stage dY for 1-8 taps.
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int CT = 16 * MI, KT = 16 * NWX, KS = 4 / NWX;
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int c0 = (int)((long)ncol * (slot & 7) / 8), ncx = (int)((long)ncol * ((slot & 7) + 1) / 8) - c0;
   const int nu = ncx * a.nseg;
   // (two nested counted loops: the flat `for (;;)` form of this walk made hipcc spill 120 VGPRs)
+  int mask_b = -1;                                       // sample whose patch masks sit in LDS
   const int u_end = a.walk ? nu : (slot >> 3) + 1, u_inc = a.walk ? S8 : u_end;     // walk 0: exactly one pass (u_inc >= 1 always)
   for (int u = slot >> 3; u < u_end; u += u_inc) {
   int nstep = brick1 - brick0;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     else if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
     // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
-    const int i0d = (q0d + a.mind[grp]) * GS_ + upd, i0h = (q0h + a.minh[grp]) * GS_ + uph, i0w = (q0w + a.minw[grp]) * GS_ + upw;
+    const int i0d = q0d * a.QS + a.mind[grp] * GS_ + upd, i0h = q0h * a.QS + a.minh[grp] * GS_ + uph, i0w = q0w * a.QS + a.minw[grp] * GS_ + upw;
     const int o0d = q0d * OS_ + pd, o0h = q0h * OS_ + ph, o0w = q0w * OS_ + pw;
     // descriptors anchored at the first d-plane of this brick (32-bit offsets span a few planes only: any tensor size works)
     const int yd0 = o0d < Dy_ ? o0d : Dy_, xd0 = i0d < 0 ? 0 : (i0d > Dx_ ? Dx_ : i0d);
@@ -216,7 +222,38 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
           const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
           if (!((unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_)) xo[it] = OOB;
         }
-      } else {                                           // block-sparse operands: patch-mask lookups per row
+      } else if (a.mask_n) {                             // block-sparse operands, the sample's patch masks cached in LDS
+        // (a global lookup per row puts two dependent memory round trips -- dY rows, then X rows -- in front of the brick's
+        // loads, and one in front of every skipped brick: the sparse levels ran at 6 us per brick for 0.6 us of MFMAs)
+        uint8_t* ldsMy = lds + a.mask_off;
+        uint8_t* ldsMx = ldsMy + a.mask_n;
+        if (b != mask_b) {                               // (uniform) first brick of a sample
+          __syncthreads();
+          for (int i = tid; i < a.mask_n; i += 256) {
+            ldsMy[i] = a.y_mask.m ? a.y_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
+            ldsMx[i] = a.x_mask.m ? a.x_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
+          }
+          __syncthreads();
+          mask_b = b;
+        }
+        const int ybs = a.y_mask.bs, xbs = a.x_mask.bs, mfh = a.y_mask.fh, mfw = a.y_mask.fw;
+        unsigned yany = 0;
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
+          const bool inr = yo[it] != OOB && od < Dy_ && oh < Hy_ && ow < Wy_;
+          const bool ok = inr && ldsMy[inr ? ((od >> ybs) * mfh + (oh >> ybs)) * mfw + (ow >> ybs) : 0] != 0;
+          if (!ok) yo[it] = OOB;
+          yany |= ok ? 1u : 0u;
+        }
+        if (a.y_mask.m && !__syncthreads_or(yany != 0)) continue;    // nothing active in this brick (block-sparse dY)
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
+          const bool inr = xo[it] != OOB && (unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_;
+          if (!(inr && ldsMx[inr ? ((id >> xbs) * mfh + (ih >> xbs)) * mfw + (iw >> xbs) : 0] != 0)) xo[it] = OOB;
+        }
+      } else {                                           // (masks too large for LDS: global patch-mask lookups per row)
         unsigned yany = 0;
 #pragma unroll
         for (int it = 0; it < NITY; ++it) {
@@ -262,8 +299,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
         // contraction index k = 8g + j of the MFMA  <->  voxel ks*32 + (j < 4 ? 4g + j : 16 + 4g + j - 4): any bijection
         // works as long as A and B agree; this one makes each half-wave read 8 consecutive voxel rows
         const int v1 = ks * 32 + g * 4 + q, v2 = v1 + 16;
-        const int xa1 = (((v1 / (BW * BH)) * EH + (v1 / BW) % BH) * EW + v1 % BW) * RSX + (16 * wx + 4 * p) * 2;
-        const int xa2 = (((v2 / (BW * BH)) * EH + (v2 / BW) % BH) * EW + v2 % BW) * RSX + (16 * wx + 4 * p) * 2;
+        constexpr int LS = S2 ? 2 : 1;                   // LDS voxel rows per q step
+        const int xa1 = (((v1 / (BW * BH)) * LS * EH + ((v1 / BW) % BH) * LS) * EW + (v1 % BW) * LS) * RSX + (16 * wx + 4 * p) * 2;
+        const int xa2 = (((v2 / (BW * BH)) * LS * EH + ((v2 / BW) % BH) * LS) * EW + (v2 % BW) * LS) * RSX + (16 * wx + 4 * p) * 2;
         s16x4 alo[MI], ahi[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -275,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int i = 0; i < MI; ++i)
           af[i] = __builtin_bit_cast(bfx8, s16x8{alo[i][0], alo[i][1], alo[i][2], alo[i][3], ahi[i][0], ahi[i][1], ahi[i][2], ahi[i][3]});
-        if constexpr (NTAP == 9 && BW == 16) {
+        if constexpr (NTAP == 9 && BW == 16 && !S2) {
           // conv k3 unit = 9 taps (th, tw) of one d-shift (tap t = 3*th + tw, window offset (th*EW + tw) rows).  The two voxel
           // halves of a k-step are the h-rows h and h+1 of the brick, so tap th needs the X rows h+th and h+th+1: the three th of
           // a tw share 4 rows -- 12 transposing reads per k-step instead of 18
@@ -405,12 +443,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(WgArgs a, int ntap
 // two rounds costs a third round with the chip empty (measured: 1026 workgroups 2.24 ms, 1008 workgroups 1.77 ms).
 constexpr int AM_WG_ROUNDS = 2;
 
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4>
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false>
 int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipStream_t st) {
-  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX>;
+  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX, S2>;
   constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
   constexpr int CT = 16 * MI, KT = 16 * NWX;
-  const size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
+  size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
+  a.mask_off = 0; a.mask_n = 0;
+  if (a.x_mask.m || a.y_mask.m) {                 // one sample's patch masks ride along in LDS when they are small (8^3 .. 12^3 patches)
+    const MaskView& mv = a.y_mask.m ? a.y_mask : a.x_mask;
+    const int n = mv.fd * mv.fh * mv.fw;
+    if (n <= 4096) { a.mask_off = (int)((lds + 15) & ~(size_t)15); a.mask_n = n; lds = (size_t)a.mask_off + 2 * (size_t)n; }
+  }
   if (lds > 160 * 1024) return -3;
   if (maxvox * (KT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
   static std::once_flag lds_cap;                  // per instantiation, thread-safe
@@ -503,9 +547,16 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   //   conv stride 2: the 8 parity sub-lattices of X (1,2,2,2,4,4,4,8 taps): X[2q + s] = X_sub[r][q + u], s = 2u + r
   int nunit;
   a.OS = 1; a.GS = 1;
+  const int Qw0 = Wy, Qh0 = Hy;
+  // stride-2 k3 on grids at least one 1x4x16 brick wide: full-resolution staging, one unit per d-tap (kernel variant S2)
+  bool s2full = bf && mode == AM_CONV_FWD && k == 3 && stride == 2 && Qw0 >= 16 && Qh0 >= 4;
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_S2FULL"); if (e_ && !atoi(e_)) s2full = false; }
+#endif
   if (mode == AM_CONV_FWD) {
     if (k != 1 && k != 3) return -2;
-    if (stride == 2) { a.GS = 2; nunit = 8; } else nunit = k;
+    if (s2full) nunit = 3;
+    else if (stride == 2) { a.GS = 2; nunit = 8; } else nunit = k;
   } else if (mode == AM_CONVT_FWD) {
     if (k != 4 || stride != 2) return -2;
     a.OS = 2; nunit = 8;
@@ -522,9 +573,11 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   { const char* e_ = getenv("AM_WG_PLANE"); if (e_ && !atoi(e_)) plane_brick = false; }
 #endif
   if (plane_brick) { bd = 1; bh = 8; bw = 16; }
+  if (s2full) { bd = 1; bh = 4; bw = 16; }
   // 32-channel operands: 32-wide tiles (MI = 2 cy tiles / NWX = 2 cx waves, the other waves split the voxels)
   int mi = 4, nwx = 4;
-  if (bf && bw == 16 && mode == AM_CONV_FWD && (k == 3 || stride == 2)) {
+  if (s2full) nwx = 2;                                    // 32-channel X tiles: the 9 x 33 full-resolution rows stay at 96 bytes
+  else if (bf && bw == 16 && mode == AM_CONV_FWD && (k == 3 || stride == 2)) {
     if (Cy <= 32 && stride == 1) mi = 2;
     if (Cx <= 32) nwx = 2;
     if (mi == 2 && nwx == 2) bd = 4;                     // thin rows: a 256-voxel brick still fits two workgroups per CU
@@ -544,7 +597,7 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
       for (int d = 0; d < 3 && ok; ++d) {
         if (mode == AM_CONVT_FWD) { const int num = p[d] + pad - t[d]; if (num & 1) ok = false; else u[d] = num / 2; }
         else if (a.GS == 2) { const int sft = t[d] - pad, r = ((sft % 2) + 2) % 2; if (r != p[d]) ok = false; else u[d] = (sft - r) / 2; }
-        else u[d] = t[d] - pad;
+        else u[d] = t[d] - pad;                           // (S2: shifts in full-resolution voxels around 2q)
       }
       if (ok && mode == AM_CONV_FWD && a.GS == 1 && td != gI) ok = false;
       if (!ok) continue;
@@ -554,15 +607,17 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     }
     ucount[gI] = n - a.tap_begin[gI];
     a.mind[gI] = mn[0]; a.minh[gI] = mn[1]; a.minw[gI] = mn[2];
-    a.ed[gI] = bd + (mx[0] - mn[0]);
-    a.eh[gI] = bh + (mx[1] - mn[1]);
-    a.ew[gI] = bw + (mx[2] - mn[2]);
+    const int ls = s2full ? 2 : 1;                        // staged voxel rows per q step
+    a.ed[gI] = (bd - 1) * ls + 1 + (mx[0] - mn[0]);
+    a.eh[gI] = (bh - 1) * ls + 1 + (mx[1] - mn[1]);
+    a.ew[gI] = (bw - 1) * ls + 1 + (mx[2] - mn[2]);
     a.mdiv_w[gI] = (1 << 20) / a.ew[gI] + 1;
     a.mdiv_hw[gI] = (1 << 20) / (a.ew[gI] * a.eh[gI]) + 1;
     const size_t v = (size_t)a.ed[gI] * a.eh[gI] * a.ew[gI];
     if (v > maxvox) maxvox = v;
   }
   for (int gI = nunit; gI <= 8; ++gI) a.tap_begin[gI] = n;
+  a.QS = s2full ? 2 : a.GS;
   a.nbd = (Qd + bd - 1) / bd; a.nbh = (Qh + bh - 1) / bh; a.nbw = (Qw + bw - 1) / bw;
   const int nbrick = B * a.nbd * a.nbh * a.nbw;
   hipStream_t st = (hipStream_t)stream;
@@ -576,7 +631,8 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     const int tiles = ((Cy + 16 * mi - 1) / (16 * mi)) * ((Cx + 16 * nwx - 1) / (16 * nwx)) * a.ngroup;
     int rc = -2;
 #define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, tiles, nbrick, det_slots, st)
-    if (bf && bd == 1 && ntap == 9 && (mi == 2 || nwx == 2)) {
+    if (s2full) rc = launch<bf16_t, 1, 4, 16, 9, 5, 4, 2, true>(a, maxvox, tiles, nbrick, det_slots, st);
+    else if (bf && bd == 1 && ntap == 9 && (mi == 2 || nwx == 2)) {
       if (mi == 2) rc = launch<bf16_t, 1, 8, 16, 9, 6, 2, 4>(a, maxvox, tiles, nbrick, det_slots, st);
       else rc = launch<bf16_t, 1, 8, 16, 9, 3, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
     } else if (bf && bw == 16 && (mi == 2 || nwx == 2)) {

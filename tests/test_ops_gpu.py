@@ -141,6 +141,30 @@ def test_conv_wgrad_plane_bricks_ragged(ops, case, det):
     close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (plane bricks)")
 
 
+@pytest.mark.parametrize("case", [(32, 64, (5, 9, 33), 2, 0), (64, 128, (6, 4, 16), 1, 1), (48, 72, (3, 21, 40), 3, 1), (128, 256, (4, 8, 16), 2, 0)])
+@pytest.mark.parametrize("det", [False, True])
+def test_conv_wgrad_stride2_full_resolution_bricks(ops, case, det):
+    """Stride-2 k3 bf16 weight gradients on grids >= 16 wide stage the X brick at full resolution, one unit per d-tap
+    (conv_wgrad_kernel<..., S2>): ragged extents, even (2n) and odd (2n - 1) input sizes, channel counts that are not tile multiples."""
+    cin, cout, so, B, odd = case
+    dtype = torch.bfloat16
+    si = tuple(2 * v - odd for v in so)
+    x = q(rnd(B, cin, *si, seed=31), dtype)
+    dy = q(rnd(B, cout, *so, seed=32), dtype)
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    y = F.conv3d(x, w, None, stride=2, padding=1)
+    assert tuple(y.shape[2:]) == so
+    y.backward(dy)
+    ops.DETERMINISTIC_WGRAD = det
+    try:
+        dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dtype), to_cl(dy, dtype), 3, 2)
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
+    dw = torch.zeros(cout, cin, 3, 3, 3, device=DEV)
+    ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+    close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (stride 2, full-resolution bricks)")
+
+
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, False), (32, 32, 3, 1, True), (32, 64, 3, 2, True), (16, 24, 1, 2, False), (64, 64, 4, 2, False)])
 def test_conv_wgrad_deterministic_mode(ops, case):
     """det_workspace: per-slot partial sums folded in slot order instead of fp32 atomics -> bit-identical from run to run (the
