@@ -37,7 +37,10 @@ using namespace amconv;
 
 namespace {
 
-template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false>
+// NB: the norm-backward-reduce variant (am_conv3d_nbred, bf16): the tile of the norm's input that the epilogue needs is fetched at
+// the START of the workgroup (32 more registers) -- loaded in the epilogue its HBM latency is exposed once per workgroup, which
+// for a one-slab data gradient (3.5 us of MFMAs) ate everything the fused reduce saves.
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false>
 __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
@@ -148,6 +151,21 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
       stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, cok_ ? soff[it] : OOB, (KCS) * (int)sizeof(T), 0)); \
   }
 
+  u32x4 nbx[NB ? VS : 1][NB ? NS / 2 : 1];
+  if constexpr (NB) {
+#pragma unroll
+    for (int j = 0; j < VS; ++j) {
+      const int v = wave * (MV / 4) + j * 16 + r16;
+      const int od = (q0d + v / (BW * BH)) * a.OS + pd, oh = (q0h + (v / BW) % BH) * a.OS + ph, ow = (q0w + v % BW) * a.OS + pw;
+      const bool inr = od < a.Do && oh < a.Ho && ow < a.Wo;
+      const size_t ovox = ((size_t)(b * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+      for (int h = 0; h < NS / 2; ++h) {
+        const bool ok = inr && co0 + h * 32 + g * 8 < a.Cout;
+        nbx[j][h] = *(const u32x4*)((const T*)a.nb_x + (ok ? ovox * a.Cout + co0 + g * 8 + h * 32 : (size_t)0));   // (!ok: any valid address; unused)
+      }
+    }
+  }
   for (int un = u0; un < u1; ++un) {
     const int tb = a.tap_begin[un], nt = a.tap_begin[un + 1] - tb;
     if (nt == 0) continue;                               // (k1 s2 dgrad parities without taps write zeros)
@@ -288,7 +306,10 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
   };
   const bool sparse_out = a.out_mask.m != nullptr;
   // bf16 statistics run on the matrix cores (below): the stored values are also laid out as a [voxel][channel] tile in LDS
-  constexpr int SRS = NT * 2 + 32;                       // row stride of that tile: conflict-free for ds_read_b64_tr_b16 (conv_wgrad.hip)
+  // row stride of that tile: 160 B (conflict-free for ds_read_b64_tr_b16, conv_wgrad.hip); the norm-backward reduce keeps a second
+  // tile (the norm's input) in the same rows, [g | x | pad] = 288 B (72 dwords: 8 consecutive rows still cover all 64 banks) -- two
+  // separate 160-byte tiles would be 80 KB, exactly half a CU's LDS, and cost the second resident workgroup
+  constexpr int SRS = NB ? 4 * NT + 32 : 2 * NT + 32;
   const bool mstats = sizeof(T) == 2 && part && !AM_DBG(a, 512);
   if (mstats) __syncthreads();                           // (uniform) the main loop's fragment reads are done: the staging area is free
 #pragma unroll
@@ -324,7 +345,28 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
         if (wr) { if (a.nt_store) __builtin_nontemporal_store(__builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7), (bfx8*)dst); else *(bfx8*)dst = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7); }
         if (mstats) {
           const bfx8 z8 = __builtin_bit_cast(bfx8, u32x4{0u, 0u, 0u, 0u});
-          *(bfx8*)(lds + v * SRS + (h * 32 + g * 8) * 2) = act && wr ? __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7) : z8;
+          bfx8 gk = act && wr ? __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7) : z8;
+          if constexpr (NB) {
+            // norm-backward reduce: second tile = the norm's input at the same voxels (exact copy); first tile = g = dy * act'(x*sc + sh)
+            const bfx8 xv = act && wr ? __builtin_bit_cast(bfx8, nbx[j][h]) : z8;
+            if (a.nb_act != AM_ACT_NONE) {
+              const int co = co0 + h * 32 + g * 8;
+              const f32x4 sc0 = *(const f32x4*)(a.nb_scale + co), sc1 = *(const f32x4*)(a.nb_scale + co + 4);
+              const f32x4 sh0 = *(const f32x4*)(a.nb_shift + co), sh1 = *(const f32x4*)(a.nb_shift + co + 4);
+              typedef __attribute__((ext_vector_type(8))) float f32x8;
+              const f32x8 xf = __builtin_convertvector(xv, f32x8);
+              f32x8 gf = __builtin_convertvector(gk, f32x8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = xf[e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
+                const float dg = a.nb_act == AM_ACT_LRELU ? (z > 0.f ? 1.f : 0.01f) : ((z > 0.f && z < 6.f) ? 1.f : 0.f);
+                gf[e] *= dg;
+              }
+              gk = __builtin_convertvector(gf, bfx8);
+            }
+            *(bfx8*)(lds + v * SRS + 2 * NT + (h * 32 + g * 8) * 2) = xv;
+          }
+          *(bfx8*)(lds + v * SRS + (h * 32 + g * 8) * 2) = gk;
         }
       }
     }
@@ -347,8 +389,14 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + v1 * SRS + (16 * i + 4 * p) * 2));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + (v1 + 16) * SRS + (16 * i + 4 * p) * 2));
           const bfx8 f = __builtin_bit_cast(bfx8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+          bfx8 f2 = f;
+          if constexpr (NB) {                            // norm-backward reduce: diag(G x X^T) instead of diag(F x F^T)
+            const s16x4 xlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + v1 * SRS + 2 * NT + (16 * i + 4 * p) * 2));
+            const s16x4 xhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + (v1 + 16) * SRS + 2 * NT + (16 * i + 4 * p) * 2));
+            f2 = __builtin_bit_cast(bfx8, s16x8{xlo[0], xlo[1], xlo[2], xlo[3], xhi[0], xhi[1], xhi[2], xhi[3]});
+          }
           s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, ones, s1, 0, 0, 0);
-          s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, s2, 0, 0, 0);
+          s2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f2, s2, 0, 0, 0);
         }
         // D row 4g+r = channel, col r16: the diagonal element of channel c = 16i + r16 sits in the lane with r16 >> 2 == g, at r = r16 & 3
         if ((r16 >> 2) == g && co0 + 16 * i + r16 < a.Cout) {
@@ -386,10 +434,10 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
   }
 }
 
-template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false>
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false>
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
-  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS, HR>;
+  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS, HR, NB>;
   static std::once_flag lds_cap;                  // per instantiation, thread-safe: lift the 48 KB dynamic-LDS default to the CU's 160 KB
   std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   if (P.lds > 160 * 1024) return -3;
@@ -402,6 +450,14 @@ int launch(Plan& P, hipStream_t st) {
 template <typename T, int NS>
 int dispatch_nit(Plan& P, int shape, hipStream_t st) {
   const int n = P.nit;
+  if (P.a.nb_x) {                                // norm-backward-reduce variants: the k3 s1 plans (one unit), bf16
+    if constexpr (sizeof(T) == 2) {
+      if (P.tgs != 3 || P.a.OS != 1) return -7;
+      if (shape == 2) return n <= 4 ? launch<T, 4, 4, 4, NS, 4, 3, false, true>(P, st) : -7;
+      if (shape == 1) return n > 7 && n <= 11 ? (P.a.hreuse ? launch<T, 4, 4, 16, NS, 11, 3, true, true>(P, st) : launch<T, 4, 4, 16, NS, 11, 3, false, true>(P, st)) : -7;
+      return n > 7 && n <= 11 ? launch<T, 4, 8, 8, NS, 11, 3, false, true>(P, st) : -7;
+    } else return -7;
+  }
   if (P.tgs == 2) {                              // multi-unit plans: sub-bricks of at most (BD+1)(BH+1)(BW+1) voxels
     if (shape == 2) return n <= 4 ? launch<T, 4, 4, 4, NS, 4, 2>(P, st) : -3;
     if (shape == 1) return n <= 4 ? launch<T, 4, 4, 16, NS, 4, 2>(P, st) : n <= 7 ? launch<T, 4, 4, 16, NS, 7, 2>(P, st) : -3;
@@ -480,16 +536,17 @@ extern "C" int am_conv3d_partials_rows(int mode, int dtype, int ksize, int strid
   return 0;
 }
 
-extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed,
-                         const float* bias, void* y, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo,
-                         int Cout, const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift,
-                         int fd, int fh, int fw, int accumulate, float* partials, const float* ep_scale, const float* ep_shift,
-                         const void* ep_res, int ep_act, const int32_t* active_list, int n_active, int* partial_rows_written,
-                         void* stream) {
+static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed,
+                       const float* bias, void* y, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo,
+                       int Cout, const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift,
+                       int fd, int fh, int fw, int accumulate, float* partials, const float* ep_scale, const float* ep_shift,
+                       const void* ep_res, int ep_act, const int32_t* active_list, int n_active, int* partial_rows_written,
+                       const void* nb_x, const float* nb_scale, const float* nb_shift, int nb_act, void* stream) {
   if (Cin % 8 || Cout % 8) return -1;
   if (ep_scale && !ep_shift) return -1;
   Plan P;
   ConvArgs& a = P.a;
+  a.nb_x = nb_x; a.nb_scale = nb_scale; a.nb_shift = nb_shift; a.nb_act = nb_act;
   // ---- thin layers with everything resident in LDS: conv_rw.hip ----
   {
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;
@@ -504,7 +561,7 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
     { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (getenv("AM_CV_NORW")) goto generic;
 #endif
-    const int rc = conv_rw_launch(mode, dtype, ksize, stride, a, active_list, n_active, stream);
+    const int rc = nb_x ? 0 : conv_rw_launch(mode, dtype, ksize, stride, a, active_list, n_active, stream);   // (the fused reduce lives in conv_igemm_kernel only)
     if (rc < 0) return rc;
     if (rc == 1) {
       if (partial_rows_written) *partial_rows_written = conv_rw_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_mask != nullptr, out_bshift, n_active);
@@ -537,9 +594,41 @@ generic:
 #ifdef AM_ABLATE
   { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
+  if (nb_x) {                                            // two [voxel][channel] tiles in the epilogue (g and the norm's input)
+    const size_t tiles = (size_t)P.bd * P.bh * P.bw * (P.nt_tile * 4 + 32);
+    if (P.lds < tiles) P.lds = tiles;
+  }
   // outputs far larger than the 256 MB Infinity Cache bypass it (measured +2.5 % on the 1 GB decoder tensors: the halo re-reads keep L2)
   a.nt_store = ((size_t)B * Do * Ho * Wo * Cout * 2 >= ((size_t)384 << 20) && !accumulate) || AM_DBG(a, 8);
   hipStream_t st = (hipStream_t)stream;
   if (partial_rows_written) *partial_rows_written = a.B * a.nbd * a.nbh * a.nbw * a.nclass;
   return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, shape, st) : dispatch<float>(P, shape, st);
+}
+
+extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed,
+                         const float* bias, void* y, int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo,
+                         int Cout, const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift,
+                         int fd, int fh, int fw, int accumulate, float* partials, const float* ep_scale, const float* ep_shift,
+                         const void* ep_res, int ep_act, const int32_t* active_list, int n_active, int* partial_rows_written,
+                         void* stream) {
+  return conv3d_impl(mode, dtype, ksize, stride, x, w_packed, bias, y, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, in_mask, in_bshift, out_mask,
+                     out_bshift, fd, fh, fw, accumulate, partials, ep_scale, ep_shift, ep_res, ep_act, active_list, n_active,
+                     partial_rows_written, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// A data-gradient (or any) convolution whose output y is the gradient wrt a = act(nb_x * nb_scale + nb_shift), the output of a
+// norm + activation: the launch also leaves, per workgroup and channel, (sum g, sum g * nb_x) with g = y * act'(.) in `partials`
+// -- what am_norm_bwd_reduce would compute in a pass of its own over y and nb_x (am_norm_bwd_from_partials turns the rows into
+// the k0 / k1 / k2 coefficients and the affine gradients).  bf16 only; nb_x has y's shape and layout.
+extern "C" int am_conv3d_nbred(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed, void* y, int B, int Di,
+                               int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, const uint8_t* in_mask, int in_bshift,
+                               const uint8_t* out_mask, int out_bshift, int fd, int fh, int fw, int accumulate, float* partials,
+                               const void* nb_x, const float* nb_scale, const float* nb_shift, int nb_act,
+                               int* partial_rows_written, void* stream) {
+  if (dtype != AM_DT_BF16 || !partials || !nb_x) return -1;
+  if (nb_act != AM_ACT_NONE && (!nb_scale || !nb_shift)) return -1;
+  if (nb_act != AM_ACT_NONE && nb_act != AM_ACT_LRELU && nb_act != AM_ACT_RELU6) return -1;
+  return conv3d_impl(mode, dtype, ksize, stride, x, w_packed, nullptr, y, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, in_mask, in_bshift, out_mask,
+                     out_bshift, fd, fh, fw, accumulate, partials, nullptr, nullptr, nullptr, AM_ACT_NONE, nullptr, 0,
+                     partial_rows_written, nb_x, nb_scale, nb_shift, nb_act, stream);
 }

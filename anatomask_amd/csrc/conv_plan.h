@@ -8,6 +8,9 @@ namespace amconv {
 struct ConvArgs {
   const void* x; const void* w; const float* bias; void* y; float* partials;
   const float* ep_scale; const float* ep_shift; const void* ep_res; int ep_act;   // fused epilogue: act(conv * scale + shift + res)
+  // norm-backward reduce fused into a data-gradient launch (bf16): y is the gradient wrt a = act(nb_x * nb_scale + nb_shift); the
+  // partial rows then hold (sum g, sum g * nb_x) with g = y * act'(.) instead of (sum y, sum y^2)  -- am_conv3d_nbred
+  const void* nb_x; const float* nb_scale; const float* nb_shift; int nb_act;
   int B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, Cinp, Coutp;
   int OS, GS, nclass, nunit;  // output stride (parity classes), global source stride, #classes (grid.z), #units
   int nbd, nbh, nbw;          // bricks per dim of the q grid

@@ -1467,7 +1467,11 @@ __global__ __launch_bounds__(256) void partials_finalize_kernel(const float* __r
                                                                 double* __restrict__ ws, const double* count_ptr, double count_host,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                                 float* mean, float* rstd, float* scale, float* shift, float* run_mean,
-                                                                float* run_var, float momentum, long* nbt, float* sum_accum) {
+                                                                float* run_var, float momentum, long* nbt, float* sum_accum,
+                                                                const float* bw_mean, const float* bw_rstd, float* k0, float* k1, float* k2,
+                                                                float* dgamma, float* dbeta, float* dbeta2) {
+  // (k0 != nullptr: the rows are (sum g, sum g*x) of a fused norm-backward reduce, am_conv3d_nbred: the tail computes the backward
+  // coefficients and the affine gradients instead of forward statistics)
   // The rows are a real stream (a 128^3 conv at batch 16 leaves 131 072 rows x 64 channels x 8 B = 67 MB): up to 2048 workgroups, a
   // thread reads 16 bytes = (sum, sumsq) of TWO channels per row, four rows in flight, and the per-workgroup sums go to one of
   // AM_FIN_REP replicas (two thousand workgroups adding into the same cache lines serialise in L2).  The first version (256
@@ -1518,6 +1522,15 @@ __global__ __launch_bounds__(256) void partials_finalize_kernel(const float* __r
       q2 += __longlong_as_double(atomicExch((unsigned long long*)&ws[(size_t)r * 2 * C + 2 * c + 1], 0ull));
     }
     if (sum_accum) sum_accum[c] += (float)q1;
+    if (k0) {                                                  // bsum of norm_bwd_reduce: b1 = sum g, b2 = sum g * xhat = rstd * (sum g*x - mean * sum g)
+      const double b1 = q1, b2 = (double)bw_rstd[c] * (q2 - (double)bw_mean[c] * q1);
+      const float gr = gamma[c] * bw_rstd[c];
+      k0[c] = gr; k1[c] = gr * (float)(b1 / n); k2[c] = gr * (float)(b2 / n);
+      if (dgamma) dgamma[c] += (float)b2;
+      if (dbeta) dbeta[c] += (float)b1;
+      if (dbeta2) dbeta2[c] += (float)b1;
+      continue;
+    }
     if (!gamma) continue;
     const double m = q1 / n;
     double var = q2 / n - m * m;
@@ -1943,7 +1956,26 @@ int am_partials_finalize(const float* partials, int rows, int C, double* workspa
   const int rpb = ((rows + nb - 1) / nb + rstep - 1) / rstep * rstep;
   nb = (rows + rpb - 1) / rpb;
   AM_LAUNCH(partials_finalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, partials, rows, C, rpb, workspace, count_ptr, count_host,
-            gamma, beta, eps, mean, rstd, scale, shift, run_mean, run_var, momentum, num_batches_tracked, sum_accum);
+            gamma, beta, eps, mean, rstd, scale, shift, run_mean, run_var, momentum, num_batches_tracked, sum_accum,
+            (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+// rows of am_conv3d_nbred (sum g, sum g*x per workgroup and channel) -> k0 / k1 / k2 of am_norm_bwd_apply + the affine gradients:
+// replaces am_norm_bwd_reduce (+ finalize) for a norm whose output gradient came out of that launch.  Same workspace contract as
+// am_partials_finalize (zero on entry, left zero).
+int am_norm_bwd_from_partials(const float* partials, int rows, int C, double* workspace, const double* count_ptr, double count_host,
+                              const float* gamma, const float* mean, const float* rstd, float* k0, float* k1, float* k2,
+                              float* dgamma, float* dbeta, float* dbeta2, void* stream) {
+  if (C <= 0 || C > 4096 || C % 2 || rows <= 0 || !workspace || !gamma || !mean || !rstd || !k0 || !k1 || !k2) return -1;
+  const int cp = C / 2, rstep = cp <= 256 ? 256 / cp : 1;
+  int nb = rows / (rstep * 8); nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+  const int rpb = ((rows + nb - 1) / nb + rstep - 1) / rstep * rstep;
+  nb = (rows + rpb - 1) / rpb;
+  AM_LAUNCH(partials_finalize_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, partials, rows, C, rpb, workspace, count_ptr, count_host,
+            gamma, (const float*)nullptr, 0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+            0.f, (long*)nullptr, (float*)nullptr, mean, rstd, k0, k1, k2, dgamma, dbeta, dbeta2);
   AM_CHECK_LAUNCH();
   return 0;
 }

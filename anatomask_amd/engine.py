@@ -392,10 +392,16 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
         dc2 = ops.norm_backward(g, None, t["c2"], t["st2"], W[f"{q}.conv.4.weight"], ACT_NONE, None, 0,
                                 G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"])
         so = tuple(t["r"].shape[1:4])
-        dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1)
+        # (bf16) the reduce pass of the BatchNorm backward rides in this dgrad's epilogue: dr and c1 are not re-read for it.  Only where
+        # the dgrad contracts >= 128 channels: the epilogue's work per output tile is fixed (64 activation derivatives per lane), and
+        # on the 32- / 64-channel levels it costs as much as the pass it replaces (32->64 @128^3: 4.15 -> 5.61 ms for a 1.7 ms pass)
+        fuse = ops.FUSED_NORM_BWD_REDUCE and dc2.dtype == torch.bfloat16 and t["st1"].sync_world <= 1 and dc2.shape[-1] >= 128
+        dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1,
+                        norm_bwd=(t["c1"], t["st1"], ACT_RELU6) if fuse else None)
+        dr, red1 = dr if fuse else (dr, None)
         _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
         dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
-                                G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"])
+                                G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"], reduced=red1)
         du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
         ptu.finalize(None, sum_accum=G[f"{q}.up_sample.bias"])  # ConvT bias gradient = per-channel sum of du
         _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
@@ -461,9 +467,10 @@ def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: M
             sp = tuple(y2.shape[1:4])
             da1 = ops.conv3d(CONV_DGRAD, dy2, pk.get(W, f"{p}.conv2.weight", False, True), None, sp, 3, 1,
                              in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
+            red1 = None           # (the fused norm-backward reduce, ops.conv3d(norm_bwd=...), does not pay on block-sparse tensors: 64->64 @64^3 +0.12 ms for a 0.05 ms pass)
             _wgrad_into(G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
             dy1 = ops.norm_backward(da1, None, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
-                                    G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"])
+                                    G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"], reduced=red1)
             stride = t["stride"]
             if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only
                 ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None)

@@ -107,6 +107,14 @@ class ConvPartials:
         st.nrep = 1
 
 
+    def finalize_bwd(self, st: "NormStats", gamma: torch.Tensor, sc: "NormBwdScratch", dgamma=None, dbeta=None, dbeta2=None):
+        """rows of a conv3d(norm_bwd=...) launch -> k0 / k1 / k2 of the apply pass + the affine gradients (am_norm_bwd_from_partials)."""
+        ws = _stats_workspace(self.t.device, self.C)
+        hip.lib().norm_bwd_from_partials(self.t.data_ptr(), self.rows, self.C, ws.data_ptr(), _p(st.count_ptr), float(st.count_host),
+                                         gamma.data_ptr(), st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(),
+                                         sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dbeta2), _stream())
+
+
 _WS = {}
 
 
@@ -186,8 +194,11 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
            ksize: int, stride: int, in_mask: Optional[MaskInfo] = None, in_bshift: int = 0,
            out_mask: Optional[MaskInfo] = None, out_bshift: int = 0, out: Optional[torch.Tensor] = None,
            accumulate: bool = False, want_partials: bool = False, ep_scale: Optional[torch.Tensor] = None,
-           ep_shift: Optional[torch.Tensor] = None, ep_res: Optional[torch.Tensor] = None, ep_act: int = 0):
-    """ep_*: fused store epilogue y = act(conv * scale + shift + res) (eval-mode BatchNorm / skip add / activation)."""
+           ep_shift: Optional[torch.Tensor] = None, ep_res: Optional[torch.Tensor] = None, ep_act: int = 0,
+           norm_bwd: Optional[tuple] = None):
+    """ep_*: fused store epilogue y = act(conv * scale + shift + res) (eval-mode BatchNorm / skip add / activation).
+    norm_bwd = (x_pre, st, act): the output is the gradient wrt act(norm(x_pre)); the launch also leaves the norm-backward sums in
+    its partial rows (am_conv3d_nbred) -> returns (out, rows) for norm_backward(..., reduced=rows).  bf16 only."""
     B, Di, Hi, Wi, Cin = x.shape
     Cout, Kl = w_packed.logical
     assert Kl == Cin and w_packed.dtype == x.dtype, (w_packed.logical, x.shape)
@@ -196,6 +207,19 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     mp, fd, fh, fw = _mk(mk)
     # thin block-sparse layers (Cin <= 32) run on the resident-weight kernel, which walks the active-patch list
     alp, aln = _al(out_mask) if (out_mask is not None and out_mask is in_mask and Cin <= 32 and x.dtype == torch.bfloat16) else (None, 0)
+    if norm_bwd is not None:
+        xp, st, nact = norm_bwd
+        assert x.dtype == torch.bfloat16 and xp.dtype == torch.bfloat16 and tuple(xp.shape) == (B, Do, Ho, Wo, Cout) and bias is None
+        part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift, _dt(x), 64, 0)   # (cin 64: the generic kernel's row count)
+        if out is None:
+            out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
+        hip.lib().conv3d_nbred(mode, _dt(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), out.data_ptr(),
+                               B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
+                               in_mask.t.data_ptr() if in_mask else None, in_bshift,
+                               out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate),
+                               part.t.data_ptr(), xp.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), int(nact), _ROWS_ADDR, _stream())
+        part.rows = _ROWS_OUT.value
+        return out, part
     part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift, _dt(x), Cin, aln) if want_partials else None
     if out is None:
         out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
@@ -337,15 +361,26 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
                   mask: Optional[MaskInfo], bshift: int, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
                   dtoken: Optional[torch.Tensor] = None, fill: bool = False, dx: Optional[torch.Tensor] = None,
                   dres: Optional[torch.Tensor] = None, scratch: Optional[NormBwdScratch] = None,
-                  dbeta2: Optional[torch.Tensor] = None, dxsum: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  dbeta2: Optional[torch.Tensor] = None, dxsum: Optional[torch.Tensor] = None,
+                  reduced: Optional[ConvPartials] = None) -> torch.Tensor:
     """Backward of y = act(norm(x) [+res]) (or the densify fill).  Returns dx; accumulates dgamma/dbeta/dtoken.
-    out=None with an activation (layers WITHOUT a residual): the derivative comes from the recomputed x*st.scale + st.shift."""
+    out=None with an activation (layers WITHOUT a residual): the derivative comes from the recomputed x*st.scale + st.shift.
+    reduced: the partial rows of the conv3d(norm_bwd=(x, st, act)) launch that produced dout -- the reduce pass is skipped."""
     B, D, H, W, Cc = x.shape
     sc = scratch or NormBwdScratch(Cc, x.device)
     mp, fd, fh, fw = _mk(mask)
     L = hip.lib()
     s = _stream()
     ws_b, ws_x = _bwd_workspaces(x.device, Cc)
+    if reduced is not None:
+        assert st.sync_world <= 1 and out is None and dtoken is None and not fill
+        reduced.finalize_bwd(st, gamma, sc, dgamma, dbeta, dbeta2)
+        if dx is None:
+            dx = torch.empty_like(x)
+        L.norm_bwd_apply(_dt(x), dout.data_ptr(), None, x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
+                         st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
+                         dx.data_ptr(), _p(dres), _p(dxsum), ws_x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), *_al(mask), 1, s)
+        return dx
     if st.sync_world > 1:
         # SyncBatchNorm backward (torch.nn.SyncBatchNorm): dx needs the sums over the GLOBAL batch, the affine gradients stay LOCAL
         # sums (DDP then averages them like every other gradient): reduce -> finalize (param grads) -> all-reduce -> finalize (k's)
@@ -392,6 +427,9 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
 
 _BWS = {}
 FUSED_BWD_TAILS = True
+# bf16: the norm-backward reduce of a data gradient rides in the dgrad's epilogue (am_conv3d_nbred).  Measured neutral on the STUNet-B
+# step (143.0 vs 142.7-143.3 ms, tools/step_ab.py ops.FUSED_NORM_BWD_REDUCE=1,0; profiles/r02_experiments.md), so it stays off.
+FUSED_NORM_BWD_REDUCE = False
 
 
 def _bwd_workspaces(device, C: int):

@@ -58,6 +58,16 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               (Cin <= 32) run on persistent workgroups that walk only the active bricks with all weights resident in LDS */,
               int* partial_rows_written /* NULL or (host) the number of partials rows this launch wrote (<= am_conv3d_partials_rows) */,
               void* stream);
+/* am_conv3d whose output y is the gradient wrt a = act(nb_x * nb_scale + nb_shift) -- the output of a norm + activation
+ * (P/decoder3D.py:20-22 BatchNorm3d + ReLU6, P/STUNet_head.py:96-103 InstanceNorm3d + LeakyReLU): the launch also leaves, per
+ * workgroup and channel, (sum g, sum g * nb_x) with g = y * act'(.) in `partials` [rows][Cout][2] -- the sums autograd's norm
+ * backward needs, without a pass of its own over y and nb_x.  bf16 only; nb_x has y's shape and layout; nb_act AM_ACT_NONE needs
+ * no nb_scale / nb_shift.  Follow with am_norm_bwd_from_partials. */
+int am_conv3d_nbred(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed, void* y, int B, int Di,
+                    int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, const uint8_t* in_mask, int in_bshift,
+                    const uint8_t* out_mask, int out_bshift, int fd, int fh, int fw, int accumulate, float* partials,
+                    const void* nb_x, const float* nb_scale, const float* nb_shift, int nb_act,
+                    int* partial_rows_written, void* stream);
 int am_packed_dims(int dtype, int rows, int k, int* rows_padded, int* k_padded);
 int am_conv3d_partials_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout,
                             int out_sparse, int out_bshift /* the launch's out_mask != NULL and its block shift: they select the brick */,
@@ -131,6 +141,12 @@ int am_norm_finalize(const double* sums, int nrep /* AM_NREP after am_chan_stats
 int am_partials_finalize(const float* partials, int rows, int C, double* workspace, const double* count_ptr, double count_host,
                          const float* gamma, const float* beta, float eps, float* mean, float* rstd, float* scale, float* shift,
                          float* run_mean, float* run_var, float momentum, long* num_batches_tracked, float* sum_accum, void* stream);
+/* The rows of am_conv3d_nbred -> the coefficients of am_norm_bwd_apply (k0 = gamma*rstd, k1 = k0 * mean(g), k2 = k0 * mean(g*xhat))
+ * and the affine gradients (dgamma += sum g*xhat, dbeta += sum g, dbeta2 likewise or NULL): what am_norm_bwd_reduce +
+ * am_norm_bwd_finalize produce.  workspace: as am_partials_finalize (zero on entry, left zero). */
+int am_norm_bwd_from_partials(const float* partials, int rows, int C, double* workspace, const double* count_ptr, double count_host,
+                              const float* gamma, const float* mean, const float* rstd, float* k0, float* k1, float* k2,
+                              float* dgamma, float* dbeta, float* dbeta2, void* stream);
 int am_norm_fold_running(int C, const float* gamma, const float* beta, const float* run_mean, const float* run_var, float eps,
                          float* scale, float* shift, void* stream);   /* eval-mode BN (teacher) */
 /* y = act(x*scale + shift [+ res] [+ stem_w*stem_x + stem_b]); fill != NULL: inactive voxels := mask token

@@ -165,6 +165,54 @@ def test_conv_wgrad_stride2_full_resolution_bricks(ops, case, det):
     close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (stride 2, full-resolution bricks)")
 
 
+@pytest.mark.parametrize("case", [(64, 32, "relu6", False), (64, 64, "lrelu", True), (128, 64, "none", False), (32, 32, "lrelu", True), (40, 72, "relu6", False)])
+def test_conv_dgrad_with_fused_norm_backward_reduce(ops, case):
+    """am_conv3d_nbred: a data-gradient launch whose output is the gradient wrt act(norm(x_pre)) leaves the norm-backward sums
+    (sum g, sum g*x_pre per workgroup and channel) in its partial rows; norm_backward(..., reduced=rows) must give the same dx and
+    affine gradients as the stand-alone reduce pass over the same tensors (bf16: the sums see g rounded to bf16)."""
+    cdy, cdx, actn, sparse = case                        # forward conv cdx -> cdy; its dgrad produces a cdx-channel gradient
+    act = {"relu6": ops.ACT_RELU6, "lrelu": ops.ACT_LRELU, "none": ops.ACT_NONE}[actn]
+    dtype = torch.bfloat16
+    B, f, bs = 2, (2, 2, 4), 2
+    so = tuple(v << bs for v in f)                       # (8, 8, 16)
+    mask = mk_mask(B, f, 13) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    mo = O.upsample_mask(mask, so).float() if sparse else None
+    w = q(rnd(cdy, cdx, 3, 3, 3, seed=2, scale=1.0 / np.sqrt(cdx * 27)), dtype)
+    dy = q(rnd(B, cdy, *so, seed=4), dtype)
+    xp = q(rnd(B, cdx, *so, seed=5) * 1.5 + 0.7, dtype)  # the norm's input (a conv output): off-centre on purpose
+    if sparse:
+        dy, xp = dy * mo, xp * mo
+    gam = (torch.rand(cdx, generator=torch.Generator().manual_seed(6)) + 0.5).to(DEV)
+    bet = (torch.rand(cdx, generator=torch.Generator().manual_seed(7)) - 0.5).to(DEV)
+    xd = to_cl(xp, dtype)
+    st = ops.NormStats(cdx, DEV)
+    if sparse:
+        cnt = torch.zeros(1, device=DEV, dtype=torch.float64); ops.mask_count(mi, (1 << bs) ** 3, cnt); st.count_ptr = cnt
+    else:
+        st.count_host = float(B * so[0] * so[1] * so[2])
+    ops.chan_stats(xd, mi, bs if sparse else 0, st)
+    ops.norm_finalize(st, gam, bet, 1e-5)
+    wpd = ops.pack_weight(w.to(DEV), dtype, transposed_conv=False, for_dgrad=True)
+    kw = dict(in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs) if sparse else {}
+    # reference route: plain dgrad, then the stand-alone reduce + apply
+    dz = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), wpd, None, so, 3, 1, **kw)
+    dg0, db0 = torch.zeros(cdx, device=DEV), torch.zeros(cdx, device=DEV)
+    dx0 = ops.norm_backward(dz, None, xd, st, gam, act, mi, bs if sparse else 0, dg0, db0)
+    # fused route
+    dz1, rows = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), wpd, None, so, 3, 1, norm_bwd=(xd, st, act), **kw)
+    if sparse:                                           # (bricks without an active voxel are never written)
+        keep = to_cl(mo.expand(B, cdx, *so), dtype) > 0
+        assert torch.equal(torch.where(keep, dz1, torch.zeros_like(dz1)), torch.where(keep, dz, torch.zeros_like(dz)))
+    else:
+        assert torch.equal(dz1, dz)
+    dg1, db1 = torch.zeros(cdx, device=DEV), torch.zeros(cdx, device=DEV)
+    dx1 = ops.norm_backward(dz1, None, xd, st, gam, act, mi, bs if sparse else 0, dg1, db1, reduced=rows)
+    close(db1.cpu(), db0.cpu(), 4e-3, "dbeta (fused reduce)")
+    close(dg1.cpu(), dg0.cpu(), 4e-3, "dgamma (fused reduce)")
+    close(from_cl(dx1), from_cl(dx0), 1e-2, "dx (fused reduce)", mo)
+
+
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, False), (32, 32, 3, 1, True), (32, 64, 3, 2, True), (16, 24, 1, 2, False), (64, 64, 4, 2, False)])
 def test_conv_wgrad_deterministic_mode(ops, case):
     """det_workspace: per-slot partial sums folded in slot order instead of fp32 atomics -> bit-identical from run to run (the
