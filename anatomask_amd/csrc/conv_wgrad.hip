@@ -15,6 +15,10 @@
 // Partial sums leave the workgroup as f32 atomics into the packed [tap][cy][cx] gradient
 // (64-byte runs per 16 lanes; order-dependent in the last bits, like any split-K atomic reduce), or -- deterministic mode, a
 // caller-provided workspace -- as plain stores of one partial sum per brick-walk slot that a second kernel folds in slot order.
+// Brick shapes and walks: dense bf16 k3 s1 takes one-plane 1x8x16 bricks walked d-fastest, the columns of an XCD's slots interleaved
+// (HBM sees x and dY ~1.26 times instead of 2.15); bf16 k3 s2 on grids >= 16 wide stages X at full resolution, one unit per d-tap
+// (kernel variant S2); everything else walks contiguous w-fastest runs of 2x4x16 / 2x8x8 bricks.  Block-sparse launches keep the
+// current sample's patch masks in LDS.
 #include <mutex>
 #include <stdlib.h>
 #include "common.h"
