@@ -288,19 +288,36 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
   }
   const bool fused = a.ep_scale != nullptr || a.ep_res != nullptr || a.ep_act != AM_ACT_NONE;   // (uniform) eval-mode norm / residual / activation
   const T* __restrict__ resg = (const T*)a.ep_res;
-  auto ep = [&](f32x4 o, int i, const T* res, bool ok) {
-    if (a.ep_scale && ok) {
-      const int co = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
-      o = o * *(const f32x4*)(a.ep_scale + co) + *(const f32x4*)(a.ep_shift + co);
-    }
-    if (res && ok) {
+  // the lane's per-channel scale / shift are fetched ONCE, like the bias (as conditional loads inside the store loop they were 32
+  // dependent round trips per lane: the teacher's eval-BatchNorm decoder convs ran 17 % slower than the student's)
+  f32x4 esc[NS], esh[NS];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] += TT<T>::ld(res + r);
+  for (int i = 0; i < NS; ++i) {
+    const int co = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
+    const bool okc = a.ep_scale && co < a.Cout;
+    esc[i] = okc ? *(const f32x4*)(a.ep_scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+    esh[i] = okc ? *(const f32x4*)(a.ep_shift + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float act_slope = a.ep_act == AM_ACT_LRELU ? 0.01f : (a.ep_act == AM_ACT_RELU6 ? 0.f : 1.f);
+  const float act_hi = a.ep_act == AM_ACT_RELU6 ? 6.f : __builtin_inff();
+  // 8 consecutive channels of a tensor shaped like y, as two f32x4: ONE 16-byte load for bf16 (element-wise 2-byte loads before)
+  auto load8 = [&](const T* p, f32x4& lo, f32x4& hi) {
+    if constexpr (sizeof(T) == 4) { lo = *(const f32x4*)p; hi = *(const f32x4*)(p + 4); }
+    else {
+      typedef __attribute__((ext_vector_type(8))) __bf16 bfx8_;
+      typedef __attribute__((ext_vector_type(8))) float f32x8_;
+      const f32x8_ f = __builtin_convertvector(*(const bfx8_*)p, f32x8_);
+      lo = f32x4{f[0], f[1], f[2], f[3]}; hi = f32x4{f[4], f[5], f[6], f[7]};
     }
+  };
+  auto ep = [&](f32x4 o, int i, f32x4 radd) {
+    if (a.ep_scale) o = o * esc[i] + esh[i];
+    o += radd;
+    // act(v) = min(max(v, slope * v), hi) with (slope, hi) = (1, inf) none / (0.01, inf) LeakyReLU / (0, 6) ReLU6: four instructions
+    // per value on uniform constants (a per-element `if (act == ...)` chain compiled to ~8 and cost the teacher's decoder convs 9 %)
+    if (a.ep_act != AM_ACT_NONE) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (a.ep_act == AM_ACT_RELU6) o[r] = fminf(fmaxf(o[r], 0.f), 6.f);
-      else if (a.ep_act == AM_ACT_LRELU) o[r] = o[r] > 0.f ? o[r] : 0.01f * o[r];
+      for (int r = 0; r < 4; ++r) { const float t = fmaxf(o[r], o[r] * act_slope); o[r] = t > act_hi ? act_hi : t; }   // (a NaN stays a NaN, as in torch)
     }
     return o;
   };
@@ -326,13 +343,15 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
       T* dst = dstv + h * 32;
       const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout && !AM_DBG(a, 1);     // Cout % 8 == 0 (C % 8 == 0 contract)
       if (fused) {
-        const T* rs = resg ? resg + (dst - yg) : nullptr;
-        o0 = ep(o0, 2 * h, rs, act && wr); o1 = ep(o1, 2 * h + 1, rs ? rs + 4 : nullptr, act && wr);
+        f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        if (resg && act && wr) load8(resg + (dst - yg), r0, r1);
+        o0 = ep(o0, 2 * h, r0); o1 = ep(o1, 2 * h + 1, r1);
       }
       if (sparse_out && !act) { o0 = f32x4{0.f, 0.f, 0.f, 0.f}; o1 = o0; }
       if (a.accumulate && act && wr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { o0[r] += TT<T>::ld(dst + r); o1[r] += TT<T>::ld(dst + 4 + r); }
+        f32x4 p0_, p1_;
+        load8(dst, p0_, p1_);
+        o0 += p0_; o1 += p1_;
       }
       if constexpr (sizeof(T) == 4) {
         if (wr) { *(f32x4*)dst = o0; *(f32x4*)(dst + 4) = o1; }
@@ -350,6 +369,7 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
             // norm-backward reduce: second tile = the norm's input at the same voxels (exact copy); first tile = g = dy * act'(x*sc + sh)
             const bfx8 xv = act && wr ? __builtin_bit_cast(bfx8, nbx[j][h]) : z8;
             if (a.nb_act != AM_ACT_NONE) {
+              const float nb_slope = a.nb_act == AM_ACT_LRELU ? 0.01f : 0.f, nb_hi = a.nb_act == AM_ACT_RELU6 ? 6.f : __builtin_inff();
               const int co = co0 + h * 32 + g * 8;
               const f32x4 sc0 = *(const f32x4*)(a.nb_scale + co), sc1 = *(const f32x4*)(a.nb_scale + co + 4);
               const f32x4 sh0 = *(const f32x4*)(a.nb_shift + co), sh1 = *(const f32x4*)(a.nb_shift + co + 4);
@@ -359,8 +379,7 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
 #pragma unroll
               for (int e = 0; e < 8; ++e) {
                 const float z = xf[e] * (e < 4 ? sc0[e & 3] : sc1[e & 3]) + (e < 4 ? sh0[e & 3] : sh1[e & 3]);
-                const float dg = a.nb_act == AM_ACT_LRELU ? (z > 0.f ? 1.f : 0.01f) : ((z > 0.f && z < 6.f) ? 1.f : 0.f);
-                gf[e] *= dg;
+                gf[e] *= (z > 0.f && z < nb_hi) ? 1.f : nb_slope;
               }
               gk = __builtin_convertvector(gf, bfx8);
             }

@@ -71,6 +71,10 @@ tr.step(x, epoch=500)
 e1.record()
 torch.cuda.synchronize()
 print(f"step (side stream off, instrumented): {e0.elapsed_time(e1):.1f} ms, {len(rec)} conv launches")
+if os.environ.get("AM_CENSUS_EACH"):               # every launch of the shapes that contain this substring, in issue order
+    for name, fl, a, b in rec:
+        if os.environ["AM_CENSUS_EACH"] in name:
+            print(f"   {name:44s} {a.elapsed_time(b):8.3f} ms {fl / a.elapsed_time(b) / 1e9:8.0f} TFLOP/s")
 agg = OrderedDict()
 for name, fl, a, b in rec:
     t = a.elapsed_time(b)
