@@ -41,7 +41,7 @@ namespace {
 // the START of the workgroup (32 more registers) -- loaded in the epilogue its HBM latency is exposed once per workgroup, which
 // for a one-slab data gradient (3.5 us of MFMAs) ate everything the fused reduce saves.
 template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false>
-__global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
   constexpr int MV = BD * BH * BW;
@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256, TGS == 2 ? 3 : 2) void conv_igemm_kernel(ConvA
           for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
 #pragma unroll
           for (int j = 0; j < VS; ++j) {
-            const u32x4 bf = *(const u32x4*)(lds + bb[j] + tob);
+            // (16-wide bricks with one d-plane per wave: subtile j is h-row j, so its offset is bb[0] + j rows -- no register per subtile)
+            const u32x4 bf = *(const u32x4*)(lds + ((BW == 16 && MV / 4 == BH * BW) ? bb[0] + j * (EW * LROWB) : bb[j]) + tob);
 #pragma unroll
             for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
           }
@@ -478,6 +479,7 @@ int dispatch_nit(Plan& P, int shape, hipStream_t st) {
     } else return -7;
   }
   if (P.tgs == 2) {                              // multi-unit plans: sub-bricks of at most (BD+1)(BH+1)(BW+1) voxels
+    if (shape == 3) return n <= 12 ? launch<T, 4, 8, 16, NS, 12, 2>(P, st) : -3;     // 512-voxel bricks (dense transposed convs)
     if (shape == 2) return n <= 4 ? launch<T, 4, 4, 4, NS, 4, 2>(P, st) : -3;
     if (shape == 1) return n <= 4 ? launch<T, 4, 4, 16, NS, 4, 2>(P, st) : n <= 7 ? launch<T, 4, 4, 16, NS, 7, 2>(P, st) : -3;
     return n <= 4 ? launch<T, 4, 8, 8, NS, 4, 2>(P, st) : n <= 7 ? launch<T, 4, 8, 8, NS, 7, 2>(P, st) : -3;
@@ -522,7 +524,7 @@ static int brick_shape(int os, int qw, bool out_sparse, int out_bshift, int* bd,
 // the channel tile (2x the workgroups, each still 4 subtiles x 2 channel tiles per wave = 24 MFMAs per weight group); only if
 // that still leaves most CUs idle do they drop to 64-voxel bricks (6 MFMAs per barrier: measured 151 us for the 512->512 conv
 // at 8^3 where the 256-voxel brick x 32 channels takes a third of that).
-static int pick_tiling(int os, int B, int qd, int qh, int qw, int Cout, bool out_sparse, int out_bshift, int* bd, int* bh, int* bw, int* nt) {
+static int pick_tiling(int os, int B, int qd, int qh, int qw, int Cout, bool out_sparse, int out_bshift, int* bd, int* bh, int* bw, int* nt, bool big_ok = true) {
   int shape = brick_shape(os, qw, out_sparse, out_bshift, bd, bh, bw);
   *nt = Cout <= 32 ? 32 : 64;
   const long q = (long)qd * qh * qw;
@@ -531,6 +533,11 @@ static int pick_tiling(int os, int B, int qd, int qh, int qw, int Cout, bool out
     *nt = 32;
     if (nwg(32) < 192 && shape != 2) { shape = 2; *bh = 4; *bw = 4; }
   }
+  // dense two-class-stride launches (ConvTranspose3d: 8 output parity classes of 8 taps) with plenty of workgroups: 4x8x16 bricks.
+  // A 4x4x16 workgroup of such a plan has only 128 MFMAs per wave and slab between its prologue and its 32 KB store (64->64
+  // @128^3: 731 TFLOP/s); twice the voxels halve the staging per MFMA (5x9x17 rows for 512 voxels: 1.49x, against 1.66x) and
+  // every weight fragment feeds 8 MFMAs instead of 4.
+  if (os == 2 && !out_sparse && shape == 1 && *nt == 64 && qh >= 8 && nwg(64) >= 4096 && big_ok) { shape = 3; *bh = 8; }
   return shape;
 }
 
@@ -591,8 +598,12 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
 generic:
 #endif
   const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
+  bool big_ok = true;
+#ifdef AM_ABLATE
+  if (getenv("AM_CV_NOBIG")) big_ok = false;
+#endif
   int shape = pick_tiling(os_, B, (Do + os_ - 1) / os_, (Ho + os_ - 1) / os_, (Wo + os_ - 1) / os_, Cout, out_mask != nullptr, out_bshift,
-                          &P.bd, &P.bh, &P.bw, &P.nt_tile);
+                          &P.bd, &P.bh, &P.bw, &P.nt_tile, big_ok);
   int rc = build_plan(P, mode, ksize, stride);
   if (rc) return rc;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;
@@ -613,6 +624,10 @@ generic:
 #ifdef AM_ABLATE
   { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
+  if (partials && dtype == AM_DT_BF16) {                 // the bf16 statistics epilogue lays the output tile out in LDS: [voxel][NT channels + 32 B]
+    const size_t tile = (size_t)P.bd * P.bh * P.bw * (P.nt_tile * 2 + 32);
+    if (P.lds < tile) P.lds = tile;                      // (only when asked for: 512-voxel bricks would lose their second workgroup per CU to it)
+  }
   if (nb_x) {                                            // two [voxel][channel] tiles in the epilogue (g and the norm's input)
     const size_t tiles = (size_t)P.bd * P.bh * P.bw * (P.nt_tile * 4 + 32);
     if (P.lds < tiles) P.lds = tiles;

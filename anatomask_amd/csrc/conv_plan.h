@@ -125,10 +125,6 @@ inline int build_plan(Plan& P, int mode, int k, int stride) {
   a.w_lds_off = (int)brick;
   P.tgs = a.nunit > 1 ? 2 : 3;
   P.lds = a.w_lds_off + 2 * TG_OF(P.nt_tile / 16, P.tgs) * P.nt_tile * ROWB;
-  {                                                      // the bf16 statistics epilogue lays the output tile out in LDS: [voxel][NT channels + 32 B]
-    const size_t tile = (size_t)P.bd * P.bh * P.bw * (P.nt_tile * 2 + 32);
-    if (P.lds < tile) P.lds = tile;
-  }
   return 0;
 }
 

@@ -324,6 +324,21 @@ def test_conv_transpose(ops, dtype, ch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_transpose_512_voxel_bricks(ops, dtype):
+    """Dense transposed convolutions with >= 4096 workgroups of the 4x4x16 plan take 4x8x16 q-bricks (conv_igemm.hip pick_tiling
+    shape 3): a grid large enough to trigger them, with extents that are not brick multiples in any dimension."""
+    cin, cout, B, si = 64, 64, 4, (15, 33, 64)
+    so = tuple(2 * v for v in si)
+    x = q(rnd(B, cin, *si, seed=1), dtype)
+    w = q(rnd(cin, cout, 4, 4, 4, seed=2, scale=1.0 / np.sqrt(cin * 8)), dtype)
+    bias = rnd(cout, seed=3)
+    yr = F.conv_transpose3d(x, w, bias, stride=2, padding=1)
+    wp = ops.pack_weight(w.to(DEV), dtype, transposed_conv=True, for_dgrad=False)
+    y = ops.conv3d(ops.CONVT_FWD, to_cl(x, dtype), wp, bias.to(DEV), so, 4, 2)
+    close(from_cl(y), yr, TOL[dtype], "convT fwd (512-voxel bricks)")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_odd_extent(ops, dtype):
     """Grids that are not multiples of the 4x8x8 brick (the reference recipe's 7x7x8 stage-4 grid)."""
     B, cin, cout, sp = 1, 32, 48, (7, 7, 8)

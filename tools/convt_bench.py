@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anatomask_amd import ops  # noqa: E402
 
 dev = "cuda:0"
-B = 4
+B = int(os.environ.get("AM_CB_BATCH", "4"))
 
 
 def timed(fn, iters=20):
