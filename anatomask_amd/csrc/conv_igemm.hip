@@ -600,7 +600,7 @@ generic:
   const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
   bool big_ok = true;
 #ifdef AM_ABLATE
-  if (getenv("AM_CV_NOBIG")) big_ok = false;
+  { const char* e_ = getenv("AM_CV_NOBIG"); if (e_ && atoi(e_)) big_ok = false; }
 #endif
   int shape = pick_tiling(os_, B, (Do + os_ - 1) / os_, (Ho + os_ - 1) / os_, (Wo + os_ - 1) / os_, Cout, out_mask != nullptr, out_bshift,
                           &P.bd, &P.bh, &P.bw, &P.nt_tile, big_ok);
