@@ -13,11 +13,12 @@ from anatomask_amd.trainer import AnatoMaskTrainer  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda:0")
-kw = M.STUNET_CONFIGS["B"]
+SIZE, PATCH, MR = os.environ.get("AM_CENSUS_SIZE", "B"), int(os.environ.get("AM_CENSUS_PATCH", "128")), float(os.environ.get("AM_CENSUS_MASK", "0.6"))
+kw = M.STUNET_CONFIGS[SIZE]                      # AM_CENSUS_SIZE=L AM_CENSUS_PATCH=160 AM_CENSUS_MASK=0.7 python tools/conv_census.py 4
 torch.manual_seed(0)
-model = M.build_spark(kw["dims"], kw["depth"], kw["width"], (128,) * 3, 0.6, compute_dtype=torch.bfloat16).to(dev)
+model = M.build_spark(kw["dims"], kw["depth"], kw["width"], (PATCH,) * 3, MR, compute_dtype=torch.bfloat16).to(dev)
 tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=1)
-x = torch.randn(B, 1, 128, 128, 128, device=dev)
+x = torch.randn(B, 1, PATCH, PATCH, PATCH, device=dev)
 engine._USE_SIDE = False
 for _ in range(2):
     tr.step(x, epoch=500)
