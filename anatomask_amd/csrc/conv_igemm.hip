@@ -513,10 +513,14 @@ int dispatch(Plan& P, int shape, hipStream_t st) {
 // brick of q-space voxels per workgroup: 0 = 4x8x8 (narrow grids), 1 = 4x4x16, 2 = 4x4x4 (tiny grids, chosen by the caller).
 // Block-sparse outputs whose patches are 8 q-voxels wide take the 4x8x8 brick: it lies inside ONE patch, so 60 % of the bricks
 // are skipped outright (a 4x4x16 brick spans two patches and is empty only 36 % of the time).
-static int brick_shape(int os, int qw, bool out_sparse, int out_bshift, int* bd, int* bh, int* bw) {
+static int brick_shape(int os, int qh, int qw, bool out_sparse, int out_bshift, int* bd, int* bh, int* bw) {
   *bd = 4;
   const int qblock = out_sparse ? ((1 << out_bshift) / os) : 0;
-  if (qw >= 16 && qblock != 8) { *bh = 4; *bw = 16; return 1; }
+  // two-class-stride plans (transposed convs) on grids whose width is not a multiple of 16 (STUNet-L 160^3: q = 20; STUNet-H: 24, 12):
+  // the brick that pads the (h, w) plane less (ConvT 512->512 @40^3 627 -> 834 TFLOP/s).  The k3 s1 plans stay 16-wide whatever the
+  // padding: their h-run fragment reuse is worth more than the zero-operand MFMAs of the padding cost (512->512 @40^3: 1 094 vs 1 013)
+  const long pad16 = (long)((qh + 3) / 4 * 4) * ((qw + 15) / 16 * 16), pad8 = (long)((qh + 7) / 8 * 8) * ((qw + 7) / 8 * 8);
+  if (qw >= 16 && qblock != 8 && (os != 2 || pad16 * 100 <= pad8 * 108)) { *bh = 4; *bw = 16; return 1; }
   *bh = 8; *bw = 8; return 0;
 }
 
@@ -525,7 +529,7 @@ static int brick_shape(int os, int qw, bool out_sparse, int out_bshift, int* bd,
 // that still leaves most CUs idle do they drop to 64-voxel bricks (6 MFMAs per barrier: measured 151 us for the 512->512 conv
 // at 8^3 where the 256-voxel brick x 32 channels takes a third of that).
 static int pick_tiling(int os, int B, int qd, int qh, int qw, int Cout, bool out_sparse, int out_bshift, int* bd, int* bh, int* bw, int* nt, bool big_ok = true) {
-  int shape = brick_shape(os, qw, out_sparse, out_bshift, bd, bh, bw);
+  int shape = brick_shape(os, qh, qw, out_sparse, out_bshift, bd, bh, bw);
   *nt = Cout <= 32 ? 32 : 64;
   const long q = (long)qd * qh * qw;
   auto nwg = [&](int tile) { return (long)B * ((q + *bd * *bh * *bw - 1) / (*bd * *bh * *bw)) * ((Cout + tile - 1) / tile) * (os == 2 ? 8 : 1); };
