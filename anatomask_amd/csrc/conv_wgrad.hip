@@ -583,7 +583,10 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   if (s2full) nwx = 2;                                    // 32-channel X tiles: the 9 x 33 full-resolution rows stay at 96 bytes
   else if (bf && bw == 16 && mode == AM_CONV_FWD && (k == 3 || stride == 2)) {
     if (Cy <= 32 && stride == 1) mi = 2;
+    // dY channel counts that 64-wide tiles pad by a quarter or more (STUNet-H: 96 -> 128): 32-wide cy tiles (three for 96, no padding)
+    if (Cy > 64 && stride == 1 && ((Cy + 63) / 64 * 64 - Cy) * 4 >= Cy) mi = 2;
     if (Cx <= 32) nwx = 2;
+    else if (mi == 4 && Cx > 64 && ((Cx + 63) / 64 * 64 - Cx) * 4 >= Cx) nwx = 2;     // likewise for X (64 x 32 tiles; not both: 32 x 32 tiles are LDS-read bound)
     if (mi == 2 && nwx == 2) bd = 4;                     // thin rows: a 256-voxel brick still fits two workgroups per CU
   }
   const int pad = (mode == AM_CONVT_FWD) ? 1 : k / 2;

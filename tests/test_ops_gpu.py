@@ -119,7 +119,7 @@ def test_conv_wgrad_narrow_channels_wide_grid(ops, case, sparse):
     close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (narrow channels)")
 
 
-@pytest.mark.parametrize("case", [(64, 64, (5, 20, 40), 3), (96, 64, (9, 8, 16), 1), (64, 32, (7, 12, 24), 2), (40, 72, (33, 9, 17), 1)])
+@pytest.mark.parametrize("case", [(64, 64, (5, 20, 40), 3), (96, 64, (9, 8, 16), 1), (64, 32, (7, 12, 24), 2), (40, 72, (33, 9, 17), 1), (96, 96, (4, 8, 32), 2), (128, 96, (3, 16, 16), 1)])
 @pytest.mark.parametrize("det", [False, True])
 def test_conv_wgrad_plane_bricks_ragged(ops, case, det):
     """Dense k3 s1 bf16 weight gradients walk one-plane 1x8x16 bricks d-fastest, columns interleaved over the slots of an XCD
