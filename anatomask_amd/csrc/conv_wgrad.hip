@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   // same XCD under round-robin dispatch (shared L2: x and dy are fetched from HBM once, not once per group) -- speed only
   const int ng_ = a.ngroup;
   const int blk_ = blockIdx.x / (8 * ng_), rem_ = blockIdx.x % (8 * ng_);
-  const int slot = blk_ * 8 + (rem_ & 7);
+  // (fewer than 8 slots -- layers whose tiles alone fill the chip: the live slots rotate with the tile index, or every live
+  // workgroup would sit on XCD 0)
+  const int slot = blk_ * 8 + ((rem_ & 7) + (a.split < 8 ? 8 - (blockIdx.y & 7) : 0)) % 8;
   if (slot >= a.split) return;
   const int grp = a.zmap[rem_ >> 3];
   const int ncxt = (a.Cx + KT - 1) / KT;
@@ -481,12 +483,17 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WG_ROUNDS"); if (e_) R0 = atoi(e_); }
 #endif
-  for (int R = R0; R <= 2 * R0 || !split8; ++R) {
+  for (int R = R0; R <= 2 * R0 || (!split8 && R <= 8 * R0); ++R) {
     const int s8 = cap * R / tiles;
     const double eff = (double)s8 * tiles / (cap * R);
     if (s8 >= 1 && eff > best + 0.02) { best = eff; split8 = s8; }
   }
-  int split = split8 * 8;
+  // more tiles than 16 rounds of the chip hold (STUNet-H's 1536-channel layers: 1728 tiles): the tiles alone fill the chip, so only
+  // as many brick-walk slots as R0 rounds need -- every extra slot is another [taps][64][64] block of atomics per tile (with the 8
+  // slots the whole-round rule ended up with, those layers flushed 2 GB per launch: 7.9 ms for five launches, 3.6 with one slot).
+  // Between 432 and 768 tiles (768 / 1024 channels) 8 slots measured better than 2-3.
+  int split = split8 ? split8 * 8 : (cap * 8 * R0 + tiles - 1) / tiles;
+  if (split < 1) split = 1;
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WG_OLDSPLIT"); if (e_ && atoi(e_)) split = (1024 + tiles - 1) / tiles; }
 #endif
