@@ -532,7 +532,8 @@ static int pick_tiling(int os, int B, int qd, int qh, int qw, int Cout, bool out
   int shape = brick_shape(os, qh, qw, out_sparse, out_bshift, bd, bh, bw);
   *nt = Cout <= 32 ? 32 : 64;
   const long q = (long)qd * qh * qw;
-  auto nwg = [&](int tile) { return (long)B * ((q + *bd * *bh * *bw - 1) / (*bd * *bh * *bw)) * ((Cout + tile - 1) / tile) * (os == 2 ? 8 : 1); };
+  // (bricks counted per dimension: a 12^3 grid is 3 x 2 x 2 = 12 bricks of 4x8x8, not ceil(1728 / 256) = 7)
+  auto nwg = [&](int tile) { return (long)B * ((qd + *bd - 1) / *bd) * ((qh + *bh - 1) / *bh) * ((qw + *bw - 1) / *bw) * ((Cout + tile - 1) / tile) * (os == 2 ? 8 : 1); };
   if (nwg(*nt) < 256) {
     *nt = 32;
     if (nwg(32) < 192 && shape != 2) { shape = 2; *bh = 4; *bw = 4; }
