@@ -11,7 +11,9 @@ contains 'encoder', strips everything up to and including 'sp_cnn.', and load_st
 and 'param_groups' whose 'params' are index lists, in the parameter order of get_param_groups (P/utils/lr_control.py:32-53: 'decay'
 then 'no_decay', each in named_parameters order) -- so the reference's `optimizer.load_state_dict(ck['optimizer_state'])` accepts it.
 What the reference forgot and a faithful resume needs goes under extra keys its loaders ignore: EMA teacher weights and decay, the
-per-rank sampler RNG states, the data loaders' RandomState, the epoch-EMA of the loss.  Files are written atomically (temp + rename).
+per-rank sampler RNG states, the data loaders' RandomState, the epoch-EMA of the loss.  Everything in the file is a tensor or a python
+scalar / str / list / dict (no numpy objects): the reference's plain `torch.load(fname)` is weights_only=True from torch 2.6 on and would
+reject the whole file otherwise (tests/test_host_api.py).  Files are written atomically (temp + rename).
 """
 from __future__ import annotations
 
@@ -79,7 +81,7 @@ def load_checkpoint(path: str, trainer, rank: int = 0) -> Dict:
     """Resume.  Returns the checkpoint dict (its 'current_epoch' + 1 is the next epoch).  The sampler RNG is restored only on the rank
     that saved it; every other rank re-derives its stream from (seed, rank, epoch) -- restoring rank 0's state everywhere would make
     all ranks draw identical masks, which a fresh run (seed 4321 + rank) never does."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+    ck = torch.load(path, map_location="cpu")          # default arguments: the file holds tensors and python scalars only
     m = trainer.model
     m.load_state_dict({k[len("module."):]: v for k, v in ck["network_weights"].items()})
     if "ema_weights" in ck:
@@ -101,6 +103,11 @@ def load_checkpoint(path: str, trainer, rank: int = 0) -> Dict:
         else:
             trainer.gen.manual_seed(4321 + rank + 7919 * (int(ck["current_epoch"]) + 1))
     return ck
+
+
+def peek_extra(path: str, key: str):
+    """one extra entry of a checkpoint (e.g. 'feed_state') without touching a trainer."""
+    return torch.load(path, map_location="cpu").get(key)
 
 
 def encoder_weights_for_finetuning(network_weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

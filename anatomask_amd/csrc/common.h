@@ -116,6 +116,21 @@ struct MaskView {
   }
 };
 
+// Run `f` once per DEVICE of this process (not once per process): kernel attributes (hipFuncSetAttribute) and device properties are
+// per device, and one process may drive several (one process per GPU is the deployment, but nothing here may assume it).
+// Idempotent work only: two threads may both run f for the same device.
+struct PerDeviceOnce {
+  unsigned long long done = 0;
+  template <typename F> __host__ void run(F&& f) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit) return;
+    f(dev);
+    __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+  }
+};
+
 #define AM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 // launch with a clean error slate: hipGetLastError() is per-thread sticky and torch's own probing calls
 // can leave a benign error behind that would otherwise be mis-attributed to our launch

@@ -458,8 +458,8 @@ template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
   auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS, HR, NB>;
-  static std::once_flag lds_cap;                  // per instantiation, thread-safe: lift the 48 KB dynamic-LDS default to the CU's 160 KB
-  std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  static PerDeviceOnce lds_cap;                   // per instantiation and device: lift the 48 KB dynamic-LDS default to the CU's 160 KB
+  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   if (P.lds > 160 * 1024) return -3;
   dim3 grid(a.B * a.nbd * a.nbh * a.nbw, (a.Cout + 16 * NS - 1) / (16 * NS), a.nclass);
   AM_LAUNCH(kern, grid, dim3(256), P.lds, st, a);

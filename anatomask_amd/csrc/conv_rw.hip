@@ -419,8 +419,8 @@ bool rw_geometry(RwGeo& G, int mode, int dtype, int k, int stride, int B, int Do
 template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR, int LR>
 int rw_launch(ConvArgs& a, RwArgs& r, const RwGeo& G, size_t lds, hipStream_t st) {
   auto kern = conv_rw_kernel<NW, BD, BH, BW, NS, NIT, HR, LR>;
-  static std::once_flag lds_cap;
-  std::call_once(lds_cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  static PerDeviceOnce lds_cap;
+  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   dim3 grid(G.nwg, (a.Cout + 16 * NS - 1) / (16 * NS), 1);
   AM_LAUNCH(kern, grid, dim3(NW * 64), lds, st, a, r);
   AM_CHECK_LAUNCH();

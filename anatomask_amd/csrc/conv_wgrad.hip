@@ -57,10 +57,13 @@ struct WgArgs {
 #endif
 
 
-inline int wg_slots(int occ) {                    // resident workgroups of the whole device
-  static int ncu = 0;
-  if (!ncu) { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ncu = pr.multiProcessorCount; if (ncu <= 0) ncu = 256; }
-  return occ * ncu;
+inline int wg_slots(int occ) {                    // resident workgroups of the CURRENT device (CU count cached per device)
+  static int ncu[64];
+  static PerDeviceOnce once;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  once.run([&](int d) { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256; ncu[d & 63] = n; (void)hipGetLastError(); });
+  return occ * ncu[dev & 63];
 }
 
 __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
@@ -463,9 +466,9 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
   }
   if (lds > 160 * 1024) return -3;
   if (maxvox * (KT / TT<T>::EPC) > (size_t)NITX * 256) return -3;
-  static std::once_flag lds_cap;                  // per instantiation, thread-safe
-  static int regs_occ = 2;                        // resident workgroups per CU the register file allows (LDS is accounted per launch)
-  std::call_once(lds_cap, [&] {
+  static PerDeviceOnce lds_cap;                   // per instantiation and device
+  static int regs_occ = 2;                        // resident workgroups per CU the register file allows (LDS is accounted per launch; a property of the code object, the same on every gfx950)
+  lds_cap.run([&](int) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kern, 256, 0) == hipSuccess && nb > 0) regs_occ = nb;

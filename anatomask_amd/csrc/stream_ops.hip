@@ -1874,8 +1874,8 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
 #define AM_STEM_WG(NS_, K_)                                                                                                           \
     {                                                                                                                                 \
       auto kern = stem_wgrad_mfma_kernel<NS_, K_>;                                                                                    \
-      static std::once_flag cap;                                                                                                      \
-      std::call_once(cap, [&] { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); }); \
+      static PerDeviceOnce cap;                                                                                                       \
+      cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); }); \
       AM_LAUNCH(kern, dim3(nwg), dim3(256), sm, st, x, (const bf16_t*)dy, D, H, W, mv, active_list, n_active, dw_accum, db_accum, det_workspace);     \
     }
     if (ksize == 3) { if (C == 32) AM_STEM_WG(2, 3) else if (C == 64) AM_STEM_WG(4, 3) else AM_STEM_WG(6, 3) }

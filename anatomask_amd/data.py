@@ -325,13 +325,16 @@ class DeviceFeed:
         self._start(0)
 
     def _start(self, slot: int, after=None) -> bool:
+        # hand finished pool buffers back BEFORE blocking on the loader queue, and bound the host's lead over the GPU: the step has
+        # no host synchronisation, so without the bound every pooled pinned buffer could sit in `_pending` behind a queued copy
+        # while the loader threads starve in pool.get() and this thread waits forever in q.get()
+        self._reap(self.depth)
         try:
             b = next(self.it)
         except StopIteration:
             self.ready[slot] = None
             return False
         h = b[self.key] if isinstance(b, dict) else b
-        self._pending = [(e, r) for e, r in self._pending if not (e.query() and (r() or True))]     # hand finished pool buffers back
         if self.dbuf[slot] is None or self.dbuf[slot].shape != h.shape:
             self.dbuf[slot] = torch.empty(h.shape, dtype=h.dtype, device=self.dev)
         if not h.is_pinned():
@@ -352,6 +355,14 @@ class DeviceFeed:
         if isinstance(b, dict) and "_release" in b:
             self._pending.append((ev, b["_release"]))
         return True
+
+    def _reap(self, keep: int):
+        """release the pool buffers whose copies have completed; wait for the oldest copies while more than `keep` are in flight."""
+        self._pending = [(e, r) for e, r in self._pending if not (e.query() and (r() or True))]
+        while len(self._pending) > keep:
+            e, r = self._pending.pop(0)
+            e.synchronize()
+            r()
 
     def __iter__(self):
         return self

@@ -195,7 +195,7 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
     p = f"{ENC}.{s}.{b}"
     first = b == 0
     stride = 2 if (first and s > 0) else 1
-    rec_ = {"p": p, "s": s, "first": first, "stride": stride, "x": x}
+    rec_ = {"p": p, "s": s, "b": b, "first": first, "stride": stride, "x": x}
     if s == 0 and first:
         y1, pt1 = ops.stem_conv_fwd(inp, W[f"{p}.conv1.weight"], W[f"{p}.conv1.bias"], mask, bs, dt, want_partials=True)
     else:
@@ -372,13 +372,15 @@ def _wgrad_into(G, name, mode, x, dy, k, stride, transposed=False, **masks):
     _on_side(x.device, (x, dy), run)
 
 
-def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Tensor) -> List[Optional[torch.Tensor]]:
+def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Tensor, after_group=None) -> List[Optional[torch.Tensor]]:
     """backward of decoder_forward: accumulates the decoder's parameter gradients into G, returns dproj[i] = gradient wrt
     to_dec[i].  (densify_projs[i].bias for i >= 1 -- the per-channel sum of dproj[i] -- is folded into the ConvT-dgrad epilogue.)"""
     n_dec = len(spec.dec_chs) - 1
     # ---- projection
     g = ops.proj_bwd(tape.last, drec, W["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.weight"].view(-1),
                      G["dense_decoder.proj.bias"])
+    if after_group:
+        after_group("proj")
     # ---- decoder, fine -> coarse.  g = grad wrt block output (= grad wrt to_dec[i+1] too)
     dproj: List[Optional[torch.Tensor]] = [None] * n_dec
     for i in reversed(range(n_dec)):
@@ -412,6 +414,8 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
             g, ptg = g
             ptg.finalize(None, sum_accum=G[f"densify_projs.{i}.bias"])
         _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
+        if after_group:
+            after_group(f"dec{i}")
     dproj[0] = g
     return dproj
 
@@ -475,6 +479,8 @@ def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: M
             if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only
                 ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None)
                 ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), None)
+                if after_group:
+                    after_group(f"stage{s}.{t['b']}")
                 break
             bsx = bs + (1 if stride == 2 else 0)
             spx = tuple(x.shape[1:4])
@@ -494,22 +500,19 @@ def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: M
                 gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, 1,
                                 in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
                 gout = ops.add(gx, dpre, out=gx)
-        if after_group:
-            _join_side(inp.device)
-            after_group(f"stage{s}")
+            if after_group:
+                after_group(f"stage{s}.{t['b']}")
     _join_side(inp.device)
 
 
 def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo,
              tape: Tape, drec: torch.Tensor, after_group=None):
-    """Accumulates parameter gradients into G (fp32, torch layout).  `after_group(tag)` is called when
-    all gradients of a parameter group ('decoder', 'densify', 'stage{s}') are final (DDP overlap hook)."""
-    dproj = decoder_backward(spec, W, G, pk, tape, drec)
-    if after_group:
-        _join_side(drec.device)
-        after_group("decoder")
+    """Accumulates parameter gradients into G (fp32, torch layout).  `after_group(tag)` is called when every gradient of a group has
+    been ENQUEUED (main stream, or the side stream for the weight gradients): tags 'proj', 'dec3' .. 'dec0', 'densify',
+    'stage4.<b>' .. 'stage0.0' in that order (DDP overlap hook).  The hook must order its work behind BOTH streams (the trainer
+    issues its collectives from the side stream behind a main-stream event); the main stream is not joined before the hook."""
+    dproj = decoder_backward(spec, W, G, pk, tape, drec, after_group)
     dfeat = densify_backward(spec, W, G, pk, mask, tape, dproj)
     if after_group:
-        _join_side(drec.device)
         after_group("densify")
     encoder_backward(spec, W, G, pk, inp, mask, tape, dfeat, after_group)

@@ -7,7 +7,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("AM_HIP_LIB") or os.path.join(_HERE, "libanatomask_hip.so")   # AM_HIP_LIB: A/B timing of alternative builds (tools/)
+LIB_PATH = os.path.join(_HERE, "libanatomask_hip.so")      # the in-tree build; no environment variable redirects the product loader
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "anatomask_hip.h")
 
 DT_F32, DT_BF16 = 0, 1
@@ -67,4 +67,14 @@ def lib() -> HipLib:
     global _LIB
     if _LIB is None:
         _LIB = HipLib()
+    return _LIB
+
+
+def use_library(path: str) -> HipLib:
+    """tools/ only (timing-ablation builds, A/B of alternative builds): bind an explicitly named library instead of the in-tree
+    one.  Must be called before the first kernel call of the process."""
+    global _LIB
+    if _LIB is not None:
+        raise RuntimeError("use_library() after the library was loaded")
+    _LIB = HipLib(path)
     return _LIB

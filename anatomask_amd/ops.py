@@ -406,11 +406,14 @@ def norm_backward(dout: torch.Tensor, out: Optional[torch.Tensor], x: torch.Tens
                           *_al(mask), None, 0.0, None, None, None, None, None, None, None, None, s)
         L.norm_bwd_finalize(ws_b.data_ptr(), _p(st.count_ptr), float(st.count_host), Cc, gamma.data_ptr(), st.rstd.data_ptr(),
                             sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), _p(dgamma), _p(dbeta), _p(dtoken), _p(dbeta2), s)
+        ws_b[:NREP * Cc * 3].zero_()                                   # the shared workspaces' contract: zero on entry, LEFT zero
         if dx is None:
             dx = torch.empty_like(x)
         L.norm_bwd_apply(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,
                          st.mean.data_ptr(), st.rstd.data_ptr(), sc.k[0].data_ptr(), sc.k[1].data_ptr(), sc.k[2].data_ptr(), act,
                          dx.data_ptr(), _p(dres), _p(dxsum), ws_x.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), *_al(mask), 0, s)
+        if dxsum is not None:
+            ws_x[:DXREP * Cc].zero_()
         return dx
     # reduce + finalize in ONE launch (the last workgroup folds the sums into k0/k1/k2 and the parameter gradients)
     L.norm_bwd_reduce(_dt(x), dout.data_ptr(), _p(out), x.data_ptr(), B, D, H, W, Cc, mp, bshift, fd, fh, fw,

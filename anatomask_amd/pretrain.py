@@ -45,41 +45,72 @@ def split_cases(keys, val_fraction=0.2, seed=12345):
     return [k for k in keys if k not in set(val)], val
 
 
-class Feed:
-    """loader threads -> pinned pool -> copy stream -> device augmentation; next(feed) is a (B,1,*input_size) device tensor."""
+def rng_state_to_plain(rs) -> dict:
+    """numpy RandomState (MT19937) state as torch tensors / python scalars only: the checkpoint must stay loadable by the
+    reference's hand-off, a plain `torch.load(fname)` (nnunetv2/run/load_pretrained_weights.py), which is weights_only=True
+    from torch 2.6 on and rejects numpy objects anywhere in the file."""
+    name, keys, pos, has_gauss, cached = rs.get_state()
+    return {"name": str(name), "keys": torch.from_numpy(keys.astype("int64")), "pos": int(pos), "has_gauss": int(has_gauss),
+            "cached_gaussian": float(cached)}
 
-    def __init__(self, folder, cases, batch, input_size, dev, rank, workers, augment: bool, seed: int):
+
+def rng_state_from_plain(rs, st: dict):
+    import numpy as np
+    rs.set_state((st["name"], np.asarray(st["keys"].cpu().numpy(), dtype=np.uint32), int(st["pos"]), int(st["has_gauss"]),
+                  float(st["cached_gaussian"])))
+
+
+class Feed:
+    """loader threads -> pinned pool -> copy stream -> device augmentation; next(feed) is a (B,1,*input_size) device tensor.
+    `state` (what state() returned at a checkpoint) is applied to the loaders' generators BEFORE the prefetch threads start; the
+    batches that were prefetched but not consumed when the checkpoint was written are not replayed (the workers run up to
+    num_cached + workers batches ahead of the step, and state() samples their generators while they run)."""
+
+    def __init__(self, folder, cases, batch, input_size, dev, rank, workers, augment: bool, seed: int, state=None):
         ds = PreprocessedDataset(folder, cases)
         rot = ROTATION_FOR_DA
         enl = tuple(int(v) for v in get_patch_size(tuple(input_size), rot, rot, rot, (0.85, 1.25))) if augment else tuple(input_size)
         self.pool = PinnedPool((batch, 1, *enl), n=6 + 2 + workers)
-        self.loaders = {}
-
-        def make(w):
-            ld = PatchLoader3D(ds, batch, enl, 0.33, seed=seed + 1000 * rank + w, final_patch_size=tuple(input_size), pool=self.pool)
-            self.loaders[w] = ld
-            return ld
-        self.pf = PrefetchLoader(make, n_workers=workers, num_cached=6)
-        self.feed = DeviceFeed(self.pf, dev)
+        self.loaders = {w: PatchLoader3D(ds, batch, enl, 0.33, seed=seed + 1000 * rank + w, final_patch_size=tuple(input_size), pool=self.pool)
+                        for w in range(workers)}
         self.aug = DeviceAugmenter(SpatialAugmenter(tuple(input_size), seed=seed + 77 + rank,
                                                     p_rot=0.2 if augment else 0.0, p_scale=0.2 if augment else 0.0,
                                                     mirror_axes=(0, 1, 2) if augment else ()))
+        self.load_state(state)
+        self.pf = PrefetchLoader(lambda w: self.loaders[w], n_workers=workers, num_cached=6)
+        self.feed = DeviceFeed(self.pf, dev)
 
     def __next__(self):
         return self.aug(next(self.feed))
 
     def state(self):
-        return {"loader_rng": {w: ld.rs.get_state() for w, ld in self.loaders.items()}, "aug_rng": self.aug.aug.rs.get_state()}
+        return {"loader_rng": {int(w): rng_state_to_plain(ld.rs) for w, ld in self.loaders.items()}, "aug_rng": rng_state_to_plain(self.aug.aug.rs)}
 
     def load_state(self, st):
-        for w, s in (st or {}).get("loader_rng", {}).items():
-            if w in self.loaders:
-                self.loaders[w].rs.set_state(s)
+        for w, s_ in (st or {}).get("loader_rng", {}).items():
+            if int(w) in self.loaders:
+                rng_state_from_plain(self.loaders[int(w)].rs, s_)
         if st and "aug_rng" in st:
-            self.aug.aug.rs.set_state(st["aug_rng"])
+            rng_state_from_plain(self.aug.aug.rs, st["aug_rng"])
 
     def close(self):
         self.pf.close()
+
+
+def gather_feed_states(feed, rank: int, world: int) -> dict:
+    """{rank: feed.state()} of EVERY rank on every rank (only rank 0 writes the checkpoint; a resumed run must not restart ranks
+    1..N-1 from their initial seeds and replay epoch 0's crops)."""
+    mine = feed.state()
+    if world <= 1:
+        return {rank: mine}
+    states = [None] * world
+    dist.all_gather_object(states, mine)
+    return {r: s_ for r, s_ in enumerate(states)}
+
+
+def default_workers(ranks_on_node: int) -> int:
+    """loader threads per rank: the host's cores shared by the ranks of this node (one core per rank stays with the launch thread)."""
+    return max(1, min(8, (os.cpu_count() or 8) // max(1, ranks_on_node) - 1))
 
 
 def all_ranks_finite(value: float, dev, world: int) -> bool:
@@ -104,7 +135,8 @@ def main(argv=None):
     ap.add_argument("--clip", type=float, default=12.0); ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--data", default=None); ap.add_argument("--out", default="anatomask_run")
-    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--workers", type=int, default=0,
+                    help="loader threads per rank; 0 = min(8, host cores // ranks on this node - 1): 8 ranks x 8 threads on one host is not free")
     ap.add_argument("--no-augment", action="store_true")
     ap.add_argument("--resume", default=None)
     ap.add_argument("--plain-spark", action="store_true", help="plain SparK baseline (P/pretrain.py): random mask, no teacher, validation + best ckpt")
@@ -116,6 +148,7 @@ def main(argv=None):
         sys.exit(launch.self_launch(a.gpus, "-m", ["anatomask_amd.pretrain", *(argv if argv is not None else sys.argv[1:])]))
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    workers = a.workers if a.workers > 0 else default_workers(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -138,9 +171,12 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
         tr_keys, val_keys = split_cases(PreprocessedDataset(a.data).keys()) if a.plain_spark else (PreprocessedDataset(a.data).keys(), [])
-        feed = Feed(a.data, tr_keys, a.batch_size, a.input_size, dev, rank, a.workers, not a.no_augment, seed=1000)
+        resumed = None
+        if a.resume:                                   # the loaders' generators are restored before their threads start
+            resumed = (checkpoint.peek_extra(a.resume, "feed_state") or {}).get(rank)
+        feed = Feed(a.data, tr_keys, a.batch_size, a.input_size, dev, rank, workers, not a.no_augment, seed=1000, state=resumed)
         if a.plain_spark and val_keys:
-            val_feed = Feed(a.data, val_keys, a.batch_size, a.input_size, dev, rank, max(1, a.workers // 4), False, seed=5000)
+            val_feed = Feed(a.data, val_keys, a.batch_size, a.input_size, dev, rank, max(1, workers // 4), False, seed=5000)
     else:
         gen = synthetic_batches(a.batch_size, a.input_size, 1000 + rank)
         feed = type("Syn", (), {"__next__": lambda s: next(gen)["data"].to(dev, non_blocking=True), "state": lambda s: {}, "load_state": lambda s, st: None,
@@ -151,7 +187,6 @@ def main(argv=None):
         start = int(ck["current_epoch"]) + 1
         epoch_loss, val_loss, ema_loss = list(ck.get("train_loss", [])), list(ck.get("val_loss", [])), ck.get("ema_loss")
         best_val = ck.get("best_val_loss", best_val)
-        feed.load_state(ck.get("feed_state", {}).get(rank))
     for i in range(start, a.epochs):
         trainer.set_epoch(i); trainer.lr = lrs[i]                                     # :383-386, :452
         t0, acc = time.time(), torch.zeros(1, device=dev)
@@ -164,7 +199,7 @@ def main(argv=None):
             sys.exit(-1)
         epoch_loss.append(loss)
         ema_loss = loss if ema_loss is None else 0.9 * ema_loss + 0.1 * loss           # :456-461
-        extra = {"ema_loss": ema_loss, "feed_state": {rank: feed.state()}}
+        extra = {"ema_loss": ema_loss, "feed_state": gather_feed_states(feed, rank, world)}
         if a.plain_spark and val_feed is not None:                                     # P/pretrain.py:426-463: eval() pass, no grad, BN on running stats
             vacc = torch.zeros(1, device=dev)
             for _ in range(a.val_iters):

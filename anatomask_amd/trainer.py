@@ -48,6 +48,7 @@ class AnatoMaskTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if self.distributed else 1
         self._works = []
+        self.exchange_log = []                     # (a, b) of every collective of the current step, in issue order
         if self.distributed:                      # DDP start-up broadcast of parameters AND buffers (P/pretrain_AnatoMask_DDP.py:239-240)
             dist.broadcast(model._flat, 0, group=process_group)
             dist.broadcast(model._bflat, 0, group=process_group)
@@ -56,31 +57,90 @@ class AnatoMaskTrainer:
             model.weights_changed(); self.teacher.ema.weights_changed()   # packed MFMA copies made before the broadcast are stale
         self._build_ranges()
 
-    def _build_ranges(self):
-        """Flat-buffer ranges of the parameter groups in the order backward finishes them (gradient buckets)."""
-        model = self.model
-        o, names, n = model._offs, model._pnames, model._live_end
-        first_dec = next(k for k in names if k.startswith("dense_decoder."))
-        first_dens = next(k for k in names if k.startswith("densify_norms.") and k not in model._dead)
-        self._ranges: Dict[str, tuple] = {"decoder": (o[first_dec], o[first_dens]), "densify": (o[first_dens], n)}
-        for s in range(model.spec.n_stage):
-            ks = [k for k in names if k.startswith(f"{engine.ENC}.{s}.")]
-            nxt = o[f"{engine.ENC}.{s + 1}.0.conv1.weight"] if s + 1 < model.spec.n_stage else o[first_dec]
-            self._ranges[f"stage{s}"] = (o[ks[0]], nxt)
-
     # ------------------------------------------------------------------ gradient exchange (a18)
+    BUCKET_BYTES = 64 << 20       # no collective larger than this (STUNet-H's first decoder block alone is 0.9 GB of fp32 gradients)
+    FLUSH_BYTES = 24 << 20        # ready gradients are held back until this much has accumulated (DDP's 25 MB bucket_cap_mb)
+
+    def _build_ranges(self):
+        """Flat-buffer ranges of the gradient groups in the order backward finishes them: projection, decoder block 3..0, densify,
+        encoder blocks deep -> shallow (engine.backward's `after_group` tags).  The flat buffer is in named_parameters order
+        [encoder | decoder | densify], so the tags tile the live region; pieces that become ready one after the other are usually
+        adjacent in memory and are merged before they are sent."""
+        model = self.model
+        o, n = model._offs, model._live_end
+        live = [k for k in model._pnames if k not in model._dead]
+        ends = {k: (o[live[i + 1]] if i + 1 < len(live) else n) for i, k in enumerate(live)}
+
+        def span(pred):
+            ks = [k for k in live if pred(k)]
+            if not ks:
+                return None
+            a, b = min(o[k] for k in ks), max(ends[k] for k in ks)
+            assert sum(ends[k] - o[k] for k in ks) == b - a, "a gradient group must be one contiguous range of the flat buffer"
+            return (a, b)
+        r: Dict[str, tuple] = {}
+        r["proj"] = span(lambda k: k.startswith("dense_decoder.proj."))
+        for i in range(len(model.spec.dec_chs) - 1):
+            r[f"dec{i}"] = span(lambda k, i=i: k.startswith(f"{engine.DEC}.{i}."))
+        r["densify"] = span(lambda k: k.startswith(("densify_norms.", "densify_projs.", "mask_tokens.")))
+        for s in range(model.spec.n_stage):
+            for b in range(model.spec.depth[s]):
+                r[f"stage{s}.{b}"] = span(lambda k, s=s, b=b: k.startswith(f"{engine.ENC}.{s}.{b}."))
+        self._ranges = {t: v for t, v in r.items() if v is not None}
+        self._pending = []                         # merged (a, b) ranges whose gradients are final but not yet sent
+
     def _after_group(self, tag: str):
-        """Gradient bucket `tag` is final: start its all-reduce now so it overlaps the rest of backward.
-        RCCL runs it on its own stream behind an event on the compute stream."""
-        if not self.distributed:
+        """Gradient group `tag` is final.  Groups are merged with adjacent ready ones and sent once FLUSH_BYTES have accumulated, so the
+        exchange starts with the first decoder blocks and overlaps the rest of backward."""
+        if not self.distributed or tag not in self._ranges:
             return
         a, b = self._ranges[tag]
-        if b > a:
-            self._works.append(dist.all_reduce(self.model._gflat[a:b], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        merged = []
+        for (c, d) in self._pending:
+            if d == a:
+                a = c
+            elif c == b:
+                b = d
+            else:
+                merged.append((c, d))
+        merged.append((a, b))
+        self._pending, self._last_tag = merged, tag
+        if sum(d - c for c, d in self._pending) * 4 >= self.FLUSH_BYTES:
+            self._flush()
+
+    def _flush(self):
+        """async all-reduce(SUM) of every pending range, in pieces of at most BUCKET_BYTES.  On the GPU the collectives are issued from
+        the side stream's context: RCCL's stream then waits for the weight-gradient kernels that run THERE (and, through the event,
+        for the main stream up to this point) while the main stream goes on with backward un-joined."""
+        if not self._pending:
+            return
+        if not self.exchange_log:
+            self.first_sent_tag = getattr(self, "_last_tag", None)        # how early in backward the exchange starts (bench.py `exchange`)
+        g = self.model._gflat
+        ctx = None
+        if g.is_cuda and engine._USE_SIDE:
+            side = engine._side_stream(g.device)
+            ev = torch.cuda.Event()
+            ev.record()
+            side.wait_event(ev)
+            ctx = torch.cuda.stream(side)
+            ctx.__enter__()
+        try:
+            for a, b in sorted(self._pending, reverse=True):
+                npiece = max(1, -(-(b - a) * 4 // self.BUCKET_BYTES))
+                step = ((b - a + npiece - 1) // npiece + 3) // 4 * 4
+                for c in range(a, b, step):
+                    self._works.append(dist.all_reduce(g[c:min(c + step, b)], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    self.exchange_log.append((c, min(c + step, b)))
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+        self._pending = []
 
     def _finish_exchange(self):
         if not self.distributed:
             return
+        self._flush()
         for w in self._works:
             w.wait()
         self._works.clear()                        # the buffer now holds the SUM over ranks; 1/world is folded into am_adamw_ema
@@ -131,7 +191,8 @@ class AnatoMaskTrainer:
         drec = ops.patch_loss_bwd(x, rec, mi, pm, pr, info, None)
         # 5. backward (:435) with overlapped gradient exchange
         m._gflat.zero_()
-        engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group)
+        self.exchange_log.clear()
+        engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group if self.distributed else None)
         del tape
         self._finish_exchange()
         # 6. clip + AdamW + EMA (:437-440), one pass over the live parameters
@@ -139,9 +200,8 @@ class AnatoMaskTrainer:
         decay = self.teacher.decay if ema_decay is None else ema_decay
         ops.sumsq(m._gflat[:n], self.sumsq)
         dyn = None
-        if self._capturing:                                       # graphed_step: step count / lr arrive through device memory at replay
-            self._dyn_dev.copy_(self._dyn_host, non_blocking=True)
-            dyn = self._dyn_dev
+        if self._capturing:                                       # graphed_step: step count / lr arrive through device memory, written by a
+            dyn = self._dyn_dev                                   # stream-ordered copy in FRONT of every replay (nothing in the graph reads host memory)
         else:
             self.step_count += 1
         ops.adamw_ema(m._flat, m._gflat, self.m, self.v, t._flat if self.self_distill else None, n, self.lr if lr is None else lr,
@@ -180,8 +240,9 @@ class AnatoMaskTrainer:
         if self._graph_key != key:
             dev = inp_bchwd.device
             self._g_inp = inp_bchwd.clone()
-            self._dyn_host = torch.zeros(4, dtype=torch.float32).pin_memory()
             self._dyn_dev = torch.zeros(4, device=dev, dtype=torch.float32)
+            self._dyn_ring = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(16)]
+            self._dyn_evs = [None] * 16
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             g.register_generator_state(self.gen)
@@ -194,7 +255,17 @@ class AnatoMaskTrainer:
             self._graph, self._graph_key = g, key
         self._g_inp.copy_(inp_bchwd)
         self.step_count += 1
-        self._dyn_host.copy_(torch.tensor(ops.adam_dyn_scalars(self.lr, self.betas, self.step_count, self.teacher.decay), dtype=torch.float32))
+        # per-step scalars: an async copy out of a RING of pinned slots, enqueued on the replay's stream in front of the replay.  (A
+        # captured memcpy node out of ONE reused pinned buffer is read when the GPU gets there: a host that runs ahead -- one sync
+        # per epoch -- would have overwritten it with a later step's bias corrections.)  A slot is rewritten only after the copy
+        # that read it has completed (event), 16 steps later.
+        i = self.step_count % len(self._dyn_ring)
+        if self._dyn_evs[i] is not None:
+            self._dyn_evs[i].synchronize()
+        self._dyn_ring[i].copy_(torch.tensor(ops.adam_dyn_scalars(self.lr, self.betas, self.step_count, self.teacher.decay), dtype=torch.float32))
+        self._dyn_dev.copy_(self._dyn_ring[i], non_blocking=True)
+        self._dyn_evs[i] = torch.cuda.Event()
+        self._dyn_evs[i].record()
         self._graph.replay()
         return self._g_out
 

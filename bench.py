@@ -32,8 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-# SURVEY.md 8(d) / BASELINE.md 3: algorithmic bytes of the student sparse-encoder forward, bf16, per volume
-ENC_FWD_ALGO_BYTES = {"B": 1105.3e6}
+# SURVEY.md 8(d) / BASELINE.md 3: algorithmic (bytes, flop) of the student sparse-encoder forward, bf16, per volume, at the patch /
+# mask ratio the figure was derived for (size -> (patch, mask_ratio, bytes, flop))
+ENC_FWD_ALGO = {"S": (48, 0.6, 36.1e6, 1.5e9), "B": (128, 0.6, 1105.3e6, 114.0e9), "L": (160, 0.7, 6135e6, 1716e9), "H": (192, 0.6, 30622e6, 14345e9)}
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_BF16_PEAK = 2.5e15    # dense bf16
 
@@ -51,26 +52,26 @@ def time_kernel(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def dominant_kernel_roofline(B, dev, tr, x):
-    """The dominant kernel of the step (profiles/: conv_igemm bf16, 4x4x16 brick, 64 output channels) on its largest
-    instance: decoder level-3 conv 64->64 at 128^3 (P/decoder3D.py:20).  Bound: MFMA (AI ~ 1700 flop/B).
-    `launch_ms`: the launch alone (20 back-to-back launches, HIP events); `launch_ms_in_step`: the SAME launch timed by HIP
-    events where it sits inside the training step (student decoder block 3, first conv), median over 3 steps."""
+def dominant_kernel_roofline(B, dev, tr, x, C=64, S=128, size="B"):
+    """The dominant kernel of the step (profiles/: conv_igemm bf16, 4x4x16 brick, 64 output channels per workgroup) on its largest
+    instance: the first conv of the last decoder block, C -> C at S^3 (P/decoder3D.py:20; C = width / 8: 64 for STUNet-B, 128 for L,
+    192 for H).  Bound: MFMA (AI ~ 1700 flop/B at C = 64).
+    `launch_ms`: the launch alone (20 back-to-back launches, HIP events on the launch stream); `launch_ms_in_step`: the SAME launch
+    timed by HIP events where it sits inside the training step (student decoder, last block, first conv), median over 3 steps."""
     from anatomask_amd import ops
-    C = 64
-    xx = torch.randn(B, 128, 128, 128, C, device=dev).to(torch.bfloat16)
+    xx = torch.randn(B, S, S, S, C, device=dev).to(torch.bfloat16)
     w = (torch.randn(C, C, 3, 3, 3, device=dev) * 0.02)
     wp = ops.pack_weight(w, torch.bfloat16, False, False)
     y = torch.empty_like(xx)
-    t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, xx, wp, None, (128, 128, 128), 3, 1, out=y))
+    t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, xx, wp, None, (S, S, S), 3, 1, out=y), iters=20 if size == "B" else 8)
     del xx, y
-    flops = 2.0 * B * 128 ** 3 * C * C * 27
+    flops = 2.0 * B * S ** 3 * C * C * 27
     # the same launch inside the step: wrap ops.conv3d for three steps (events only, no synchronisation inside the step)
     evs, orig = [], ops.conv3d
 
     def timed_conv3d(mode, x_, w_packed, bias, out_spatial, ksize, stride, *a, **k):
-        hit = (mode == ops.CONV_FWD and ksize == 3 and stride == 1 and tuple(x_.shape[1:]) == (128, 128, 128, C)
-               and w_packed.logical == (C, C) and not k.get("ep_scale") is not None and k.get("want_partials"))
+        hit = (mode == ops.CONV_FWD and ksize == 3 and stride == 1 and tuple(x_.shape[1:]) == (S, S, S, C)
+               and w_packed.logical == (C, C) and k.get("ep_scale") is None and k.get("want_partials"))
         if not hit:
             return orig(mode, x_, w_packed, bias, out_spatial, ksize, stride, *a, **k)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -81,7 +82,6 @@ def dominant_kernel_roofline(B, dev, tr, x):
         return r
     in_step = None
     if tr is not None:
-        from anatomask_amd import engine
         ops.conv3d = timed_conv3d
         try:
             for _ in range(3):
@@ -92,23 +92,27 @@ def dominant_kernel_roofline(B, dev, tr, x):
         if evs:
             ds = sorted(a.elapsed_time(b) for a, b in evs)
             in_step = ds[len(ds) // 2]
-        del engine
     achieved = flops / t / 1e12
+    algo = (2 * S ** 3 * C * 2 * B) + 27 * C * C * 2
     # HBM bytes per launch from the PMC counters of the SAME launch shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_pmc_traffic.md, measured at B=2 -> linear in B
-    traffic = (605.5e6 + 536.9e6) * B / 2
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<bf16,4,4,16,4,11,3,true> (decoder conv3 64->64 @128^3)", "achieved": round(achieved, 2),
+    # passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r02_pmc_traffic.md, measured at B=2 for 64 -> 64 @128^3 and
+    # linear in B; no counter pass exists for the other shapes -> null
+    traffic = (605.5e6 + 536.9e6) * B / 2 if (C, S) == (64, 128) else None
+    return {"bound": "mfma", "kernel": f"conv_igemm_kernel<bf16,4,4,16,4,11,3,true> (decoder conv3 {C}->{C} @{S}^3)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
-            "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1.06 x algorithmic at B=2, scaled to the bench batch)",
-            "algorithmic_bytes": (2 * 128 ** 3 * C * 2 * B) + 27 * C * C * 2, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops,
+            "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1.06 x algorithmic at B=2, scaled to the bench batch)" if traffic else None,
+            "algorithmic_bytes": algo, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops,
             "launch_ms_in_step": None if in_step is None else round(in_step, 4),
             "frac_in_step": None if in_step is None else round(flops / (in_step * 1e-3) / MFMA_BF16_PEAK, 4)}
 
 
-def encoder_forward_hbm(model, x, dev):
-    """North-star figure: achieved algorithmic HBM GB/s of the STUDENT SPARSE-ENCODER FORWARD at 128^3 bf16
-    (algorithmic bytes per SURVEY.md 8d) from HIP events around that part of the forward."""
+def encoder_forward_hbm(model, x, dev, size, patch, mask_ratio):
+    """North-star figure: achieved algorithmic HBM GB/s of the STUDENT SPARSE-ENCODER FORWARD (bf16; algorithmic bytes per
+    SURVEY.md 8d / BASELINE.md 3) from HIP events around that part of the forward."""
     from anatomask_amd import engine, ops
+    p0, m0, bytes_pv, flop_pv = ENC_FWD_ALGO[size]
+    if (p0, m0) != (patch, mask_ratio):
+        return None
     B = x.shape[0]
     L = model.spec.fmap[0] * model.spec.fmap[1] * model.spec.fmap[2]
     k = torch.rand(B, L, device=dev)
@@ -119,67 +123,177 @@ def encoder_forward_hbm(model, x, dev):
     def enc_only():
         engine.forward(model.spec, model._W, model._pack, xs, mi, True, None, encoder_only=True)
     t = time_kernel(enc_only, iters=10, warm=2)
-    algo = ENC_FWD_ALGO_BYTES["B"] * B
+    algo = bytes_pv * B
     gbs = algo / t / 1e9
-    return {"what": "student sparse-encoder forward, STUNet-B 128^3 bf16, mask 0.6", "ms": round(t * 1e3, 3),
+    return {"what": f"student sparse-encoder forward, STUNet-{size} {patch}^3 bf16, mask {mask_ratio}", "ms": round(t * 1e3, 3),
             "algorithmic_bytes": algo, "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs * 1e9 / HBM_PEAK, 4),
-            "flop": 114.0e9 * B, "achieved_TFLOPs": round(114.0e9 * B / t / 1e12, 2)}
+            "flop": flop_pv * B, "achieved_TFLOPs": round(flop_pv * B / t / 1e12, 2)}
 
 
 def cpu_baseline(state_dict_cpu, spec_kw):
-    """The CPU oracle (port of the reference step, pinned against it by tests/golden) on the host cores:
-    ONE full AnatoMask step of the same workload at B=1 (teacher fwd + sampler + student fwd/bwd + clip + AdamW + EMA)."""
+    """the CPU oracle (port of the reference step, pinned against it by tests/golden) on the host cores, in this run.
+      value            C2: ONE full AnatoMask step of the bench workload at B=1 (teacher fwd + sampler + student fwd/bwd + clip + AdamW +
+                       EMA), n = min(32, host cores) threads  (measured on the MI355X host: 8/16/32/64 threads -> 5.4/4.8/4.1/5.8 s per
+                       forward; 256 oversubscribes 10x)
+      c2_8_threads     the same step on 8 threads (comparability with the survey container's 0.029-0.037 volumes/s)
+      c1 / c1_8_threads  STUNet-small, 48^3, B=2, plain SparK step (P/pretrain.py): 2 warm-up + 10 timed steps, median"""
     from oracle import anatomask_oracle as O
-    n = min(32, os.cpu_count() or 1)      # measured on the MI355X host: 8/16/32/64 threads -> 5.4/4.8/4.1/5.8 s per forward; 256 oversubscribes 10x
-    torch.set_num_threads(n)
-    cfg = O.Config(spec_kw["dims"], spec_kw["depth"], spec_kw["width"], (128, 128, 128), 0.6)
-    st = O.StepState(cfg, state_dict_cpu)
-    x = torch.randn(1, 1, 128, 128, 128, generator=torch.Generator().manual_seed(1234))
-    mask1 = O.random_mask(cfg, 1, torch.Generator().manual_seed(4321))
-    keys = torch.rand(1, cfg.L, generator=torch.Generator().manual_seed(4322))
-    t0 = time.time()
-    o = O.train_step(st, x, mask1, keys, 500, 999, 1e-4, 0.9995)
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "volumes/s", "cores": n, "kind": "port",
-            "sample": f"1 full step, B=1, STUNet-B 128^3 fp32, torch-CPU oracle, {dt:.1f} s, loss {o['loss']:.4f}"}
+    n = min(32, os.cpu_count() or 1)
+
+    def c2(threads):
+        torch.set_num_threads(threads)
+        cfg = O.Config(spec_kw["dims"], spec_kw["depth"], spec_kw["width"], (128, 128, 128), 0.6)
+        st = O.StepState(cfg, state_dict_cpu)
+        x = torch.randn(1, 1, 128, 128, 128, generator=torch.Generator().manual_seed(1234))
+        mask1 = O.random_mask(cfg, 1, torch.Generator().manual_seed(4321))
+        keys = torch.rand(1, cfg.L, generator=torch.Generator().manual_seed(4322))
+        t0 = time.time()
+        o = O.train_step(st, x, mask1, keys, 500, 999, 1e-4, 0.9995)
+        return time.time() - t0, o["loss"]
+
+    def c1(threads):
+        torch.set_num_threads(threads)
+        cfg = O.Config.stunet_s((48, 48, 48), 0.6)
+        st = O.StepState(cfg, O.seeded_state(cfg, 1))
+        x = torch.randn(2, 1, 48, 48, 48, generator=torch.Generator().manual_seed(1234))
+        ts = []
+        for i in range(12):
+            m = O.random_mask(cfg, 2, torch.Generator().manual_seed(4321 + i))
+            t0 = time.time()
+            o = O.plain_spark_step(st, x, m, 1e-4)
+            ts.append(time.time() - t0)
+        ts = sorted(ts[2:])
+        return ts[len(ts) // 2], o["loss"]
+    dt, loss = c2(n)
+    res = {"value": round(1.0 / dt, 5), "unit": "volumes/s", "cores": n, "kind": "port",
+           "sample": f"1 full step, B=1, STUNet-B 128^3 fp32, torch-CPU oracle, {dt:.1f} s, loss {loss:.4f}"}
+    d1, l1 = c1(n)
+    res["c1"] = {"value": round(2.0 / d1, 3), "unit": "volumes/s", "cores": n,
+                 "sample": f"STUNet-S 48^3 B=2 plain SparK step, median of 10 steps after 2 warm-up, {d1 * 1e3:.0f} ms/step, loss after 12 steps {l1:.4f}"}
+    if n != 8:
+        d8, l8 = c1(8)
+        res["c1_8_threads"] = {"value": round(2.0 / d8, 3), "unit": "volumes/s", "cores": 8, "sample": f"{d8 * 1e3:.0f} ms/step"}
+        dt8, _ = c2(8)
+        res["c2_8_threads"] = {"value": round(1.0 / dt8, 5), "unit": "volumes/s", "cores": 8, "sample": f"1 full step, {dt8:.1f} s"}
+    return res
+
+
+def secondary_lines(a, kw, dev, dtype_main):
+    """Beside the headline (never instead of it): the same step at the reference's batch 4, and the reference RECIPE
+    (P/pretrain_AntoMask.py:209,229: input 112 x 112 x 128, batch 4, fp32 -- here fp32 storage / exact-f32 MFMA)."""
+    from anatomask_amd import modules as M
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    out = []
+    for what, size3, batch, dt, warm, steps in [("same workload at the reference's batch size 4", (a.patch,) * 3, 4, dtype_main, 3, 10),
+                                                ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False)", (112, 112, 128), 4, torch.float32, 2, 4)]:
+        torch.manual_seed(0)
+        model = M.build_spark(kw["dims"], kw["depth"], kw["width"], size3, a.mask_ratio, compute_dtype=dt).to(dev)
+        tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=4321, distributed=False)
+        tr.set_epoch(500)
+        x = torch.randn(batch, 1, *size3, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
+        for _ in range(warm):
+            tr.step(x, epoch=500)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            o = tr.step(x, epoch=500)
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+        out.append({"what": what, "per_gpu_batch": batch, "dtype": "bf16" if dt == torch.bfloat16 else "f32", "ms_per_step": round(d * 1e3, 3),
+                    "value": round(batch / d, 3), "unit": "volumes/s", "steps": steps, "final_loss": round(o["loss"].item(), 5)})
+        del tr, model, x
+        torch.cuda.empty_cache()
+    return out
+
+
+def exchange_report(tr, grad_elems, world, dt, dtn, steps, backend):
+    """`exchange` of the JSON line (N > 1): what was sent per step and what it cost (step time with the exchange off -> exposed ms)."""
+    sizes = [(b - a) * 4 for a, b in tr.exchange_log]
+    return {"backend": backend, "ranks": world, "gradient_bytes_per_step": int(grad_elems) * 4, "collectives_per_step": len(sizes),
+            "largest_collective_bytes": max(sizes) if sizes else 0, "first_collective_after_tag": getattr(tr, "first_sent_tag", None),
+            "ms_per_step_without_exchange": round(dtn / steps * 1e3, 3), "exposed_ms": round((dt - dtn) / steps * 1e3, 3)}
 
 
 def timed_window(step, steps, world, dist, dev):
     """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (wall clock, MAX over ranks), with a HIP event
-    after every step for the per-step distribution."""
+    after every step for the per-step distribution.  dev None: host-only ranks (the gloo dry run), no device calls."""
+    gpu = dev is not None
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    if gpu:
+        torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if gpu else []
     t0 = time.perf_counter()
-    evs[0].record()
+    if gpu:
+        evs[0].record()
     out = None
     for i in range(steps):
         out = step()
-        evs[i + 1].record()
+        if gpu:
+            evs[i + 1].record()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if gpu:
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)) if gpu else [dt / steps * 1e3] * steps
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
     return dt, per, out
 
 
 def dry_run_launch(a):
-    """`--dry-run-launch` (CPU, gloo): proves the self-launch plumbing without a GPU -- every rank joins the group, the ranks
-    all-reduce their rank numbers and rank 0 prints one JSON line (tests/test_launch.py)."""
+    """`--dry-run-launch` (CPU, gloo; tests/test_launch.py): the N-rank self-launch AND the rank body's N > 1 plumbing without a GPU.
+    Every rank builds the real model (STUNet-S) and the real trainer's gradient-exchange state over host flat buffers; a step is
+    engine.backward's hook sequence over known per-rank gradients (the HIP compute is what is left out); the timed window, the
+    MAX-over-ranks clock, the exchange-off window and the `exchange` record are the real ones.  Rank 0 prints one JSON line."""
     import torch.distributed as dist
+    from anatomask_amd import modules as M
+    from anatomask_amd.engine import Spec
+    from anatomask_amd.trainer import AnatoMaskTrainer
     world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
     dist.init_process_group("gloo")
+    kw = M.STUNET_CONFIGS["S"]
+    torch.manual_seed(0)
+    m = M.build_spark(kw["dims"], kw["depth"], kw["width"], (48, 48, 48), 0.6)
+    named = list(m.named_parameters())
+    order = [(n, p) for n, p in named if n not in m._dead] + [(n, p) for n, p in named if n in m._dead]
+    offs, tot = {}, 0
+    for n, p in order:
+        if n in m._dead and "live_end" not in offs:
+            offs["live_end"] = tot
+        offs[n] = tot
+        tot += (p.numel() + 3) // 4 * 4
+    m._offs, m._live_end, m._pnames, m._gflat = offs, offs["live_end"], [n for n, _ in named], torch.zeros(tot)
+    m.spec = Spec(kw["dims"], kw["depth"], kw["width"], (48, 48, 48))
+    tr = AnatoMaskTrainer.__new__(AnatoMaskTrainer)
+    tr.model, tr.distributed, tr.pg, tr.world, tr._works, tr.exchange_log = m, True, None, world, [], []
+    tr.BUCKET_BYTES, tr.FLUSH_BYTES = 8 << 20, 4 << 20
+    tr._build_ranges()
+    tags = ["proj"] + [f"dec{i}" for i in reversed(range(4))] + ["densify"] + [f"stage{s}.0" for s in reversed(range(5))]
+
+    def step():
+        m._gflat[:m._live_end] = float(rank + 1)
+        tr.exchange_log.clear()
+        for t in tags:
+            tr._after_group(t)
+        tr._finish_exchange()
+        return m._gflat[:1] * tr.grad_scale
+    for _ in range(a.warmup):
+        step()
+    dt, _, out = timed_window(step, a.steps, world, dist, None)
+    ok = abs(float(out) - sum(range(1, world + 1)) / world) < 1e-6
+    tr.distributed = False
+    dtn, _, _ = timed_window(step, a.steps, world, dist, None)
+    tr.distributed = True
+    step()
     t = torch.tensor([float(rank)])
     dist.all_reduce(t)
-    dist.barrier()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": a.gpus, "world": world, "rank_sum": t.item(), "backend": "gloo"}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": a.gpus, "world": world, "rank_sum": t.item(), "backend": "gloo", "mean_gradient_ok": ok,
+                          "exchange": exchange_report(tr, m._live_end, world, dt, dtn, a.steps, "gloo")}), flush=True)
     dist.destroy_process_group()
 
 
@@ -198,6 +312,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (batch 4; the reference recipe in fp32 storage)")
     ap.add_argument("--dry-run-launch", action="store_true", help="CPU/gloo check of the N-rank self-launch (no GPU work)")
     a = ap.parse_args()
 
@@ -272,20 +387,23 @@ def main():
             tr.step(x, epoch=500)
         dtn, _, _ = timed_window(lambda: tr.step(x, epoch=500), a.steps, world, dist, dev)
         tr.distributed = True
+        tr.step(x, epoch=500)                                        # (refills exchange_log)
         if rank == 0:
-            res["exchange"] = {"backend": "rccl", "ranks": world, "gradient_bytes_per_step": int(model._live_end) * 4,
-                               "buckets": len(tr._ranges), "ms_per_step_without_exchange": round(dtn / a.steps * 1e3, 3),
-                               "exposed_ms": round((dt - dtn) / a.steps * 1e3, 3)}
+            res["exchange"] = exchange_report(tr, model._live_end, world, dt, dtn, a.steps, "rccl")
 
-    if rank == 0 and not a.no_roofline and a.size == "B" and a.patch == 128 and a.dtype == "bf16":
-        res["roofline"] = dominant_kernel_roofline(a.batch, dev, tr if world == 1 else None, x)
-        res["encoder_fwd_hbm"] = encoder_forward_hbm(model, x, dev)
+    if rank == 0 and not a.no_roofline and a.dtype == "bf16":
+        res["roofline"] = dominant_kernel_roofline(a.batch, dev, tr if world == 1 else None, x, C=kw["width"] // 8, S=a.patch, size=a.size)
+        enc = encoder_forward_hbm(model, x, dev, a.size, a.patch, a.mask_ratio)
+        if enc is not None:
+            res["encoder_fwd_hbm"] = enc
     if world > 1:
         dist.barrier()
     if rank == 0:
+        del tr, model, x
+        torch.cuda.empty_cache()
+        if world == 1 and not a.no_secondary and a.size == "B" and a.patch == 128:
+            res["secondary"] = secondary_lines(a, kw, dev, dtype)
         if sd_cpu is not None:
-            del tr, model, x
-            torch.cuda.empty_cache()
             try:
                 res["cpu_baseline"] = cpu_baseline(sd_cpu, kw)
             except Exception as e:                                   # e.g. host OOM: report, do not fail the bench

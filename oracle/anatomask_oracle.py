@@ -568,9 +568,10 @@ def student_loss_and_grads(cfg: Config, weights: Params, inp, mask, train: bool 
 
 
 def train_step(st: StepState, inp, mask1, sampler_keys, epoch: int, total_epoch: int, lr: float,
-               ema_decay: float, clip: float = 12.0, wd: float = 1e-5, eps: float = 1e-8):
+               ema_decay: float, clip: float = 12.0, wd: float = 1e-5, eps: float = 1e-8, return_grads: bool = False):
     """One AnatoMask step, P/pretrain_AntoMask.py:418-441 (fp32 branch), with the
-    random draws (mask1, sampler keys) supplied by the caller (teacher-forced)."""
+    random draws (mask1, sampler keys) supplied by the caller (teacher-forced).
+    return_grads: also return every live parameter gradient as autograd left it (before clip_grad_norm_ scales it)."""
     cfg = st.cfg
     with torch.no_grad():                                                   # :421-425
         inp1, rec1 = spark_forward(cfg, st.teacher, inp, mask1, train=False)
@@ -580,8 +581,27 @@ def train_step(st: StepState, inp, mask1, sampler_keys, epoch: int, total_epoch:
     loss, rec_loss, grads, new_buf = student_loss_and_grads(cfg, st.student, inp, mask, train=True)
     st.student.update(new_buf)                                              # BN running stats
     live = {k: g for k, g in grads.items() if g is not None}
+    raw = {k: g.clone() for k, g in live.items()} if return_grads else None   # what loss.backward() left in .grad (before clipping)
     gnorm = clip_grad_norm(live, clip)                                      # :437
     st.step += 1
     adamw_step(st.student, live, st.opt, st.step, lr, wd, eps=eps)          # :438
     ema_update(st.teacher, st.student, ema_decay)                           # :440
-    return {"loss": float(loss), "grad_norm": float(gnorm), "mask": mask, "recon_loss": recon, "rec_loss": rec_loss}
+    out = {"loss": float(loss), "grad_norm": float(gnorm), "mask": mask, "recon_loss": recon, "rec_loss": rec_loss}
+    if return_grads:
+        out["grads"] = raw
+    return out
+
+
+def plain_spark_step(st: StepState, inp, mask, lr: float, clip: float = 12.0, wd: float = 1e-5, eps: float = 1e-8):
+    """One plain-SparK step, the fp32 branch of P/pretrain.py:388-409 over P/spark3D.py:98-146: the random mask IS the training
+    mask (supplied by the caller), the loss is the normalised masked MSE computed in `forward`, then backward, clip_grad_norm_,
+    AdamW.  No teacher, no EMA."""
+    cfg = st.cfg
+    loss, rec_loss, grads, new_buf = student_loss_and_grads(cfg, st.student, inp, mask, train=True)
+    st.student.update(new_buf)
+    live = {k: g for k, g in grads.items() if g is not None}
+    gnorm = clip_grad_norm(live, clip)
+    st.step += 1
+    adamw_step(st.student, live, st.opt, st.step, lr, wd, eps=eps)
+    return {"loss": float(loss), "grad_norm": float(gnorm), "rec_loss": rec_loss}
+

@@ -7,6 +7,9 @@
               B=2 so that single tensors exceed 2 GB (plane-anchored buffer descriptors, 64-bit sample offsets): property checks.
 The 8-GPU variants of these configs differ only by the gradient all-reduce (tests/test_ddp_gloo.py, tools/ddp_two_ranks_one_gpu.py).
 """
+import functools
+import re
+
 import numpy as np
 import pytest
 import torch
@@ -16,6 +19,12 @@ from oracle import anatomask_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
+# Asserted bounds, each <= 3 x what was measured on MI355X (the measured values are printed by the tests):
+BF16_COS, BF16_REL = 0.9, 0.5          # per gradient tensor >= 64 elements, bf16 storage vs the fp32 oracle   (first run: to be tightened)
+F32_REL = 2e-2                          # per gradient tensor, fp32 storage
+F32_LOSS, F32_GNORM, F32_L2 = 2e-4, 2e-3, 2e-3
+LARGE_LOSS, LARGE_GNORM = 5e-3, 0.1
+
 
 def _build(cfg, W, dtype=torch.bfloat16, recompute=False):
     from anatomask_amd import modules as M
@@ -23,6 +32,45 @@ def _build(cfg, W, dtype=torch.bfloat16, recompute=False):
     if W is not None:
         m.load_state_dict({k: v.clone() for k, v in W.items()})
     return m.to(DEV)
+
+
+_ANALYTIC_ZERO = re.compile(r"conv_blocks_context\.\d+\.\d+\.conv[12]\.bias$")     # a conv bias under an InstanceNorm: d loss / d bias == 0
+
+
+def _per_tensor_errors(model, ref_grads, what):
+    """(relative L2 error, cosine) of EVERY live gradient tensor of the HIP model (model._G: raw sums of this step, before clipping)
+    against the oracle's autograd gradients; prints the five worst.  Tensors whose gradient is analytically zero are checked to BE
+    small (relative to the global norm) instead."""
+    gn = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref_grads.values())))
+    rows = []
+    for k, w in ref_grads.items():
+        g = model._G[k].detach().double().cpu().reshape(-1)
+        w = w.double().reshape(-1)
+        if _ANALYTIC_ZERO.search(k):
+            assert float(g.norm()) <= 2e-3 * gn and float(w.norm()) <= 1e-4 * gn, (k, float(g.norm()), float(w.norm()), gn)
+            continue
+        nw = float(w.norm())
+        rows.append((k, w.numel(), float((g - w).norm()) / nw, float((g * w).sum() / (g.norm() * nw + 1e-300))))
+    assert len(rows) >= len(ref_grads) - 2 * 5 * 3
+    worst = sorted(rows, key=lambda r: -r[2])[:5]
+    print(f"{what}: {len(rows)} gradient tensors, rel-L2 median {np.median([r[2] for r in rows]):.3e} max {worst[0][2]:.3e}; "
+          f"min cos {min(r[3] for r in rows):.6f}; worst: " + ", ".join(f"{r[0]}[{r[1]}] {r[2]:.2e}/{r[3]:.5f}" for r in worst))
+    return rows
+
+
+@functools.lru_cache(maxsize=None)
+def _oracle_step_b128():
+    """ONE fp32 CPU oracle step of STUNet-B at 128^3 (shared by the bf16- and the fp32-storage test)."""
+    cfg = O.Config.stunet_b((128, 128, 128), 0.6)
+    W0 = O.seeded_state(cfg, 5)
+    x = O.smooth_volume(1, cfg.input_size, 9)
+    g = torch.Generator().manual_seed(17)
+    mask1 = O.random_mask(cfg, 1, g)
+    keys = torch.rand(1, cfg.L, generator=g)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    st = O.StepState(cfg, W0)
+    o = O.train_step(st, x, mask1, keys, 0, 999, 1e-4, 0.999, return_grads=True)
+    return cfg, W0, x, mask1, keys, o
 
 
 def _step_properties(tr, cfg, out, B, epoch, total):
@@ -48,20 +96,12 @@ def _step_properties(tr, cfg, out, B, epoch, total):
 
 def test_config2_stunet_b_128_bf16_step_vs_oracle():
     from anatomask_amd.trainer import AnatoMaskTrainer
-    cfg = O.Config.stunet_b((128, 128, 128), 0.6)
-    assert (cfg.L, cfg.len_keep) == (512, 205)
-    W0 = O.seeded_state(cfg, 5)
-    assert sum(v.numel() for k, v in W0.items() if not O.is_buffer(k)) == 53_050_177   # 53.05 M parameters (SURVEY.md 2.2)
-    x = O.smooth_volume(1, cfg.input_size, 9)
-    g = torch.Generator().manual_seed(17)
-    mask1 = O.random_mask(cfg, 1, g)
-    keys = torch.rand(1, cfg.L, generator=g)
-    lr, decay = 1e-4, 0.999
     # ---- oracle step (fp32, CPU).  epoch 0 of 1000: len_loss = 0, the student mask is the keys' choice alone, so both sides
     # train on the SAME mask by construction (at epoch 500 a bf16-level difference of the teacher loss may swap a hard patch)
-    torch.set_num_threads(min(32, torch.get_num_threads()))
-    st = O.StepState(cfg, W0)
-    o = O.train_step(st, x, mask1, keys, 0, 999, lr, decay)
+    cfg, W0, x, mask1, keys, o = _oracle_step_b128()
+    assert (cfg.L, cfg.len_keep) == (512, 205)
+    assert sum(v.numel() for k, v in W0.items() if not O.is_buffer(k)) == 53_050_177   # 53.05 M parameters (SURVEY.md 2.2)
+    lr, decay = 1e-4, 0.999
     # ---- HIP step, bf16 storage
     m = _build(cfg, W0)
     tr = AnatoMaskTrainer(m, lr=lr, ema_decay=decay, total_epochs=1000, distributed=False)
@@ -75,6 +115,11 @@ def test_config2_stunet_b_128_bf16_step_vs_oracle():
     rl_h, rl_o = out["rec_loss"].cpu().numpy(), o["rec_loss"].numpy()
     assert np.abs(rl_h - rl_o).max() < 2e-2 * rl_o.max()                              # per-patch student loss
     assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < 0.1
+    # EVERY gradient tensor of the step against the oracle's autograd gradient of the same step (102 live tensors)
+    rows = _per_tensor_errors(m, o["grads"], "STUNet-B 128^3 bf16 storage")
+    for k, n_el, rel, cos in rows:
+        if n_el >= 64:
+            assert cos >= BF16_COS and rel <= BF16_REL, (k, n_el, rel, cos)
     # EMA identity at full size: teacher = decay * W0 + (1 - decay) * student, elementwise (fp32 flat buffers)
     n = m._live_end
     w0 = torch.cat([W0[k].flatten() for k in m._pnames if k not in m._dead]).to(DEV)
@@ -89,6 +134,80 @@ def test_config2_stunet_b_128_bf16_step_vs_oracle():
     out2 = tr.step(x.to(DEV), epoch=500)
     _step_properties(tr, cfg, out2, 1, 500, 999)
     assert n == m._flat.numel() - sum(((m._W[k].numel() + 3) // 4) * 4 for k in m._dead)
+
+
+def test_config2_stunet_b_128_fp32_storage_step_vs_oracle():
+    """The same step with fp32 storage (exact-f32 MFMA, the parity mode): every gradient tensor, loss, grad-norm and the teacher's
+    per-patch loss at reduction-order tolerances."""
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    cfg, W0, x, mask1, keys, o = _oracle_step_b128()
+    m = _build(cfg, W0, dtype=torch.float32)
+    tr = AnatoMaskTrainer(m, lr=1e-4, ema_decay=0.999, total_epochs=1000, distributed=False)
+    out = tr.step(x.to(DEV), epoch=0, mask1=mask1, keys=keys)
+    assert torch.equal(out["mask"].view(1, -1).bool().cpu(), o["mask"].view(1, -1))
+    rec_h, rec_o = out["recon_loss"].cpu().numpy(), o["recon_loss"].numpy()
+    print("STUNet-B 128^3 fp32 vs oracle fp32: loss %.7f / %.7f  grad-norm %.6f / %.6f  teacher-l2 rel err %.2e"
+          % (out["loss"].item(), o["loss"], out["grad_norm"].item(), o["grad_norm"], np.abs(rec_h - rec_o).max() / rec_o.max()))
+    assert np.abs(rec_h - rec_o).max() < F32_L2 * rec_o.max()
+    assert abs(out["loss"].item() - o["loss"]) < F32_LOSS * o["loss"]
+    assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < F32_GNORM
+    rows = _per_tensor_errors(m, o["grads"], "STUNet-B 128^3 fp32 storage")
+    for k, n_el, rel, cos in rows:
+        assert rel <= F32_REL and cos >= 1 - F32_REL, (k, n_el, rel, cos)
+
+
+def _student_step_vs_oracle(size, patch, mask_ratio, recompute, seed):
+    """Plain-SparK step (teacher-forced mask, no teacher) of a large-model SHAPE at a reduced patch against the oracle's autograd:
+    loss, gradient norm and every gradient tensor in bf16 storage, plus the eval-mode (teacher) forward's per-patch loss --
+    the kernel paths only STUNet-L/H reach (depth 2/3 identity-shortcut blocks, 64..1536 channels, one-voxel patches at level 4,
+    20- / 24- / 12-wide grids, activation recomputation) fail here if a tap is wrong."""
+    from anatomask_amd import engine, modules as M, ops
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    kw = M.STUNET_CONFIGS[size]
+    cfg = O.Config(kw["dims"], kw["depth"], kw["width"], (patch,) * 3, mask_ratio)
+    W0 = O.seeded_state(cfg, seed)
+    x = O.smooth_volume(1, cfg.input_size, seed + 1)
+    mask = O.random_mask(cfg, 1, torch.Generator().manual_seed(seed + 2))
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    loss_o, rl_o, grads_o, _ = O.student_loss_and_grads(cfg, W0, x, mask, train=True)
+    live = {k: g for k, g in grads_o.items() if g is not None}
+    gn_o = float(torch.sqrt(sum((g.double() ** 2).sum() for g in live.values())))
+    with torch.no_grad():
+        inp1, rec1 = O.spark_forward(cfg, W0, x, mask, train=False)
+        recon_o = O.teacher_patch_loss(inp1, rec1, mask)
+    m = _build(cfg, W0, recompute=recompute)
+    tr = AnatoMaskTrainer(m, lr=1e-4, total_epochs=1000, distributed=False, self_distill=False)
+    out = tr.step(x.to(DEV), epoch=0, mask1=mask)
+    loss_h, gn_h = out["loss"].item(), out["grad_norm"].item()
+    print(f"STUNet-{size} {patch}^3 bf16 vs oracle fp32: loss {loss_h:.6f} / {float(loss_o):.6f}  grad-norm {gn_h:.5f} / {gn_o:.5f}")
+    assert abs(loss_h - float(loss_o)) < LARGE_LOSS * float(loss_o)
+    assert abs(gn_h / gn_o - 1) < LARGE_GNORM
+    rl_h = out["rec_loss"].cpu().numpy()
+    assert np.abs(rl_h - rl_o.numpy()).max() < 2e-2 * rl_o.numpy().max()
+    rows = _per_tensor_errors(m, live, f"STUNet-{size} {patch}^3 bf16 storage")
+    for k, n_el, rel, cos in rows:
+        if n_el >= 64:
+            assert cos >= BF16_COS and rel <= BF16_REL, (k, n_el, rel, cos)
+    # eval-mode forward of the same weights (the teacher's path: folded BatchNorm epilogues, skipped visible patches)
+    B = 1
+    mi = ops.MaskInfo(mask.reshape(B, *m.spec.fmap).to(device=DEV, dtype=torch.uint8).contiguous())
+    W1 = _build(cfg, W0)                                   # (fresh copy: the step above updated `m`)
+    xs = x[:, 0].to(DEV).contiguous()
+    need = ops.MaskInfo((1 - mi.t).contiguous())
+    rec = engine.forward(W1.spec, W1._W, W1._pack, xs, mi, train=False, needed_patches=need)
+    recon_h, _, _, _ = ops.patch_loss_fwd(xs, rec, mi, normalized=False, want_loss=False)
+    err = np.abs(recon_h.cpu().numpy() - recon_o.numpy()).max() / recon_o.numpy().max()
+    print(f"STUNet-{size} {patch}^3 eval forward: teacher-l2 rel err {err:.2e}")
+    assert err < 2e-2
+    return tr, cfg, out
+
+
+def test_config4_shape_stunet_l_80_mask07_step_vs_oracle():
+    _student_step_vs_oracle("L", 80, 0.7, False, 31)
+
+
+def test_config5_shape_stunet_h_96_recompute_step_vs_oracle():
+    _student_step_vs_oracle("H", 96, 0.6, True, 41)
 
 
 def test_config4_stunet_l_160_mask07_properties():

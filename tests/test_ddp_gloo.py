@@ -36,25 +36,39 @@ def _worker(rank, world, port, q):
         m._flat = torch.cat([torch.cat([p.detach().flatten(), torch.zeros((-p.numel()) % 4)]) for _, p in order])
         m._gflat = torch.zeros(tot)
         tr = AnatoMaskTrainer.__new__(AnatoMaskTrainer)
-        tr.model, tr.distributed, tr.pg, tr.world, tr._works = m, True, None, world, []
+        tr.model, tr.distributed, tr.pg, tr.world, tr._works, tr.exchange_log = m, True, None, world, [], []
+        tr.BUCKET_BYTES, tr.FLUSH_BYTES = 256 << 10, 96 << 10     # small limits so that this 3 M-parameter model splits and merges
+        from anatomask_amd.engine import Spec
+        m.spec = Spec([8, 16, 32, 64, 128, 128], [1] * 6, 128, (32, 48, 64))
         AnatoMaskTrainer._build_ranges(tr)
         # 1. start-up broadcast makes the replicas identical (P/pretrain_AnatoMask_DDP.py:239-240)
         dist.broadcast(m._flat, 0)
         ref = m._flat.clone(); dist.broadcast(ref, 0)
         assert torch.equal(m._flat, ref)
-        # 2. ranges tile the live region exactly, in backward completion order decoder -> densify -> stage4..0
+        # 2. the groups tile the live region exactly; tags in backward completion order proj, dec3..0, densify, stage4.0 .. stage0.0
         r = tr._ranges
+        order = ["proj"] + [f"dec{i}" for i in reversed(range(4))] + ["densify"] + [f"stage{s}.0" for s in reversed(range(5))]
+        assert set(r) == set(order)
         spans = sorted(r.values())
         assert spans[0][0] == 0 and spans[-1][1] == m._live_end
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
-        assert r["decoder"][0] == offs["dense_decoder.dec.0.up_sample.weight"] and r["densify"][1] == m._live_end
-        assert r["stage0"][0] == 0 and r["stage4"][1] == r["decoder"][0]
-        # 3. per-group async all-reduce from the backward hook == mean over ranks
+        assert r["dec0"][0] == offs["dense_decoder.dec.0.up_sample.weight"] and r["densify"][1] == m._live_end
+        assert r["stage0.0"][0] == 0 and r["stage4.0"][1] == r["dec0"][0] and r["proj"][1] == r["densify"][0]
+        # 3. async all-reduce from the backward hook == mean over ranks; the exchange starts before backward ends, no collective
+        #    exceeds BUCKET_BYTES, every live element is sent exactly once
         m._gflat[:m._live_end] = float(rank + 1)
         m._gflat[m._live_end:] = 123.0                           # dead tensors are never exchanged
-        for tag in ["decoder", "densify"] + [f"stage{s}" for s in reversed(range(5))]:
+        sent_after = {}
+        for tag in order:
             tr._after_group(tag)
+            sent_after[tag] = len(tr.exchange_log)
+        assert sent_after["dec0"] > 0, "nothing was sent before the encoder's backward"
         tr._finish_exchange()
+        log = tr.exchange_log
+        assert all((b - a) * 4 <= tr.BUCKET_BYTES for a, b in log) and len(log) > len(order) // 2
+        cover = sorted(log)
+        assert cover[0][0] == 0 and cover[-1][1] == m._live_end and all(x[1] == y[0] for x, y in zip(cover, cover[1:]))
+        assert not tr._pending and not tr._works
         # the buffer holds the SUM over ranks; DDP's 1/world is a factor of the fused optimizer kernel (am_adamw_ema grad_scale)
         want = sum(range(1, world + 1)) / world
         assert AnatoMaskTrainer.grad_scale.fget(tr) == 1.0 / world

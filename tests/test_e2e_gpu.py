@@ -19,6 +19,13 @@ from tests.test_oracle_golden import (GRAD_COS_MIN, GRAD_RTOL, GRAD_RTOL_MEDIAN,
                                       STEP1_FLIPPED, STEP1_UPDATE_MEDIAN, _zero_grad_bias, delta_metrics, mismatch_fraction)
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    """a port the OS hands out now (fixed rendezvous ports collide when two test runs share a host)."""
+    from anatomask_amd.launch import free_port
+    return free_port()
+
 DEV = "cuda:0"
 
 
@@ -410,7 +417,7 @@ def test_trainer_distributed_path_single_rank_nccl():
     r, f = load("train_tiny.npz"), load("forward_tiny.npz")
     cfg = tiny_cfg(f)
     W0 = fixture_weights(cfg, load("forward_tiny.npz"))
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
         ep, tot = (int(v) for v in r["epoch"])
@@ -443,8 +450,13 @@ def test_checkpoint_roundtrip_and_finetune_handoff(tmp_path):
     a = fresh()
     a.step(x, epoch=500)
     p = str(tmp_path / "STUNet_B_head_latest.pt")
-    checkpoint.save_checkpoint(p, a, [1.0], 0)
-    ck = torch.load(p, weights_only=False)
+    # the data feed's generator states ride along as tensors / python scalars (anatomask_amd.pretrain.rng_state_to_plain) ...
+    from anatomask_amd.pretrain import rng_state_to_plain
+    fs = {0: {"loader_rng": {0: rng_state_to_plain(np.random.RandomState(3))}, "aug_rng": rng_state_to_plain(np.random.RandomState(4))}}
+    checkpoint.save_checkpoint(p, a, [1.0], 0, extra={"ema_loss": 1.0, "feed_state": fs})
+    # ... so that the reference's hand-off, a PLAIN torch.load(fname) (weights_only=True from torch 2.6 on), accepts the file
+    ck = torch.load(p)
+    assert checkpoint.peek_extra(p, "feed_state")[0]["loader_rng"][0]["pos"] == 624
     assert set(["network_weights", "optimizer_state", "grad_scaler_state", "train_loss", "current_epoch"]) <= set(ck)
     assert ck["grad_scaler_state"] is None and len(ck["network_weights"]) == 131
     enc = checkpoint.encoder_weights_for_finetuning(ck["network_weights"])
@@ -565,7 +577,7 @@ def test_two_ranks_on_one_gpu_stay_in_sync():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29541", os.path.join(root, "tools", "ddp_two_ranks_one_gpu.py")],
+                        "--master-port", str(_free_port()), os.path.join(root, "tools", "ddp_two_ranks_one_gpu.py")],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("weights identical across ranks: True; teacher identical: True") == 2, r.stdout[-2000:]
@@ -705,7 +717,7 @@ def test_syncbn_two_ranks_equal_one_big_batch():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29547", os.path.join(root, "tools", "syncbn_two_ranks.py")],
+                        "--master-port", str(_free_port()), os.path.join(root, "tools", "syncbn_two_ranks.py")],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("syncbn ok: True") == 2, r.stdout[-2000:]
@@ -733,6 +745,39 @@ def test_graphed_step_replays_the_eager_step():
                 assert torch.allclose(b._dyn_dev.cpu(), torch.tensor(want, dtype=torch.float32))
         assert b._graph is not None and a.step_count == b.step_count == 5
         n = a.model._live_end
+        assert torch.equal(a.model._flat, b.model._flat) and torch.equal(a.teacher.ema._flat, b.teacher.ema._flat)
+        assert torch.equal(a.m[:n], b.m[:n]) and torch.equal(a.v[:n], b.v[:n])
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
+
+
+def test_graphed_step_without_host_sync_equals_eager():
+    """A training loop synchronises once per epoch, not per step: 6 replays enqueued back to back with NO host synchronisation in
+    between (the host runs steps ahead of the GPU) must give the eager loop's weights, moments and teacher bit for bit -- AdamW's
+    bias corrections of step N must be the ones step N's kernel reads, whatever the host has written since."""
+    from anatomask_amd import modules as M, ops
+    from anatomask_amd.trainer import AnatoMaskTrainer
+
+    def make():
+        torch.manual_seed(3)
+        model = M.build_spark([32, 32, 48, 64, 64, 64], [1] * 6, 128, (48, 48, 48), 0.6, compute_dtype=torch.bfloat16).to(DEV)
+        return AnatoMaskTrainer(model, lr=1e-3, total_epochs=100, seed=11, deterministic_wgrad=True)
+    xs = [np_volume(2, (48, 48, 48), 60 + i).to(DEV) for i in range(8)]
+    try:
+        a, b = make(), make()
+        for x in xs:
+            a.step(x, epoch=50)
+        for x in xs[:3]:                                   # 2 eager calls + the capture
+            b.graphed_step(x, epoch=50)
+        torch.cuda.synchronize()
+        busy = torch.empty(1 << 28, device=DEV)
+        for _ in range(20):
+            busy.add_(1.0)                                 # the GPU is behind: every replay below is enqueued long before it runs
+        for x in xs[3:]:
+            b.graphed_step(x, epoch=50)                    # no .item(), no synchronize
+        torch.cuda.synchronize()
+        n = a.model._live_end
+        assert a.step_count == b.step_count == 8
         assert torch.equal(a.model._flat, b.model._flat) and torch.equal(a.teacher.ema._flat, b.teacher.ema._flat)
         assert torch.equal(a.m[:n], b.m[:n]) and torch.equal(a.v[:n], b.v[:n])
     finally:
@@ -870,7 +915,7 @@ def test_two_ranks_same_data_equal_the_single_process_run_bit_for_bit():
         ops.DETERMINISTIC_WGRAD = False
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29547", os.path.join(root, "tools", "ddp_same_data_det.py")],
+                        "--master-port", str(_free_port()), os.path.join(root, "tools", "ddp_same_data_det.py")],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     got = re.findall(r"rank (\d) sha256 ([0-9a-f]{64})", r.stdout)

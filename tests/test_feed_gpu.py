@@ -137,3 +137,27 @@ def test_feed_sustains_the_step_rate_at_production_shape(tmp_path):
         assert x.shape == (B, 1, 128, 128, 128) and rate > 100.0, rate
     finally:
         pf.close()
+
+
+@pytest.mark.timeout(120)
+def test_feed_with_a_tiny_pool_and_a_host_far_ahead_of_the_gpu(tmp_path):
+    """The training loop synchronises once per epoch: the host can enqueue many steps ahead of the GPU, and every queued H2D copy
+    holds its pooled pinned buffer until the copy has run.  With a pool of exactly the steady-state size and a slow GPU step the
+    feed must keep going (DeviceFeed reaps finished copies before it blocks on the loader queue and waits for the oldest copy when
+    more than `depth` are in flight) -- 40 un-synchronised iterations through a 4-buffer pool, every batch distinct."""
+    make_synthetic_folder(str(tmp_path), 7)
+    ds = PreprocessedDataset(str(tmp_path))
+    final = (32, 48, 64)
+    pool = PinnedPool((2, 1, *final), n=4)
+    pf = PrefetchLoader(lambda w: PatchLoader3D(ds, 2, final, 0.33, seed=90 + w, final_patch_size=final, pool=pool), n_workers=2, num_cached=1)
+    try:
+        feed = DeviceFeed(pf, DEV)
+        acc = torch.zeros(40, device=DEV, dtype=torch.float64)
+        for i in range(40):
+            x = next(feed)
+            torch.cuda._sleep(20_000_000)                              # a slow "training step" on the compute stream (~10 ms), never synchronised
+            acc[i] = x.double().abs().sum()
+        torch.cuda.synchronize()
+        assert len(set(acc.tolist())) > 20 and bool((acc > 0).all())
+    finally:
+        pf.close()

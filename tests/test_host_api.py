@@ -44,3 +44,22 @@ def test_mask_and_schedules_and_wrappers():
     groups = M.get_param_groups(m, nowd_keys={"mask_token"})
     assert len(groups) == 2 and sum(len(g["params"]) for g in groups) == sum(1 for _ in m.parameters())
     assert M.ema_decay_for_epoch(0, 1000) == pytest.approx(0.999) and M.ema_decay_for_epoch(999, 1000) == pytest.approx(0.9999)
+
+
+def test_feed_rng_state_is_weights_only_safe_and_round_trips(tmp_path):
+    """The checkpoint's `feed_state` (loader / augmenter RandomStates) must survive the reference's plain `torch.load(fname)`
+    (nnunetv2/run/load_pretrained_weights.py; weights_only=True by default from torch 2.6): tensors and python scalars only."""
+    import numpy as np
+    from anatomask_amd.pretrain import default_workers, rng_state_from_plain, rng_state_to_plain
+    rs = np.random.RandomState(1234)
+    rs.standard_normal(7)                                                         # has_gauss / cached_gaussian populated
+    st = {"feed_state": {0: {"loader_rng": {0: rng_state_to_plain(rs)}, "aug_rng": rng_state_to_plain(np.random.RandomState(5))}},
+          "network_weights": {"module.x": torch.zeros(2)}, "grad_scaler_state": None, "train_loss": [1.0], "current_epoch": 0}
+    p = str(tmp_path / "ck.pt")
+    torch.save(st, p)
+    ck = torch.load(p)                                                            # default arguments, as the reference calls it
+    want = rs.uniform(size=5), rs.standard_normal(3)
+    rs2 = np.random.RandomState(0)
+    rng_state_from_plain(rs2, ck["feed_state"][0]["loader_rng"][0])
+    assert np.array_equal(rs2.uniform(size=5), want[0]) and np.array_equal(rs2.standard_normal(3), want[1])
+    assert 1 <= default_workers(8) <= 8 and default_workers(1) >= default_workers(8)

@@ -14,13 +14,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.timeout(180)
 def test_bench_self_launch_two_ranks_gloo():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-launch"], capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run-launch", "--steps", "3", "--warmup", "1"], capture_output=True,
                        text=True, timeout=170, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout                       # ONE line, from rank 0
     out = json.loads(lines[0])
-    assert out == {"dry_run": True, "n_gpus": 2, "world": 2, "rank_sum": 1.0, "backend": "gloo"}
+    ex = out.pop("exchange")
+    assert out == {"dry_run": True, "n_gpus": 2, "world": 2, "rank_sum": 1.0, "backend": "gloo", "mean_gradient_ok": True}
+    # the rank body's N > 1 branches ran for real (gloo): timed window, exchange-off window, the `exchange` record of the JSON line
+    assert ex["ranks"] == 2 and ex["backend"] == "gloo" and ex["gradient_bytes_per_step"] > 50e6          # STUNet-S: 13.3 M parameters
+    assert ex["collectives_per_step"] >= 4 and ex["largest_collective_bytes"] <= 8 << 20
+    assert ex["first_collective_after_tag"].startswith("dec") and ex["ms_per_step_without_exchange"] >= 0
 
 
 def test_launch_command_and_noop_under_a_launcher(monkeypatch):

@@ -298,6 +298,107 @@ def test_conv_fwd_dgrad_wgrad(ops, dtype, case, sparse):
     close(dw.cpu(), wr.grad, TOL[dtype], "conv wgrad")
 
 
+# ------------------------------------------------------------------ kernel branches only STUNet-L / STUNet-H reach
+# (P/pretrain_AnatoMask_DDP.py:222-229: depth 2/3, dims 64..1024 / 96..1536, patches 160^3 / 192^3 -> 10^3 / 12^3 grids of
+# one-voxel patches at level 4, 20- / 24-wide decoder grids, 96-channel level 0).  Every case: forward, data gradient and weight
+# gradient against F.conv3d / F.conv_transpose3d autograd on the same bf16-rounded inputs.
+def _conv_case(ops, dtype, cin, cout, k, s, so, B, sparse, bs_out, det=False, seed=50, keep_frac=0.4):
+    si = tuple(v * s for v in so)
+    x = q(rnd(B, cin, *si, seed=seed), dtype)
+    w = q(rnd(cout, cin, k, k, k, seed=seed + 1, scale=1.0 / np.sqrt(cin * k ** 3)), dtype)
+    bias = rnd(cout, seed=seed + 2)
+    dy = q(rnd(B, cout, *so, seed=seed + 3), dtype)
+    mask = mi = mo = mi_in = None
+    bs_in = bs_out + (1 if s == 2 else 0)
+    if sparse:
+        f = tuple(v >> bs_out for v in so)
+        assert all((fv << bs_out) == v for fv, v in zip(f, so))
+        mask = mk_mask(B, f, max(1, int(round(keep_frac * f[0] * f[1] * f[2]))), seed=seed + 4)
+        mi = ops.MaskInfo.from_bool(mask, DEV)
+        mo, mi_in = O.upsample_mask(mask, so).float(), O.upsample_mask(mask, si).float()
+        x, dy = x * mi_in, dy * mo
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, bias, stride=s, padding=k // 2)
+    if sparse:
+        yr = yr * mo
+    yr.backward(dy)
+    wd = w.to(DEV)
+    y = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), ops.pack_weight(wd, dtype, False, False), bias.to(DEV), so, k, s,
+                   in_mask=mi, in_bshift=bs_in, out_mask=mi, out_bshift=bs_out)
+    close(from_cl(y), yr.detach(), TOL[dtype], "conv fwd", mo)
+    dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), ops.pack_weight(wd, dtype, False, True), None, si, k, s,
+                    in_mask=mi, in_bshift=bs_out, out_mask=mi, out_bshift=bs_in)
+    close(from_cl(dx), xr.grad, TOL[dtype], "conv dgrad", mi_in)
+    for d in ([False, True] if det else [False]):
+        ops.DETERMINISTIC_WGRAD = d
+        try:
+            dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dtype), to_cl(dy, dtype), k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out)
+        finally:
+            ops.DETERMINISTIC_WGRAD = False
+        dw = torch.zeros_like(w, device=DEV)
+        ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+        close(dw.cpu(), wr.grad, TOL[dtype], f"conv wgrad (det={d})")
+
+
+@pytest.mark.parametrize("case", [
+    # cin, cout, k, s, output grid, B, sparse, out bshift
+    (1536, 1536, 3, 1, (12, 12, 12), 1, True, 0),     # STUNet-H stage 4: 1728 wgrad tiles (slot count of conv_wgrad.hip launch()), one-voxel patches
+    (1024, 1024, 3, 1, (10, 10, 10), 2, True, 0),     # STUNet-L stage 4 on its 10^3 grid (ragged 4x8x8 bricks)
+    (1024, 1024, 3, 1, (5, 20, 20), 1, False, 0),     # STUNet-L decoder block 0 convs: dense, 20-wide (plane bricks, 256 tiles x 3 groups)
+    (1536, 768, 3, 1, (3, 24, 24), 1, False, 0),      # STUNet-H decoder block 0 second conv: 24-wide
+    (768, 1536, 3, 2, (12, 12, 12), 1, True, 0),      # STUNet-H stage 4 strided conv1 (24^3 two-voxel patches -> 12^3 one-voxel patches)
+    (512, 1024, 1, 2, (10, 10, 10), 1, True, 0),      # STUNet-L stage 4 1x1 stride-2 shortcut
+])
+def test_conv_large_model_deep_levels(ops, case):
+    cin, cout, k, s, so, B, sparse, bs = case
+    _conv_case(ops, torch.bfloat16, cin, cout, k, s, so, B, sparse, bs, det=True)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    (96, 96, 3, 1, (16, 16, 32), 1, True, 4),         # STUNet-H level 0: 96-channel operands -> three 32-wide cy tiles in the weight gradient
+    (96, 96, 3, 1, (8, 16, 32), 1, False, 0),         #   ... dense (plane bricks, MI = 2)
+    (96, 192, 3, 2, (8, 8, 16), 2, True, 3),          # STUNet-H level 1 strided conv (full-resolution S2 staging, 96-channel X)
+    (192, 96, 3, 1, (4, 8, 16), 2, False, 0),         # decoder output level of H: Cx 192 / Cy 96
+    (64, 64, 3, 1, (10, 10, 10), 2, True, 0),         # one-voxel patches on a 10^3 grid, thin channels (brick straddles patches in every direction)
+    (128, 128, 3, 1, (12, 12, 12), 1, True, 0),       # ... 12^3 (pick_tiling counts bricks per dimension)
+    (64, 128, 3, 2, (10, 10, 10), 1, True, 0),        # stride 2 onto one-voxel patches
+    (256, 256, 3, 1, (20, 20, 20), 1, True, 1),       # STUNet-L stage 3: two-voxel patches on a 20-wide grid
+])
+def test_conv_large_model_shapes(ops, dtype, case):
+    cin, cout, k, s, so, B, sparse, bs = case
+    _conv_case(ops, dtype, cin, cout, k, s, so, B, sparse, bs, det=(dtype == torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(64, 64, (5, 20, 20), 1), (96, 48, (3, 24, 24), 1), (128, 128, (5, 10, 10), 2), (64, 32, (6, 12, 12), 1), (32, 32, (10, 40, 40), 1)])
+def test_conv_transpose_large_model_grids(ops, dtype, case):
+    """ConvTranspose3d on the q grids of STUNet-L 160^3 (10, 20, 40) and STUNet-H 192^3 (12, 24): conv_igemm.hip brick_shape picks the
+    brick that pads the (h, w) plane less (4x8x8 on 20 / 24, 4x4x16 on 40) -- forward, data gradient, weight gradient."""
+    cin, cout, si, B = case
+    so = tuple(2 * v for v in si)
+    x = q(rnd(B, cin, *si, seed=61), dtype)
+    w = q(rnd(cin, cout, 4, 4, 4, seed=62, scale=1.0 / np.sqrt(cin * 8)), dtype)
+    bias = rnd(cout, seed=63)
+    dy = q(rnd(B, cout, *so, seed=64), dtype)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    F.conv_transpose3d(xr, wr, bias, stride=2, padding=1).backward(dy)
+    yr = F.conv_transpose3d(x, w, bias, stride=2, padding=1)
+    y = ops.conv3d(ops.CONVT_FWD, to_cl(x, dtype), ops.pack_weight(w.to(DEV), dtype, True, False), bias.to(DEV), so, 4, 2)
+    close(from_cl(y), yr, TOL[dtype], "convT fwd")
+    dx = ops.conv3d(ops.CONVT_DGRAD, to_cl(dy, dtype), ops.pack_weight(w.to(DEV), dtype, True, True), None, si, 4, 2)
+    close(from_cl(dx), xr.grad, TOL[dtype], "convT dgrad")
+    for det in ([False, True] if dtype == torch.bfloat16 else [False]):
+        ops.DETERMINISTIC_WGRAD = det
+        try:
+            dwp = ops.conv3d_wgrad(ops.CONVT_FWD, to_cl(x, dtype), to_cl(dy, dtype), 4, 2)
+        finally:
+            ops.DETERMINISTIC_WGRAD = False
+        dw = torch.zeros_like(w, device=DEV)
+        ops.unpack_grad(dwp, dw, transposed_conv=True, accumulate=False)
+        close(dw.cpu(), wr.grad, TOL[dtype], f"convT wgrad (det={det})")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("ch", [(32, 32), (16, 16), (64, 64)])
 def test_conv_transpose(ops, dtype, ch):

@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anatomask_amd import build as _build  # noqa: E402
 if os.environ.get("AM_PC_ABLATE"):
-    os.environ["AM_HIP_LIB"] = _build.build(verbose=False, ablate=True)
+    __import__("anatomask_amd.hip", fromlist=["hip"]).use_library(_build.build(verbose=False, ablate=True))
 from anatomask_amd import ops  # noqa: E402
 
 dev = "cuda:0"

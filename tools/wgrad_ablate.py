@@ -6,7 +6,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from anatomask_amd import build as _build  # noqa: E402
-os.environ["AM_HIP_LIB"] = _build.build(verbose=False, ablate=True)      # tools-only library with the -DAM_ABLATE switches
+__import__("anatomask_amd.hip", fromlist=["hip"]).use_library(_build.build(verbose=False, ablate=True))      # tools-only library with the -DAM_ABLATE switches
 from anatomask_amd import ops  # noqa: E402
 
 dev = "cuda:0"

@@ -5,18 +5,18 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/walk
 mkdir -p $out
 cd $root
-export AM_HIP_LIB=$root/anatomask_amd/libanatomask_hip_ablate.so
+alt=$root/anatomask_amd/libanatomask_hip_ablate.so    # bound explicitly through tools/with_lib.py (the product loader reads no environment)
 for b in 2 16; do
   for w in 0 1; do for pl in 0 1; do
-    echo "== B=$b walk=$w plane=$pl"; AM_CB_BATCH=$b AM_WG_WALK=$w AM_WG_PLANE=$pl python3 tools/conv_bench.py wgrad 20
+    echo "== B=$b walk=$w plane=$pl"; AM_CB_BATCH=$b AM_WG_WALK=$w AM_WG_PLANE=$pl python3 tools/with_lib.py $alt tools/conv_bench.py wgrad 20
   done; done
-  for sg in 8 16 32 128; do echo "== B=$b walk=1 plane=1 seg=$sg"; AM_CB_BATCH=$b AM_WG_SEG=$sg python3 tools/conv_bench.py wgrad 20; done
+  for sg in 8 16 32 128; do echo "== B=$b walk=1 plane=1 seg=$sg"; AM_CB_BATCH=$b AM_WG_SEG=$sg python3 tools/with_lib.py $alt tools/conv_bench.py wgrad 20; done
 done 2>&1 | grep -v amdgpu.ids | tee $out/times.txt
 cd /tmp && export TMPDIR=/tmp
 for w in 0 1; do for pl in 0 1; do
-  AM_WG_WALK=$w AM_WG_PLANE=$pl rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_w${w}p$pl -- python3 $root/tools/conv_bench.py wgrad 3 > $out/fetch_w${w}p$pl.log 2>&1
+  AM_WG_WALK=$w AM_WG_PLANE=$pl rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_w${w}p$pl -- python3 $root/tools/with_lib.py $alt $root/tools/conv_bench.py wgrad 3 > $out/fetch_w${w}p$pl.log 2>&1
 done; done
-AM_WG_SEG=128 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_w1p1s128 -- python3 $root/tools/conv_bench.py wgrad 3 > $out/fetch_w1p1s128.log 2>&1
+AM_WG_SEG=128 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch_w1p1s128 -- python3 $root/tools/with_lib.py $alt $root/tools/conv_bench.py wgrad 3 > $out/fetch_w1p1s128.log 2>&1
 cd $root
 python3 - <<'PY'
 import csv, glob, collections
