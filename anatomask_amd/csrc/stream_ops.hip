@@ -1247,20 +1247,136 @@ __global__ __launch_bounds__(256) void stem_conv_wgrad_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------ 1x1 projection C -> 1 (P/decoder3D.py:51,61)
+// psc / psh != nullptr: x is the INPUT of a per-channel affine map (a train-mode BatchNorm whose output is never materialised):
+//   rec = b + sum_c w[c] * (x[c] * psc[c] + psh[c])  =  (b + sum_c w[c] psh[c]) + sum_c (w[c] psc[c]) x[c]
 template <typename T>
 __global__ __launch_bounds__(256) void proj_fwd_kernel(const T* __restrict__ x, long nvox, int C, const float* __restrict__ w,
-                                                       const float* __restrict__ b, float* __restrict__ rec) {
+                                                       const float* __restrict__ b, const float* __restrict__ psc,
+                                                       const float* __restrict__ psh, float* __restrict__ rec) {
   constexpr int EPC = TT<T>::EPC;
   const long v = (long)blockIdx.x * 256 + threadIdx.x;
   if (v >= nvox) return;
   float s = b[0];
-  for (int c = 0; c < C; c += EPC) {
-    float f[EPC];
-    chunk_to_f<T>(*(const u32x4*)(x + (size_t)v * C + c), f);
+  if (psc) {
+    for (int c = 0; c < C; c += EPC) {
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + (size_t)v * C + c), f);
 #pragma unroll
-    for (int i = 0; i < EPC; ++i) s += f[i] * w[c + i];
+      for (int i = 0; i < EPC; ++i) s += (f[i] * psc[c + i] + psh[c + i]) * w[c + i];       // (uniform operands: scalar loads)
+    }
+  } else {
+    for (int c = 0; c < C; c += EPC) {
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + (size_t)v * C + c), f);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) s += f[i] * w[c + i];
+    }
   }
   rec[v] = s;
+}
+
+// ---- projection head + the BatchNorm in front of it, backward (P/decoder3D.py:22 -> :51,61) -------------------------------------
+// rec = proj(o), o = BN_train(x) = x * scale + shift (no activation, no skip: the LAST decoder block).  The gradient wrt o is the
+// rank-1 tensor g[v][c] = drec[v] * w[c], so neither o nor g has to exist in memory:
+//   S0 = sum_v drec[v],  S1[c] = sum_v drec[v] * (x[v][c] - mean[c])                         (ONE pass over x and drec)
+//   proj:  db += S0,  dw[c] += sum_v drec * o = scale[c] * S1[c] + beta[c] * S0              (shift + mean * scale = beta)
+//   BN:    sum g = w S0,  sum g xhat = rstd w S1  ->  dbeta += w S0, dgamma += rstd w S1,
+//          dx[v][c] = k0 w drec[v] - k1 - k2 xhat[v][c],  k0 = gamma rstd, k1 = k0 w S0 / n, k2 = k0 rstd w S1 / n   (second pass)
+// Against proj_bwd + norm_bwd_reduce + norm_bwd_apply this drops the write and two reads of g and the read of o (forward: o's
+// write + read), 6 of the 13 tensor-sized transfers of the head.
+struct ProjNormFin {
+  unsigned* ticket; double n;
+  const float *gamma, *beta, *rstd, *scale, *w;
+  float *k0w, *k1, *k2, *dgamma, *dbeta, *dw, *db;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void proj_norm_bwd_reduce_kernel(const T* __restrict__ x, const float* __restrict__ drec, long nvox, int C,
+                                                                   int vpw, const float* __restrict__ mean, double* __restrict__ acc,
+                                                                   ProjNormFin fin) {
+  constexpr int EPC = TT<T>::EPC;
+  __shared__ float red[256 * 8];
+  __shared__ float redb[4];
+  __shared__ double s0sh;
+  Walk<T> wk(C);
+  float s1[EPC], mu[EPC], sb = 0.f;
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { s1[i] = 0.f; mu[i] = wk.live ? mean[wk.cl * EPC + i] : 0.f; }
+  const long v0 = (long)blockIdx.x * vpw, v1 = min(v0 + (long)vpw, nvox);
+  if (wk.live)
+    for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+      const float d = drec[v];
+      float f[EPC];
+      chunk_to_f<T>(*(const u32x4*)(x + (size_t)v * C + wk.cl * EPC), f);
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) s1[i] += d * (f[i] - mu[i]);
+      if (wk.cl == 0) sb += d;
+    }
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) red[threadIdx.x * 8 + i] = s1[i];
+  sb = warp_sum(sb);
+  if ((threadIdx.x & 63) == 0) redb[threadIdx.x >> 6] = sb;
+  __syncthreads();
+  double* ar = acc + (size_t)(blockIdx.x % NREP) * (C + 1);
+  if (threadIdx.x < wk.cpv) {
+    double a1[EPC];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) a1[i] = 0.0;
+    for (int vl = 0; vl < wk.vpp; ++vl)
+#pragma unroll
+      for (int i = 0; i < EPC; ++i) a1[i] += red[(vl * wk.cpv + threadIdx.x) * 8 + i];
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) atomicAdd(&ar[threadIdx.x * EPC + i], a1[i]);
+  }
+  if (threadIdx.x == 0) atomicAdd(&ar[C], (double)redb[0] + (double)redb[1] + (double)redb[2] + (double)redb[3]);
+  // ---- last workgroup: coefficients of the apply pass + the four parameter gradients; accumulators re-zeroed
+  if (!last_workgroup(fin.ticket)) return;
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int r = 0; r < NREP; ++r) t += __longlong_as_double(atomicExch((unsigned long long*)&acc[(size_t)r * (C + 1) + C], 0ull));
+    s0sh = t;
+    fin.db[0] += (float)t;
+  }
+  __syncthreads();
+  const double S0 = s0sh;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double S1 = 0.0;
+    for (int r = 0; r < NREP; ++r) S1 += __longlong_as_double(atomicExch((unsigned long long*)&acc[(size_t)r * (C + 1) + c], 0ull));
+    const double wc = fin.w[c], rs = fin.rstd[c];
+    const double b1 = wc * S0, b2 = rs * wc * S1;
+    const float gr = fin.gamma[c] * fin.rstd[c];
+    fin.k0w[c] = gr * fin.w[c]; fin.k1[c] = gr * (float)(b1 / fin.n); fin.k2[c] = gr * (float)(b2 / fin.n);
+    fin.dgamma[c] += (float)b2;
+    fin.dbeta[c] += (float)b1;
+    fin.dw[c] += (float)((double)fin.scale[c] * S1 + (double)fin.beta[c] * S0);
+  }
+  if (threadIdx.x == 0) atomicExch(fin.ticket, 0u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void proj_norm_bwd_apply_kernel(const T* __restrict__ x, const float* __restrict__ drec, long nvox, int C,
+                                                                  int vpw, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ k0w, const float* __restrict__ k1,
+                                                                  const float* __restrict__ k2, T* __restrict__ dx) {
+  constexpr int EPC = TT<T>::EPC;
+  Walk<T> wk(C);
+  if (!wk.live) return;
+  float mu[EPC], c0[EPC], c1[EPC], c2[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) {
+    const int c = wk.cl * EPC + i;
+    mu[i] = mean[c]; c0[i] = k0w[c]; c1[i] = k1[c]; c2[i] = k2[c] * rstd[c];
+  }
+  const long v0 = (long)blockIdx.x * vpw, v1 = min(v0 + (long)vpw, nvox);
+  for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
+    const float d = drec[v];
+    const size_t off = (size_t)v * C + wk.cl * EPC;
+    float f[EPC], r[EPC];
+    chunk_to_f<T>(*(const u32x4*)(x + off), f);
+#pragma unroll
+    for (int i = 0; i < EPC; ++i) r[i] = c0[i] * d - c1[i] - c2[i] * (f[i] - mu[i]);
+    *(u32x4*)(dx + off) = f_to_chunk<T>(r);
+  }
 }
 
 // dx[v][c] = drec[v]*w[c];  dw[c] += sum_v drec[v]*x[v][c];  db += sum_v drec[v]
@@ -1900,12 +2016,33 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
   return 0;
 }
 
-int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b, float* rec, void* stream) {
+int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b, const float* pre_scale, const float* pre_shift,
+                float* rec, void* stream) {
   CHK_C(C);
+  if ((pre_scale == nullptr) != (pre_shift == nullptr)) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)((nvox + 255) / 256);
-  DISPATCH_T(dtype, AM_LAUNCH(proj_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, nvox, C, w, b, rec),
-             AM_LAUNCH(proj_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, nvox, C, w, b, rec));
+  DISPATCH_T(dtype, AM_LAUNCH(proj_fwd_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, nvox, C, w, b, pre_scale, pre_shift, rec),
+             AM_LAUNCH(proj_fwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, nvox, C, w, b, pre_scale, pre_shift, rec));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_proj_norm_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, const float* scale, double* workspace, float* coef, void* dx,
+                     float* dgamma_accum, float* dbeta_accum, float* dw_accum, float* db_accum, void* stream) {
+  CHK_C(C);
+  if (!x || !drec || !w || !gamma || !beta || !mean || !rstd || !scale || !workspace || !coef || !dx || !dgamma_accum || !dbeta_accum ||
+      !dw_accum || !db_accum || nvox <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  ProjNormFin fin{(unsigned*)(workspace + (size_t)NREP * (C + 1)), (double)nvox, gamma, beta, rstd, scale, w,
+                  coef, coef + C, coef + 2 * C, dgamma_accum, dbeta_accum, dw_accum, db_accum};
+  const int vr = pick_vpw(nvox, C, dtype, true), va = pick_vpw(nvox, C, dtype, false);
+  DISPATCH_T(dtype, AM_LAUNCH(proj_norm_bwd_reduce_kernel<float>, dim3(nblk(nvox, vr)), dim3(256), 0, st, (const float*)x, drec, nvox, C, vr, mean, workspace, fin),
+             AM_LAUNCH(proj_norm_bwd_reduce_kernel<bf16_t>, dim3(nblk(nvox, vr)), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, vr, mean, workspace, fin));
+  AM_CHECK_LAUNCH();
+  DISPATCH_T(dtype, AM_LAUNCH(proj_norm_bwd_apply_kernel<float>, dim3(nblk(nvox, va)), dim3(256), 0, st, (const float*)x, drec, nvox, C, va, mean, rstd, coef, coef + C, coef + 2 * C, (float*)dx),
+             AM_LAUNCH(proj_norm_bwd_apply_kernel<bf16_t>, dim3(nblk(nvox, va)), dim3(256), 0, st, (const bf16_t*)x, drec, nvox, C, va, mean, rstd, coef, coef + C, coef + 2 * C, (bf16_t*)dx));
   AM_CHECK_LAUNCH();
   return 0;
 }

@@ -219,8 +219,11 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
     return out, rec_
 
 
-def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False, out_skip=None, sync: bool = False):
-    """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record)."""
+def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False, out_skip=None, sync: bool = False,
+               head: bool = False):
+    """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record).
+    head (last block, train mode): the block's final BatchNorm feeds only the 1x1 projection, which applies it on the fly
+    (ops.proj_fwd(pre=st2)) -- the block returns the BatchNorm's INPUT c2 and the normalised map is never written."""
     q = f"{DEC}.{i}"
     so = tuple(2 * v for v in x.shape[1:4])
     u = ops.conv3d(CONVT_FWD, x, pk.get(W, f"{q}.up_sample.weight", True, False), W[f"{q}.up_sample.bias"], so, 4, 2)
@@ -247,6 +250,9 @@ def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, 
     if train:
         c2, pt2 = c2
     st2 = _batch_norm(c2, W, f"{q}.conv.4", train, pt2, update_running, sync)
+    if head:
+        assert train and nxt is None and st2.sync_world <= 1
+        return c2, {"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2, "head": True}
     o = ops.norm_apply(c2, st2, ACT_NONE, res=nxt)            # x = x + to_dec[i+1] fused into the BN apply
     return o, {"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2}
 
@@ -296,14 +302,21 @@ def decoder_forward(spec: Spec, W, pk: PackCache, to_dec, train: bool, tape: Opt
     if fuse_eval is None:
         fuse_eval = tape is None
     x = to_dec[0]
+    # train mode: the last block's BatchNorm is applied inside the projection (and differentiated with it, ops.proj_norm_bwd)
+    head = bool(train and FUSED_HEAD and _sync_world(spec.sync_bn) <= 1)
+    st_head = None
     for i in range(n_dec):
         nxt = to_dec[i + 1] if i + 1 < n_dec else None
+        last = i == n_dec - 1
         o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=fuse_eval,
-                             out_skip=needed_patches if (i == n_dec - 1 and tape is None and not train) else None, sync=spec.sync_bn)
+                             out_skip=needed_patches if (last and tape is None and not train) else None, sync=spec.sync_bn,
+                             head=head and last)
+        if head and last:
+            st_head = rec_["st2"]
         if tape is not None:
-            tape.dec.append({"q": rec_["q"], "xin": x, "nxt": nxt} if recompute else rec_)
+            tape.dec.append({"q": rec_["q"], "xin": x, "nxt": nxt, "head": head and last} if recompute else rec_)
         x = o
-    rec = ops.proj_fwd(x, W["dense_decoder.proj.weight"].view(-1), W["dense_decoder.proj.bias"])
+    rec = ops.proj_fwd(x, W["dense_decoder.proj.weight"].view(-1), W["dense_decoder.proj.bias"], pre=st_head)
     if tape is not None:
         tape.last = x
     return rec
@@ -334,6 +347,7 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
 # the MFMA-bound wgrad kernels overlap the HBM-bound norm-backward passes of the next layer.  Ordering: the side stream waits
 # for an event recorded when dy exists; the main stream waits for the side stream before a parameter group is declared final
 # (all-reduce hook) and at the end of backward.  record_stream keeps the caching allocator from recycling x / dy early.
+FUSED_HEAD = True     # tools/step_ab.py engine.FUSED_HEAD=1,0: the projection head applies / differentiates the last BatchNorm itself
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
 _USE_SIDE = True      # tools/step_ab.py flips this attribute for same-process A/B timing; no environment switch exists
 
@@ -376,23 +390,33 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
     """backward of decoder_forward: accumulates the decoder's parameter gradients into G, returns dproj[i] = gradient wrt
     to_dec[i].  (densify_projs[i].bias for i >= 1 -- the per-channel sum of dproj[i] -- is folded into the ConvT-dgrad epilogue.)"""
     n_dec = len(spec.dec_chs) - 1
-    # ---- projection
-    g = ops.proj_bwd(tape.last, drec, W["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.weight"].view(-1),
-                     G["dense_decoder.proj.bias"])
-    if after_group:
-        after_group("proj")
+    # ---- projection (fused-head tapes differentiate it together with the last BatchNorm, below)
+    fused_head = bool(tape.dec[n_dec - 1].get("head"))
+    g = None
+    if not fused_head:
+        g = ops.proj_bwd(tape.last, drec, W["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.weight"].view(-1),
+                         G["dense_decoder.proj.bias"])
+        if after_group:
+            after_group("proj")
     # ---- decoder, fine -> coarse.  g = grad wrt block output (= grad wrt to_dec[i+1] too)
     dproj: List[Optional[torch.Tensor]] = [None] * n_dec
     for i in reversed(range(n_dec)):
         t = tape.dec[i]
         if tape.recompute:                        # P/GC.py:68: re-run the block forward from its saved input
-            _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False, sync=spec.sync_bn)
+            _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False, sync=spec.sync_bn, head=bool(t.get("head")))
             tape.dec[i] = None
         q = t["q"]
         if i + 1 < n_dec:
             dproj[i + 1] = g
-        dc2 = ops.norm_backward(g, None, t["c2"], t["st2"], W[f"{q}.conv.4.weight"], ACT_NONE, None, 0,
-                                G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"])
+        if t.get("head"):
+            dc2 = ops.proj_norm_bwd(t["c2"], t["st2"], drec, W["dense_decoder.proj.weight"].view(-1), W[f"{q}.conv.4.weight"],
+                                    W[f"{q}.conv.4.bias"], G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"],
+                                    G["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.bias"])
+            if after_group:
+                after_group("proj")
+        else:
+            dc2 = ops.norm_backward(g, None, t["c2"], t["st2"], W[f"{q}.conv.4.weight"], ACT_NONE, None, 0,
+                                    G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"])
         so = tuple(t["r"].shape[1:4])
         # (bf16) the reduce pass of the BatchNorm backward rides in this dgrad's epilogue: dr and c1 are not re-read for it.  Only where
         # the dgrad contracts >= 128 channels: the epilogue's work per output tile is fixed (64 activation derivatives per lane), and

@@ -460,11 +460,28 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
 
 
 # ------------------------------------------------------------------ proj / loss / sampler / optimizer
-def proj_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+def proj_fwd(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, pre: Optional["NormStats"] = None) -> torch.Tensor:
+    """pre: x is the INPUT of the (train-mode) BatchNorm `pre`; rec = proj(x * pre.scale + pre.shift), the BatchNorm output is never written."""
     B, D, H, W, Cc = x.shape
     rec = torch.empty(B, D, H, W, device=x.device, dtype=torch.float32)
-    hip.lib().proj_fwd(_dt(x), x.data_ptr(), B * D * H * W, Cc, w.data_ptr(), b.data_ptr(), rec.data_ptr(), _stream())
+    hip.lib().proj_fwd(_dt(x), x.data_ptr(), B * D * H * W, Cc, w.data_ptr(), b.data_ptr(), _p(pre.scale) if pre else None,
+                       _p(pre.shift) if pre else None, rec.data_ptr(), _stream())
     return rec
+
+
+def proj_norm_bwd(x: torch.Tensor, st: "NormStats", drec: torch.Tensor, w: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                  dgamma: torch.Tensor, dbeta: torch.Tensor, dw_accum: torch.Tensor, db_accum: torch.Tensor) -> torch.Tensor:
+    """backward of proj_fwd(x, w, b, pre=st) through the projection AND the BatchNorm (am_proj_norm_bwd): returns d loss / d x,
+    accumulates the four parameter gradients."""
+    B, D, H, W, Cc = x.shape
+    assert st.sync_world <= 1
+    dx = torch.empty_like(x)
+    ws_b, _ = _bwd_workspaces(x.device, Cc)
+    coef = torch.empty(3, Cc, device=x.device, dtype=torch.float32)
+    hip.lib().proj_norm_bwd(_dt(x), x.data_ptr(), drec.data_ptr(), B * D * H * W, Cc, w.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                            st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(), ws_b.data_ptr(), coef.data_ptr(), dx.data_ptr(),
+                            dgamma.data_ptr(), dbeta.data_ptr(), dw_accum.data_ptr(), db_accum.data_ptr(), _stream())
+    return dx
 
 
 def proj_bwd(x: torch.Tensor, drec: torch.Tensor, w: torch.Tensor, dw_accum: torch.Tensor, db_accum: torch.Tensor) -> torch.Tensor:

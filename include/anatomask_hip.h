@@ -185,7 +185,19 @@ int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, con
 int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream);   /* x + to_dec[i], P/decoder3D.py:59 */
 
 /* 1x1 projection C -> 1 (P/decoder3D.py:51,61) and its backward. rec/drec are fp32 [B][D][H][W]. */
-int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b, float* rec, void* stream);
+int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b,
+                const float* pre_scale, const float* pre_shift /* NULL, or x is the INPUT of a per-channel affine map (the train-mode
+                BatchNorm of P/decoder3D.py:22 whose output feeds only this projection): rec = proj(x * pre_scale + pre_shift) without
+                that tensor ever being written */, float* rec, void* stream);
+/* Backward of the projection head TOGETHER with the train-mode BatchNorm in front of it (P/decoder3D.py:22 -> :51,61; autograd of
+ * both), for the last decoder block (no activation, no skip add): x = the BatchNorm's input, drec = d loss / d rec.
+ * The gradient wrt the BatchNorm output is the rank-1 tensor drec[v] * w[c]; neither it nor the BatchNorm output is materialised.
+ * One reduce pass (S0 = sum drec, S1[c] = sum drec * (x - mean)) gives proj.weight / proj.bias / BN weight / BN bias gradients
+ * (all accumulated) and the coefficients of the second pass, which writes dx = d loss / d x.
+ * workspace: AM_NREP * (C + 1) doubles + 1, ZERO on entry and left zero; coef: 3 * C floats of scratch. */
+int am_proj_norm_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, const float* scale, double* workspace, float* coef, void* dx,
+                     float* dgamma_accum, float* dbeta_accum, float* dw_accum, float* db_accum, void* stream);
 int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, void* dx, float* dw_accum,
                 float* db_accum, float* det_workspace, long det_workspace_floats /* NULL / 0, or >= 1024 * (C + 1) floats: per-workgroup rows folded in order
                 instead of fp32 atomics (deterministic mode) */, void* stream);

@@ -19,19 +19,17 @@ from oracle import anatomask_oracle as O
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-# Asserted bounds, each <= 3 x what was measured on MI355X (the measured values are printed by the tests):
-BF16_COS, BF16_REL = 0.9, 0.5          # per gradient tensor >= 64 elements, bf16 storage vs the fp32 oracle   (first run: to be tightened)
-F32_REL = 2e-2                          # per gradient tensor, fp32 storage
-F32_LOSS, F32_GNORM, F32_L2 = 2e-4, 2e-3, 2e-3
-LARGE_LOSS, LARGE_GNORM = 5e-3, 0.1
-
-
-def _build(cfg, W, dtype=torch.bfloat16, recompute=False):
-    from anatomask_amd import modules as M
-    m = M.build_spark(cfg.dims, cfg.depth, cfg.width, cfg.input_size, cfg.mask_ratio, compute_dtype=dtype, recompute=recompute)
-    if W is not None:
-        m.load_state_dict({k: v.clone() for k, v in W.items()})
-    return m.to(DEV)
+# Asserted bounds, each <= 3 x what was measured on MI355X (the tests print the measured values; round 3: B / L / H):
+F32_REL = 1.8e-2                        # per gradient tensor, fp32 storage: measured 6.0e-3 (= the reference's own fp32-vs-fp64 distance)
+F32_LOSS, F32_GNORM, F32_L2 = 2e-6, 2e-4, 1e-6     # measured < 1e-7, 6.7e-5, 7.3e-8
+BF16_LOSS, BF16_GNORM, BF16_L2 = 1e-4, 2e-2, 1.5e-4   # measured 3e-6 / 3e-5 / 1e-5, 2.4e-3 / 7.6e-3 / 5.8e-3, 4.9e-5
+# bf16 storage is a different function from fp32 (gate flips accumulate with depth): per gradient tensor the HIP evaluation must be no
+# further from fp32 than BF16_VS_EMU_FACTOR x the ideal bf16 emulation is (+ 0.05), and no further from the emulation than
+# BF16_PAIR_FACTOR x the emulation is from fp32 (+ 0.1) -- any two bf16 evaluations of this network differ by as much as either
+# differs from fp32 (measured medians, HIP-fp32 / emulation-fp32 / HIP-emulation: B 0.29 / 0.28 / 0.32, L 0.47 / 0.44 / 0.49, H 0.60 / 0.57 / 0.65)
+BF16_VS_EMU_FACTOR = 1.6
+F32_L2_LARGE, BF16_L2_LARGE = 1e-5, 1e-3       # eval-forward per-patch loss of the STUNet-L / H shapes (first run: to be tightened)
+BF16_PAIR_FACTOR = 1.6
 
 
 _ANALYTIC_ZERO = re.compile(r"conv_blocks_context\.\d+\.\d+\.conv[12]\.bias$")     # a conv bias under an InstanceNorm: d loss / d bias == 0
@@ -47,7 +45,7 @@ def _per_tensor_errors(model, ref_grads, what):
         g = model._G[k].detach().double().cpu().reshape(-1)
         w = w.double().reshape(-1)
         if _ANALYTIC_ZERO.search(k):
-            assert float(g.norm()) <= 2e-3 * gn and float(w.norm()) <= 1e-4 * gn, (k, float(g.norm()), float(w.norm()), gn)
+            assert float(g.norm()) <= 2e-3 * gn and float(w.norm()) <= 2e-3 * gn, (k, float(g.norm()), float(w.norm()), gn)
             continue
         nw = float(w.norm())
         rows.append((k, w.numel(), float((g - w).norm()) / nw, float((g * w).sum() / (g.norm() * nw + 1e-300))))
@@ -56,6 +54,39 @@ def _per_tensor_errors(model, ref_grads, what):
     print(f"{what}: {len(rows)} gradient tensors, rel-L2 median {np.median([r[2] for r in rows]):.3e} max {worst[0][2]:.3e}; "
           f"min cos {min(r[3] for r in rows):.6f}; worst: " + ", ".join(f"{r[0]}[{r[1]}] {r[2]:.2e}/{r[3]:.5f}" for r in worst))
     return rows
+
+
+def _emulated_bf16_grads(cfg, W0, x, mask):
+    """The oracle's IDEAL bf16-storage evaluation of the same student pass (fp32 arithmetic; every stored C > 1 activation, its
+    gradient and the MFMA weight copies rounded to bf16 at the points where the HIP path stores them: oracle.storage)."""
+    with O.storage("bf16"):
+        _, _, g, _ = O.student_loss_and_grads(cfg, W0, x, mask, train=True)
+    return {k: v for k, v in g.items() if v is not None}
+
+
+def _check_bf16_rows(rows_vs_fp32, emu_grads, model, fp32_grads, what):
+    """bf16 storage is a different FUNCTION from the fp32 reference (activation gates of elements near zero flip, and the flips
+    accumulate with depth: the ideal emulation itself sits at rel-L2 0.28 / 0.47 / 0.60 from fp32 for STUNet-B / L / H).  What is
+    asserted: (1) the HIP gradients are as close to fp32 as the ideal emulation's are, per tensor; (2) the HIP gradients agree with
+    the emulation's -- the same function evaluated in another summation order -- far more tightly than either does with fp32."""
+    emu_vs_fp32 = {}
+    for k, w in fp32_grads.items():
+        if _ANALYTIC_ZERO.search(k):
+            continue
+        a, w = emu_grads[k].double().reshape(-1), w.double().reshape(-1)
+        emu_vs_fp32[k] = (float((a - w).norm() / w.norm()), float((a * w).sum() / (a.norm() * w.norm() + 1e-300)))
+    print(f"{what}: ideal bf16 emulation vs fp32: rel-L2 median {np.median([v[0] for v in emu_vs_fp32.values()]):.3e} "
+          f"max {max(v[0] for v in emu_vs_fp32.values()):.3e}; min cos {min(v[1] for v in emu_vs_fp32.values()):.5f}")
+    for k, n_el, rel, cos in rows_vs_fp32:
+        if n_el >= 64:
+            e_rel, e_cos = emu_vs_fp32[k]
+            assert rel <= BF16_VS_EMU_FACTOR * e_rel + 0.05 and 1 - cos <= BF16_VS_EMU_FACTOR ** 2 * (1 - e_cos) + 0.01, (k, n_el, rel, cos, e_rel, e_cos)
+    rows = _per_tensor_errors(model, emu_grads, f"{what} bf16 storage vs the ideal bf16 emulation")
+    for k, n_el, rel, cos in rows:
+        if n_el >= 64:
+            assert rel <= BF16_PAIR_FACTOR * emu_vs_fp32[k][0] + 0.1, (k, n_el, rel, cos, emu_vs_fp32[k])
+    med = lambda r: float(np.median([v[2] for v in r]))
+    assert med(rows_vs_fp32) <= 1.15 * float(np.median([v[0] for v in emu_vs_fp32.values()])) + 0.01     # the medians: measured 1.05 / 1.06 / 1.04 x
 
 
 @functools.lru_cache(maxsize=None)
@@ -110,16 +141,14 @@ def test_config2_stunet_b_128_bf16_step_vs_oracle():
     rec_h, rec_o = out["recon_loss"].cpu().numpy(), o["recon_loss"].numpy()
     print("STUNet-B 128^3 bf16 vs oracle fp32: loss %.6f / %.6f  grad-norm %.5f / %.5f  teacher-l2 rel err %.2e"
           % (out["loss"].item(), o["loss"], out["grad_norm"].item(), o["grad_norm"], np.abs(rec_h - rec_o).max() / rec_o.max()))
-    assert np.abs(rec_h - rec_o).max() < 2e-2 * rec_o.max()                           # teacher pass, bf16 storage
-    assert abs(out["loss"].item() - o["loss"]) < 2e-3 * o["loss"]
+    assert np.abs(rec_h - rec_o).max() < BF16_L2 * rec_o.max()                        # teacher pass, bf16 storage
+    assert abs(out["loss"].item() - o["loss"]) < BF16_LOSS * o["loss"]
     rl_h, rl_o = out["rec_loss"].cpu().numpy(), o["rec_loss"].numpy()
     assert np.abs(rl_h - rl_o).max() < 2e-2 * rl_o.max()                              # per-patch student loss
-    assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < 0.1
+    assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < BF16_GNORM
     # EVERY gradient tensor of the step against the oracle's autograd gradient of the same step (102 live tensors)
-    rows = _per_tensor_errors(m, o["grads"], "STUNet-B 128^3 bf16 storage")
-    for k, n_el, rel, cos in rows:
-        if n_el >= 64:
-            assert cos >= BF16_COS and rel <= BF16_REL, (k, n_el, rel, cos)
+    rows = _per_tensor_errors(m, o["grads"], "STUNet-B 128^3 bf16 storage vs fp32 oracle")
+    _check_bf16_rows(rows, _emulated_bf16_grads(cfg, W0, x, o["mask"]), m, o["grads"], "STUNet-B 128^3")
     # EMA identity at full size: teacher = decay * W0 + (1 - decay) * student, elementwise (fp32 flat buffers)
     n = m._live_end
     w0 = torch.cat([W0[k].flatten() for k in m._pnames if k not in m._dead]).to(DEV)
@@ -157,10 +186,12 @@ def test_config2_stunet_b_128_fp32_storage_step_vs_oracle():
 
 
 def _student_step_vs_oracle(size, patch, mask_ratio, recompute, seed):
-    """Plain-SparK step (teacher-forced mask, no teacher) of a large-model SHAPE at a reduced patch against the oracle's autograd:
-    loss, gradient norm and every gradient tensor in bf16 storage, plus the eval-mode (teacher) forward's per-patch loss --
+    """Plain-SparK step (teacher-forced mask, no teacher) of a large-model SHAPE at a reduced patch against the oracle's autograd --
     the kernel paths only STUNet-L/H reach (depth 2/3 identity-shortcut blocks, 64..1536 channels, one-voxel patches at level 4,
-    20- / 24- / 12-wide grids, activation recomputation) fail here if a tap is wrong."""
+    20- / 24- / 12-wide grids, activation recomputation):
+      fp32 storage: loss, gradient norm and EVERY gradient tensor at reduction-order tolerance (a wrong tap fails here);
+      bf16 storage: loss / gradient norm, every gradient tensor against the ideal bf16 emulation's distances (_check_bf16_rows);
+      eval-mode (teacher) forward: per-patch loss (folded BatchNorm epilogues, skipped visible patches)."""
     from anatomask_amd import engine, modules as M, ops
     from anatomask_amd.trainer import AnatoMaskTrainer
     kw = M.STUNET_CONFIGS[size]
@@ -175,31 +206,37 @@ def _student_step_vs_oracle(size, patch, mask_ratio, recompute, seed):
     with torch.no_grad():
         inp1, rec1 = O.spark_forward(cfg, W0, x, mask, train=False)
         recon_o = O.teacher_patch_loss(inp1, rec1, mask)
-    m = _build(cfg, W0, recompute=recompute)
-    tr = AnatoMaskTrainer(m, lr=1e-4, total_epochs=1000, distributed=False, self_distill=False)
-    out = tr.step(x.to(DEV), epoch=0, mask1=mask)
-    loss_h, gn_h = out["loss"].item(), out["grad_norm"].item()
-    print(f"STUNet-{size} {patch}^3 bf16 vs oracle fp32: loss {loss_h:.6f} / {float(loss_o):.6f}  grad-norm {gn_h:.5f} / {gn_o:.5f}")
-    assert abs(loss_h - float(loss_o)) < LARGE_LOSS * float(loss_o)
-    assert abs(gn_h / gn_o - 1) < LARGE_GNORM
-    rl_h = out["rec_loss"].cpu().numpy()
-    assert np.abs(rl_h - rl_o.numpy()).max() < 2e-2 * rl_o.numpy().max()
-    rows = _per_tensor_errors(m, live, f"STUNet-{size} {patch}^3 bf16 storage")
-    for k, n_el, rel, cos in rows:
-        if n_el >= 64:
-            assert cos >= BF16_COS and rel <= BF16_REL, (k, n_el, rel, cos)
-    # eval-mode forward of the same weights (the teacher's path: folded BatchNorm epilogues, skipped visible patches)
-    B = 1
-    mi = ops.MaskInfo(mask.reshape(B, *m.spec.fmap).to(device=DEV, dtype=torch.uint8).contiguous())
-    W1 = _build(cfg, W0)                                   # (fresh copy: the step above updated `m`)
-    xs = x[:, 0].to(DEV).contiguous()
-    need = ops.MaskInfo((1 - mi.t).contiguous())
-    rec = engine.forward(W1.spec, W1._W, W1._pack, xs, mi, train=False, needed_patches=need)
-    recon_h, _, _, _ = ops.patch_loss_fwd(xs, rec, mi, normalized=False, want_loss=False)
-    err = np.abs(recon_h.cpu().numpy() - recon_o.numpy()).max() / recon_o.numpy().max()
-    print(f"STUNet-{size} {patch}^3 eval forward: teacher-l2 rel err {err:.2e}")
-    assert err < 2e-2
-    return tr, cfg, out
+    emu = _emulated_bf16_grads(cfg, W0, x, mask)
+    for dtype, name in ((torch.float32, "fp32"), (torch.bfloat16, "bf16")):
+        m = _build(cfg, W0, dtype=dtype, recompute=recompute)
+        tr = AnatoMaskTrainer(m, lr=1e-4, total_epochs=1000, distributed=False, self_distill=False)
+        out = tr.step(x.to(DEV), epoch=0, mask1=mask)
+        loss_h, gn_h = out["loss"].item(), out["grad_norm"].item()
+        print(f"STUNet-{size} {patch}^3 {name} vs oracle fp32: loss {loss_h:.7f} / {float(loss_o):.7f}  grad-norm {gn_h:.6f} / {gn_o:.6f}")
+        rl_h = out["rec_loss"].cpu().numpy()
+        rows = _per_tensor_errors(m, live, f"STUNet-{size} {patch}^3 {name} storage vs fp32 oracle")
+        if dtype == torch.float32:
+            assert abs(loss_h - float(loss_o)) < F32_LOSS * float(loss_o) and abs(gn_h / gn_o - 1) < F32_GNORM
+            assert np.abs(rl_h - rl_o.numpy()).max() < F32_L2 * rl_o.numpy().max()
+            for k, n_el, rel, cos in rows:
+                assert rel <= F32_REL and cos >= 1 - F32_REL, (k, n_el, rel, cos)
+        else:
+            assert abs(loss_h - float(loss_o)) < BF16_LOSS * float(loss_o) and abs(gn_h / gn_o - 1) < BF16_GNORM
+            assert np.abs(rl_h - rl_o.numpy()).max() < 2e-2 * rl_o.numpy().max()
+            _check_bf16_rows(rows, emu, m, live, f"STUNet-{size} {patch}^3")
+        # eval-mode forward of the same weights (the teacher's path)
+        W1 = _build(cfg, W0, dtype=dtype)                  # (fresh copy: the step above updated `m`)
+        W1._ensure_flat()
+        mi = ops.MaskInfo(mask.reshape(1, *W1.spec.fmap).to(device=DEV, dtype=torch.uint8).contiguous())
+        xs = x[:, 0].to(DEV).contiguous()
+        need = ops.MaskInfo((1 - mi.t).contiguous())
+        rec = engine.forward(W1.spec, W1._W, W1._pack, xs, mi, train=False, needed_patches=need)
+        recon_h, _, _, _ = ops.patch_loss_fwd(xs, rec, mi, normalized=False, want_loss=False)
+        err = np.abs(recon_h.cpu().numpy() - recon_o.numpy()).max() / recon_o.numpy().max()
+        print(f"STUNet-{size} {patch}^3 {name} eval forward: teacher-l2 rel err {err:.2e}")
+        assert err < (F32_L2_LARGE if dtype == torch.float32 else BF16_L2_LARGE)
+        del m, tr, W1, rec
+        torch.cuda.empty_cache()
 
 
 def test_config4_shape_stunet_l_80_mask07_step_vs_oracle():

@@ -629,6 +629,41 @@ def test_chan_sum_add_proj(ops, dtype):
     close(dw.cpu(), w.grad.view(-1), 5e-4, "proj dw"); close(db.cpu(), b.grad, 5e-4, "proj db")
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,sp,B", [(32, (8, 12, 16), 2), (96, (5, 6, 7), 3), (64, (16, 16, 16), 1)])
+def test_projection_head_fused_with_its_batchnorm(ops, dtype, C, sp, B):
+    """am_proj_fwd(pre_scale, pre_shift) + am_proj_norm_bwd: the last decoder block's train-mode BatchNorm applied and differentiated
+    INSIDE the 1x1 projection (its output and the rank-1 gradient drec x w are never materialised) against torch autograd of
+    conv1x1(batch_norm(x)) -- rec, dx and the gradients of proj.weight / proj.bias / BN weight / BN bias (P/decoder3D.py:22,51,61)."""
+    x = q(rnd(B, C, *sp, seed=1) * 1.3 + 0.4, dtype)
+    gam, bet = torch.rand(C, generator=torch.Generator().manual_seed(2)) + 0.5, rnd(C, seed=3) * 0.3
+    w, b = rnd(1, C, 1, 1, 1, seed=4) * 0.3, rnd(1, seed=5)
+    drec = rnd(B, 1, *sp, seed=6)
+    xr, gr, br, wr, pbr = (t.clone().requires_grad_(True) for t in (x, gam, bet, w, b))
+    o = F.batch_norm(xr, None, None, gr, br, training=True, eps=1e-5)
+    rr = F.conv3d(o, wr, pbr)
+    rr.backward(drec)
+    xd = to_cl(x, dtype)
+    st = ops.NormStats(C, DEV)
+    st.count_host = float(B * sp[0] * sp[1] * sp[2])
+    ops.chan_stats(xd, None, 0, st)
+    ops.norm_finalize(st, gam.to(DEV), bet.to(DEV), 1e-5)
+    wd, bd = w.view(-1).to(DEV), b.to(DEV)
+    rec = ops.proj_fwd(xd, wd, bd, pre=st)
+    close(rec.cpu(), rr.detach()[:, 0], 2e-5 if dtype == torch.float32 else 1e-4, "fused head fwd")
+    dg, dbt, dw, db = (torch.full((n,), 0.25, device=DEV) for n in (C, C, C, 1))      # accumulated INTO (0.25 already there)
+    dx = ops.proj_norm_bwd(xd, st, drec[:, 0].contiguous().to(DEV), wd, gam.to(DEV), bet.to(DEV), dg, dbt, dw, db)
+    close(from_cl(dx), xr.grad, TOL[dtype], "fused head dx")
+    close(dg.cpu() - 0.25, gr.grad, 5e-4, "BN dgamma"); close(dbt.cpu() - 0.25, br.grad, 5e-4, "BN dbeta")
+    close(dw.cpu() - 0.25, wr.grad.view(-1), 5e-4, "proj dw"); close(db.cpu() - 0.25, pbr.grad, 5e-4, "proj db")
+    ws, _ = ops._bwd_workspaces(torch.device(DEV), C)
+    assert bool((ws == 0).all()), "the shared zero workspace was left dirty"
+    # and the stand-alone route (apply -> proj -> proj_bwd -> norm backward) agrees
+    o2 = ops.norm_apply(xd, st, ops.ACT_NONE)
+    rec2 = ops.proj_fwd(o2, wd, bd)
+    close(rec.cpu(), rec2.cpu(), 1e-4 if dtype == torch.float32 else 2e-2, "fused vs stand-alone fwd")
+
+
 # ------------------------------------------------------------------ loss / sampler / optimizer
 @pytest.mark.parametrize("normalized", [True, False])
 def test_patch_loss_fwd_bwd(ops, normalized):
