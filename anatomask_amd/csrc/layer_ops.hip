@@ -765,7 +765,8 @@ inline bool list_ok(const uint8_t* mask, const int* plist, int n_active) { retur
 }  // namespace
 
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == AM_DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
-#define CHK_C(C) do { if ((C) % 8 || (C) > 2048 || (C) <= 0) return -1; } while (0)
+// (a voxel row must fit the 256 threads of a workgroup as 16-byte chunks: C <= 2048 in bf16, C <= 1024 in fp32 -- refuse, never mis-compute)
+#define CHK_C(C) do { if ((C) % 8 || (C) > 2048 || (C) <= 0 || (dtype != AM_DT_BF16 && (C) > 1024)) return -1; } while (0)
 
 extern "C" {
 

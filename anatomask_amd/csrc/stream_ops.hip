@@ -37,21 +37,22 @@ struct Geo {                 // a channels-last tensor [B][D][H][W][C] and its (
   __device__ __forceinline__ long nvox() const { return (long)B * D * H * W; }
 };
 
-// thread -> (voxel lane, chunk lane); CPV chunks per voxel; VPP voxels per pass
+// thread -> (voxel lane, chunk lane); CPV chunks per voxel; VPP voxels per pass.  nthr = threads of the workgroup: 256, or 512
+// for rows of more than 256 chunks (fp32 storage with C > 1024: STUNet-H's 1536 channels) -- cpv <= nthr is what the kernels need.
 template <typename T> struct Walk {
   int cpv, vpp, cl, vl; bool live;
-  __device__ __forceinline__ Walk(int C) {
-    cpv = C / TT<T>::EPC; vpp = 256 / cpv; cl = threadIdx.x % cpv; vl = threadIdx.x / cpv; live = vl < vpp;
+  __device__ __forceinline__ Walk(int C, int nthr = 256) {
+    cpv = C / TT<T>::EPC; vpp = nthr / cpv; cl = threadIdx.x % cpv; vl = threadIdx.x / cpv; live = vl < vpp;
   }
 };
 
 // ------------------------------------------------------------------ statistics (forward)
 // sums[c][0] += sum x, sums[c][1] += sum x^2 over active voxels (double atomics, one per WG per channel)
-template <typename T>
-__global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ x, Geo g, double* __restrict__ sums) {
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void chan_stats_kernel(const T* __restrict__ x, Geo g, double* __restrict__ sums) {
   constexpr int EPC = TT<T>::EPC;
-  __shared__ float red[256 * 2 * 8];
-  Walk<T> wk(g.C);
+  __shared__ float red[NT * 2 * 8];
+  Walk<T> wk(g.C, NT);
   float s1[EPC], s2[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) s1[i] = s2[i] = 0.f;
@@ -147,14 +148,14 @@ __device__ __forceinline__ float act_grad_pre(float pre, int act) {   // derivat
 // ------------------------------------------------------------------ apply (forward)
 // y = act(x*scale + shift [+ res | + stem 1x1 shortcut]) on active voxels;
 // fill != nullptr: inactive voxels get the mask token (densify, P/AnatoMask.py:160-163), output dense.
-template <typename T>
-__global__ __launch_bounds__(256) void norm_apply_kernel(const T* __restrict__ x, Geo g, const float* __restrict__ scale,
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void norm_apply_kernel(const T* __restrict__ x, Geo g, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, const T* __restrict__ res,
                                                          const float* __restrict__ stem_x, const float* __restrict__ stem_w,
                                                          const float* __restrict__ stem_b, const float* __restrict__ fill,
                                                          T* __restrict__ y) {
   constexpr int EPC = TT<T>::EPC;
-  Walk<T> wk(g.C);
+  Walk<T> wk(g.C, NT);
   if (!wk.live) return;
   float sc[EPC], sh[EPC];
 #pragma unroll
@@ -257,15 +258,15 @@ __device__ __forceinline__ void dxsum_tail(double* rep, int nrep, int C, float* 
 
 // ------------------------------------------------------------------ backward: reduce
 // dpre = dout * act'(out);  bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout (token grad)}
-template <typename T>
-__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void norm_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                               const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, int fill,
                                                               double* __restrict__ bsum, const float* __restrict__ psc,
                                                               const float* __restrict__ psh, BwdFin fin) {
   constexpr int EPC = TT<T>::EPC;
-  __shared__ float red[256 * 3 * 8];
-  Walk<T> wk(g.C);
+  __shared__ float red[NT * 3 * 8];
+  Walk<T> wk(g.C, NT);
   float s1[EPC], s2[EPC], s3[EPC], mu[EPC], rs[EPC], qs[EPC], qh[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) { s1[i] = s2[i] = s3[i] = 0.f; mu[i] = rs[i] = qs[i] = qh[i] = 0.f; }
@@ -350,8 +351,8 @@ __global__ void norm_bwd_finalize_kernel(const double* bsum, const double* count
 
 // ------------------------------------------------------------------ backward: apply
 // dx = k0*dpre - k1 - k2*xhat on active voxels; optionally store dpre (gradient of the residual branch)
-template <typename T>
-__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void norm_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                              const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ k0,
                                                              const float* __restrict__ k1, const float* __restrict__ k2, int act,
@@ -359,8 +360,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(const T* __restrict
                                                              int dxrep, const float* __restrict__ psc, const float* __restrict__ psh,
                                                              float* __restrict__ dx_accum, unsigned* dx_ticket) {
   constexpr int EPC = TT<T>::EPC;
-  __shared__ float red[256 * 8];
-  Walk<T> wk(g.C);
+  __shared__ float red[NT * 8];
+  Walk<T> wk(g.C, NT);
   float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC], sx[EPC], qs[EPC], qh[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) {
@@ -765,11 +766,11 @@ __global__ __launch_bounds__(256) void mask_compact_kernel(const uint8_t* __rest
 }
 
 // ------------------------------------------------------------------ generic per-channel sum (bias grads)
-template <typename T>
-__global__ __launch_bounds__(256) void chan_sum_kernel(const T* __restrict__ x, Geo g, float* __restrict__ out) {
+template <typename T, int NT = 256>
+__global__ __launch_bounds__(NT) void chan_sum_kernel(const T* __restrict__ x, Geo g, float* __restrict__ out) {
   constexpr int EPC = TT<T>::EPC;
-  __shared__ float red[256 * 8];
-  Walk<T> wk(g.C);
+  __shared__ float red[NT * 8];
+  Walk<T> wk(g.C, NT);
   float s1[EPC];
 #pragma unroll
   for (int i = 0; i < EPC; ++i) s1[i] = 0.f;
@@ -1664,9 +1665,11 @@ __global__ __launch_bounds__(256) void partials_finalize_kernel(const float* __r
 }
 
 // voxels per workgroup: whole passes (256/(C/EPC) voxels each), ~2048 workgroups per launch (<= 1024 for reductions)
+// threads per workgroup of the linear (Walk) kernels: a voxel row of more than 256 16-byte chunks (fp32, C > 1024) takes 512
+inline int walk_threads(int C, int dtype) { return C / (dtype == AM_DT_BF16 ? 8 : 4) > 256 ? 512 : 256; }
 inline int pick_vpw(long nvox, int C, int dtype, bool reduction) {
   const int epc = dtype == AM_DT_BF16 ? 8 : 4;
-  int vpp = 256 / (C / epc); if (vpp < 1) vpp = 1;
+  int vpp = walk_threads(C, dtype) / (C / epc); if (vpp < 1) vpp = 1;
   const long target = reduction ? 1024 : 2048;
   long v = (nvox + target - 1) / target;
   v = (v + vpp - 1) / vpp * vpp;
@@ -1721,6 +1724,9 @@ inline int rows_threads(const RowGeo& r) { return r.rpp * r.rowchunks; }
 
 }  // namespace
 
+// fp32 launch of a linear (Walk) kernel: 512-thread workgroups when a voxel row has more than 256 chunks (C > 1024)
+#define AM_LAUNCH_F32W(C_, KERN_, GRID_, ST_, ...) do { if ((C_) / 4 > 256) AM_LAUNCH((KERN_<float, 512>), GRID_, dim3(512), 0, ST_, __VA_ARGS__); \
+                                                        else AM_LAUNCH((KERN_<float, 256>), GRID_, dim3(256), 0, ST_, __VA_ARGS__); } while (0)
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == AM_DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
 #define CHK_C(C) do { if ((C) % 8 || (C) > 2048 || (C) <= 0) return -1; } while (0)
 
@@ -1742,7 +1748,7 @@ int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, c
   }
   if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
-  DISPATCH_T(dtype, AM_LAUNCH(chan_stats_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, sums),
+  DISPATCH_T(dtype, AM_LAUNCH_F32W(C, chan_stats_kernel, dim3(nb), st, (const float*)x, g, sums),
              AM_LAUNCH(chan_stats_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, sums));
   AM_CHECK_LAUNCH();
   return 0;
@@ -1807,7 +1813,7 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
   if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
-             AM_LAUNCH(norm_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,
+             AM_LAUNCH_F32W(C, norm_apply_kernel, dim3(nb), st, (const float*)x, g, scale, shift, act,
                                 (const float*)res, stem_x, stem_w, stem_b, fill, (float*)y),
              AM_LAUNCH(norm_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, scale, shift, act,
                                 (const bf16_t*)res, stem_x, stem_w, stem_b, fill, (bf16_t*)y));
@@ -1847,7 +1853,7 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
   if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
   DISPATCH_T(dtype,
-             AM_LAUNCH(norm_bwd_reduce_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
+             AM_LAUNCH_F32W(C, norm_bwd_reduce_kernel, dim3(nb), st, (const float*)dout, (const float*)out,
                                 (const float*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin),
              AM_LAUNCH(norm_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,
                                 (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin));
@@ -1898,7 +1904,7 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
                          (const bf16_t*)x, rg, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket));
   } else
   DISPATCH_T(dtype,
-             AM_LAUNCH(norm_bwd_apply_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,
+             AM_LAUNCH_F32W(C, norm_bwd_apply_kernel, dim3(nb), st, (const float*)dout, (const float*)out,
                                 (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket),
              AM_LAUNCH(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
                                 (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket));
@@ -1915,9 +1921,9 @@ int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, con
   hipStream_t st = (hipStream_t)stream;
   // small tensors (the densify projection of the coarsest level: its bias gradient): ONE workgroup, so the fp32 sum has a fixed order
   // (with several workgroups the per-workgroup sums arrive as fp32 atomics in any order)
-  if ((long)B * D * H * W * C <= (4L << 20)) { g.vpw = (int)((long)B * D * H * W); const int vpp = 256 / (C / (dtype == AM_DT_BF16 ? 8 : 4)) > 0 ? 256 / (C / (dtype == AM_DT_BF16 ? 8 : 4)) : 1; g.vpw = (g.vpw + vpp - 1) / vpp * vpp; }
+  if ((long)B * D * H * W * C <= (4L << 20)) { g.vpw = (int)((long)B * D * H * W); const int vpp = walk_threads(C, dtype) / (C / (dtype == AM_DT_BF16 ? 8 : 4)) > 0 ? walk_threads(C, dtype) / (C / (dtype == AM_DT_BF16 ? 8 : 4)) : 1; g.vpw = (g.vpw + vpp - 1) / vpp * vpp; }
   const int nb = nblk((long)B * D * H * W, g.vpw);
-  DISPATCH_T(dtype, AM_LAUNCH(chan_sum_kernel<float>, dim3(nb), dim3(256), 0, st, (const float*)x, g, out_accum),
+  DISPATCH_T(dtype, AM_LAUNCH_F32W(C, chan_sum_kernel, dim3(nb), st, (const float*)x, g, out_accum),
              AM_LAUNCH(chan_sum_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, out_accum));
   AM_CHECK_LAUNCH();
   return 0;

@@ -28,8 +28,17 @@ BF16_LOSS, BF16_GNORM, BF16_L2 = 1e-4, 2e-2, 1.5e-4   # measured 3e-6 / 3e-5 / 1
 # BF16_PAIR_FACTOR x the emulation is from fp32 (+ 0.1) -- any two bf16 evaluations of this network differ by as much as either
 # differs from fp32 (measured medians, HIP-fp32 / emulation-fp32 / HIP-emulation: B 0.29 / 0.28 / 0.32, L 0.47 / 0.44 / 0.49, H 0.60 / 0.57 / 0.65)
 BF16_VS_EMU_FACTOR = 1.6
-F32_L2_LARGE, BF16_L2_LARGE = 1e-5, 1e-3       # eval-forward per-patch loss of the STUNet-L / H shapes (first run: to be tightened)
+F32_L2_LARGE, BF16_L2_LARGE = 8e-6, 4e-3       # eval-forward per-patch loss of the STUNet-L / H shapes: measured 4.9e-7 / 2.7e-6, 1.3e-3 (L)
+F32_REL_LARGE = 5e-2                    # per gradient tensor, fp32 storage, depth 2 / 3: measured 1.2e-2 (L), 1.8e-2 (H) -- the fp32 floor grows with depth
 BF16_PAIR_FACTOR = 1.6
+
+
+def _build(cfg, W, dtype=torch.bfloat16, recompute=False):
+    from anatomask_amd import modules as M
+    m = M.build_spark(cfg.dims, cfg.depth, cfg.width, cfg.input_size, cfg.mask_ratio, compute_dtype=dtype, recompute=recompute)
+    if W is not None:
+        m.load_state_dict({k: v.clone() for k, v in W.items()})
+    return m.to(DEV)
 
 
 _ANALYTIC_ZERO = re.compile(r"conv_blocks_context\.\d+\.\d+\.conv[12]\.bias$")     # a conv bias under an InstanceNorm: d loss / d bias == 0
@@ -219,7 +228,7 @@ def _student_step_vs_oracle(size, patch, mask_ratio, recompute, seed):
             assert abs(loss_h - float(loss_o)) < F32_LOSS * float(loss_o) and abs(gn_h / gn_o - 1) < F32_GNORM
             assert np.abs(rl_h - rl_o.numpy()).max() < F32_L2 * rl_o.numpy().max()
             for k, n_el, rel, cos in rows:
-                assert rel <= F32_REL and cos >= 1 - F32_REL, (k, n_el, rel, cos)
+                assert rel <= F32_REL_LARGE and cos >= 1 - F32_REL_LARGE / 10, (k, n_el, rel, cos)
         else:
             assert abs(loss_h - float(loss_o)) < BF16_LOSS * float(loss_o) and abs(gn_h / gn_o - 1) < BF16_GNORM
             assert np.abs(rl_h - rl_o.numpy()).max() < 2e-2 * rl_o.numpy().max()

@@ -490,7 +490,7 @@ def test_stem_conv(ops, dtype, k, C):
 
 # ------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C", [16, 40, 96])
+@pytest.mark.parametrize("C", [16, 40, 96, 1280, 1536])      # fp32 rows of more than 256 16-byte chunks (C > 1024: STUNet-H) take 512-thread workgroups
 def test_sparse_instance_norm_fwd_bwd(ops, dtype, C):
     B, f = 2, (2, 2, 3)
     sp = tuple(v * 4 for v in f)
@@ -525,8 +525,9 @@ def test_sparse_instance_norm_fwd_bwd(ops, dtype, C):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_batchnorm_train_eval_relu6(ops, dtype):
-    B, C, sp = 2, 24, (6, 8, 10)
+@pytest.mark.parametrize("C", [24, 1536])
+def test_batchnorm_train_eval_relu6(ops, dtype, C):
+    B, sp = 2, (6, 8, 10)
     x = q(rnd(B, C, *sp, seed=1) * 2 + 1.5, dtype).requires_grad_(True)
     p = {"bn.weight": (1 + 0.2 * rnd(C, seed=2)).requires_grad_(True), "bn.bias": (0.5 * rnd(C, seed=3)).requires_grad_(True),
          "bn.running_mean": 0.1 * rnd(C, seed=6), "bn.running_var": 1 + 0.1 * rnd(C, seed=7).abs(),
@@ -546,12 +547,15 @@ def test_batchnorm_train_eval_relu6(ops, dtype):
     close(rm.cpu(), nb["bn.running_mean"], 1e-5, "running_mean"); close(rv.cpu(), nb["bn.running_var"], 1e-5, "running_var")
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dx = ops.norm_backward(to_cl(dout, dtype), to_cl(yr.detach(), dtype), xd, st, p["bn.weight"].detach().to(DEV), ops.ACT_RELU6, None, 0, dg, db)
-    close(from_cl(dx), x.grad, 2 * TOL[dtype], "BN dx")
+    # (bf16: a saved output in (5.98, 6) rounds to 6.0 and closes the ReLU6 gate the fp32 reference holds open -- with 1536 channels
+    # a few dozen of the 3 M elements do; they are left out of the element-wise comparison)
+    edge = ((yr.detach() - 6.0).abs() > 0.03).float() if dtype == torch.bfloat16 else None
+    close(from_cl(dx), x.grad, 2 * TOL[dtype], "BN dx", edge)
     close(dg.cpu(), p["bn.weight"].grad, 2 * TOL[dtype], "BN dgamma"); close(db.cpu(), p["bn.bias"].grad, 2 * TOL[dtype], "BN dbeta")
     # out=None: the ReLU6 gate is recomputed from x * scale + shift (what the engine does for norms without a residual)
     dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
     dx2 = ops.norm_backward(to_cl(dout, dtype), None, xd, st, p["bn.weight"].detach().to(DEV), ops.ACT_RELU6, None, 0, dg2, db2)
-    close(from_cl(dx2), x.grad, 2 * TOL[dtype], "BN dx (recomputed gate)")
+    close(from_cl(dx2), x.grad, 2 * TOL[dtype], "BN dx (recomputed gate)", edge)
     close(dg2.cpu(), p["bn.weight"].grad, 2 * TOL[dtype], "BN dgamma (recomputed gate)")
     close(db2.cpu(), p["bn.bias"].grad, 2 * TOL[dtype], "BN dbeta (recomputed gate)")
     # eval: running statistics
