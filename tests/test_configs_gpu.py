@@ -28,7 +28,7 @@ BF16_LOSS, BF16_GNORM, BF16_L2 = 1e-4, 2e-2, 1.5e-4   # measured 3e-6 / 3e-5 / 1
 # BF16_PAIR_FACTOR x the emulation is from fp32 (+ 0.1) -- any two bf16 evaluations of this network differ by as much as either
 # differs from fp32 (measured medians, HIP-fp32 / emulation-fp32 / HIP-emulation: B 0.29 / 0.28 / 0.32, L 0.47 / 0.44 / 0.49, H 0.60 / 0.57 / 0.65)
 BF16_VS_EMU_FACTOR = 1.6
-F32_L2_LARGE, BF16_L2_LARGE = 8e-6, 4e-3       # eval-forward per-patch loss of the STUNet-L / H shapes: measured 4.9e-7 / 2.7e-6, 1.3e-3 (L)
+F32_L2_LARGE, BF16_L2_LARGE = 8e-6, 2.4e-2     # eval-forward per-patch loss of the STUNet-L / H shapes: measured 4.9e-7 / 2.7e-6 (fp32), 1.3e-3 / 7.8e-3 (bf16)
 F32_REL_LARGE = 5e-2                    # per gradient tensor, fp32 storage, depth 2 / 3: measured 1.2e-2 (L), 1.8e-2 (H) -- the fp32 floor grows with depth
 BF16_PAIR_FACTOR = 1.6
 
