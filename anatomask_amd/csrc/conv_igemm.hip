@@ -66,6 +66,14 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
   const int co0 = blockIdx.y * NT;
   float* part = a.partials ? a.partials + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * a.Cout) * 2 : nullptr;
+#ifdef AM_ABLATE
+  // timing experiment (tools build): delay every second set of 256 workgroups of the FIRST dispatch round, so that the two
+  // workgroups that share a CU do not run their prologue / main loop / epilogue phases in lockstep (AM_CV_DBG bits 4096.., n x s_sleep 127)
+  if ((a.dbg >> 12) & 15) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (((lin >> 8) & 1) && lin < 512) for (int i = 0; i < ((a.dbg >> 12) & 15); ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
 
   // ---- skip bricks with no active output voxel (block-sparse outputs) ----
   if (a.out_mask.m && a.brick_in_patch) {                // (uniform) every voxel of the brick shares the patch of its first voxel
