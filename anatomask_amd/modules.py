@@ -510,18 +510,16 @@ class SparK(nn.Module):
         SL.COMPUTE_DTYPE = self.compute_dtype
         fea = list(self.sparse_encoder(inp_bchwd * act_ex))          # fine -> coarse
         fea.reverse()
-        cur = act
         to_dec = []
         for i, f in enumerate(fea):
             if f is not None and i < len(self.dense_decoder.dec):    # (levels past the decoder's blocks are never read, :170 + decoder3D.py:56-60)
                 n_ = self.densify_norms[i]
-                f = SL._nc(SL._SparseBNFn.apply(SL._cl(f), n_.weight, n_.bias, None, None, None, True, 0.0, n_.eps, False))   # pooled sparse IN
-                f = torch.where(cur.expand_as(f), f, self.mask_tokens[i].to(f.dtype).expand_as(f))
+                # pooled sparse InstanceNorm + mask-token fill in one HIP apply pass (and one backward pair), as the fused engine does
+                f = SL._nc(SL._DensifyFn.apply(SL._cl(f), n_.weight, n_.bias, self.mask_tokens[i], n_.eps))
                 pr = self.densify_projs[i]
                 if not isinstance(pr, nn.Identity):
                     f = SL.dense_conv(f, pr.weight, pr.bias, pr.kernel_size[0])
                 to_dec.append(f)
-            cur = cur.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
         return self.dense_decoder(to_dec)
 
     # ---------------------------------------------------------------- masks

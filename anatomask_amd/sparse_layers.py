@@ -306,6 +306,38 @@ class _SparseBNFn(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None, None, None
 
 
+class _DensifyFn(torch.autograd.Function):
+    """P/AnatoMask.py:158-163 in one pair of kernels: pooled sparse InstanceNorm of the active voxels, mask token everywhere else
+    (`densify_norms[i]` + `torch.where(active, x, mask_token)`): am_chan_stats -> am_norm_finalize -> am_norm_apply(fill = token), and
+    backward am_norm_bwd_reduce / apply with the token gradient = the sum of dy over the inactive voxels -- what the fused STUNet
+    engine runs for its densify levels (engine.densify_forward / densify_backward)."""
+
+    @staticmethod
+    def forward(ctx, x_cl, weight, bias, token, eps):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        st = ops.NormStats(C, x_cl.device)
+        g32, b32, t32 = weight.float().contiguous(), bias.float().contiguous(), token.float().contiguous().view(-1)
+        ops.chan_stats(x_cl, mi, bs, st)
+        st.count_host = float(int(mi.t.count_nonzero().item()) if mi.n_active is None else mi.n_active) * float(1 << (3 * bs))
+        st.count_ptr = None
+        ops.norm_finalize(st, g32, b32, eps)
+        y = ops.norm_apply(x_cl, st, ops.ACT_NONE, mi, bs, fill=t32)
+        ctx.save_for_backward(x_cl, g32)
+        ctx.cfg = (mi, bs, st, token.shape, token.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x_cl, g32 = ctx.saved_tensors
+        mi, bs, st, tshape, tdtype = ctx.cfg
+        C = x_cl.shape[-1]
+        dg, db, dt = (torch.zeros(C, device=x_cl.device, dtype=torch.float32) for _ in range(3))
+        dx = ops.norm_backward(dy.contiguous(), None, x_cl, st, g32, ops.ACT_NONE, mi, bs, dg, db, dtoken=dt, fill=True, dx=torch.zeros_like(x_cl))
+        return dx, dg, db, dt.view(tshape).to(tdtype), None
+
+
 class SparseBatchNorm3d(nn.BatchNorm1d):
     """encoder3D.py:39-40 (sp_bn_forward :17-25): BatchNorm1d over the (N_active, C) matrix -- batch statistics over all active voxels
     of the (local) batch, running statistics with the unbiased variance, eval mode on the running statistics."""
