@@ -184,8 +184,9 @@ def secondary_lines(a, kw, dev, dtype_main):
     from anatomask_amd import modules as M
     from anatomask_amd.trainer import AnatoMaskTrainer
     out = []
-    for what, size3, batch, dt, warm, steps in [("same workload at the reference's batch size 4", (a.patch,) * 3, 4, dtype_main, 3, 10),
-                                                ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False)", (112, 112, 128), 4, torch.float32, 2, 4)]:
+    torch.cuda.synchronize()
+    for what, size3, batch, dt, warm, steps in [("same workload at the reference's batch size 4", (a.patch,) * 3, 4, dtype_main, 5, 11),
+                                                ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False)", (112, 112, 128), 4, torch.float32, 2, 5)]:
         torch.manual_seed(0)
         model = M.build_spark(kw["dims"], kw["depth"], kw["width"], size3, a.mask_ratio, compute_dtype=dt).to(dev)
         tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=4321, distributed=False)
@@ -194,13 +195,19 @@ def secondary_lines(a, kw, dev, dtype_main):
         for _ in range(warm):
             tr.step(x, epoch=500)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        # per-step HIP events, MEDIAN reported: right after the headline run's 60 GiB went back to the driver (empty_cache) a window's
+        # first steps can stall on allocator traffic for hundreds of ms -- a property of the process state, not of the step
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        evs[0].record()
+        for i in range(steps):
             o = tr.step(x, epoch=500)
+            evs[i + 1].record()
         torch.cuda.synchronize()
-        d = (time.perf_counter() - t0) / steps
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+        d = per[len(per) // 2] * 1e-3
         out.append({"what": what, "per_gpu_batch": batch, "dtype": "bf16" if dt == torch.bfloat16 else "f32", "ms_per_step": round(d * 1e3, 3),
-                    "value": round(batch / d, 3), "unit": "volumes/s", "steps": steps, "final_loss": round(o["loss"].item(), 5)})
+                    "ms_per_step_max": round(per[-1], 3), "value": round(batch / d, 3), "unit": "volumes/s", "steps": steps,
+                    "final_loss": round(o["loss"].item(), 5)})
         del tr, model, x
         torch.cuda.empty_cache()
     return out
