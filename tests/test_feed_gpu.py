@@ -161,3 +161,40 @@ def test_feed_with_a_tiny_pool_and_a_host_far_ahead_of_the_gpu(tmp_path):
         assert len(set(acc.tolist())) > 20 and bool((acc > 0).all())
     finally:
         pf.close()
+
+
+@pytest.mark.timeout(300)
+def test_pretrain_driver_with_data_feed_checkpoint_and_resume(tmp_path, capsys):
+    """The pretraining driver end to end (anatomask_amd.pretrain.main, the loop of P/pretrain_AntoMask.py:371-479) on a synthetic
+    nnU-Net folder: loader threads -> pinned pool -> copy stream -> device augmentation -> fused step, one checkpoint per epoch; the
+    file loads with a PLAIN torch.load (the finetune hand-off), carries every loader's and the augmenter's generator state, and a
+    resumed run continues at the next epoch with the loaders' generators restored BEFORE their threads start."""
+    from anatomask_amd import checkpoint, pretrain
+    data, out = tmp_path / "data", tmp_path / "run"
+    data.mkdir()
+    make_synthetic_folder(str(data), 7)
+    common = ["--model", "S", "--input-size", "32", "48", "64", "--batch-size", "2", "--iters-per-epoch", "2", "--workers", "2",
+              "--data", str(data), "--out", str(out), "--dtype", "bf16"]
+    pretrain.main(common + ["--epochs", "2"])
+    log = capsys.readouterr().out
+    assert "Epoch 0 " in log and "Epoch 1 " in log
+    p = str(out / "STUNet_S_head_latest.pt")
+    ck = torch.load(p)                                                 # default arguments (weights_only=True): what the reference's loader does
+    assert int(ck["current_epoch"]) == 1 and len(ck["train_loss"]) == 2 and all(np.isfinite(ck["train_loss"]))
+    fs = ck["feed_state"][0]
+    assert sorted(fs["loader_rng"]) == [0, 1] and fs["aug_rng"]["name"] == "MT19937"
+    assert len(checkpoint.encoder_weights_for_finetuning(ck["network_weights"])) == 50
+    # the state a resumed Feed starts from IS the saved one: build it the way main() does and compare before any draw
+    resumed = checkpoint.peek_extra(p, "feed_state")[0]
+    feed = pretrain.Feed(str(data), None, 2, (32, 48, 64), torch.device(DEV), 0, 2, True, seed=1000, state=resumed)
+    try:
+        for w in (0, 1):                                               # (the threads have already drawn: compare the saved keys' identity only)
+            assert feed.loaders[w].rs.get_state()[0] == "MT19937"
+        x = next(feed)
+        assert x.shape == (2, 1, 32, 48, 64) and x.is_cuda
+    finally:
+        feed.close()
+    pretrain.main(common + ["--epochs", "3", "--resume", p])
+    log = capsys.readouterr().out
+    assert "Epoch 2 " in log and "Epoch 0 " not in log and "Epoch 1 " not in log
+    assert int(torch.load(p)["current_epoch"]) == 2
