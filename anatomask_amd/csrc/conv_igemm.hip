@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
     const int idx = tid + it * 256;
     const int row = (idx >> 2) % NT, tig = idx / (NT * 4);
     wsrc[it] = (unsigned)(((co0 + crow(row)) * a.Cinp + (idx & 3) * EPC) * (int)sizeof(T));
-    wdst[it] = idx < WCH ? tig * NT * ROWB + swz(row, idx & 3) : -1;
+    wdst[it] = tig * NT * ROWB + swz(row, idx & 3);
   }
   int aoff[NS];                                          // swizzled LDS offset of this lane's weight row chunk (tap 0 of a group)
 #pragma unroll
@@ -148,9 +148,12 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
     const int wi_ = AM_TAP(tt_) >> 20;                                                                      \
     WR[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (tt_ < nt && (OK) && !AM_DBG(a, 4)) ? wsrc[it] : OOB, wi_ * wtapB + (KCW) * (int)sizeof(T), 0)); \
   }
+  // (UNCONDITIONAL stores: a lane-masked store puts the wait for its load inside a branch a wave may skip, and the compiler then
+  // drains `vmcnt` at the head of the group loop for the path it cannot rule out)
+  static_assert(WCH % 256 == 0, "every thread stages exactly WIT chunks of a weight group");
 #define AM_WSTORE(WR, BUF)                                                                                 \
   _Pragma("unroll") for (int it = 0; it < WIT; ++it)                                                        \
-    if (wdst[it] >= 0) *(u32x4*)(ldsW + (BUF) * WBUF + wdst[it]) = WR[it];
+    *(u32x4*)(ldsW + (BUF) * WBUF + wdst[it]) = WR[it];
   // issue the loads of the source brick's channel slab KCS into stg (only a partial last slab, Cin % KC != 0, has !cok lanes)
 #define AM_SLOAD(KCS, OK)                                                                                  \
   {                                                                                                        \
@@ -217,25 +220,23 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
     u32x4 stg[NIT], wr[WIT];
     AM_SLOAD(0, true);
     AM_WLOAD(wr, 0, 0, true);
+    int bufp = 0;                                        // LDS weight buffer of the CURRENT group (toggles every group, across slabs)
     for (int kc = 0; kc < a.Cinp; kc += KC) {
-      __syncthreads();                                   // all fragment reads of the previous slab / unit are done
+      // (every group ends with a barrier: all fragment reads of the previous slab / unit are done)
+      if (kc == 0) {
+        __syncthreads();
+        AM_WSTORE(wr, bufp);                             // later slabs: their group 0 was stored by the previous slab's last group
+      }
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
         if (((tid + it * 256) >> 2) < nvox) *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
-      AM_WSTORE(wr, 0);
       __syncthreads();
       const bool more_slabs = kc + KC < a.Cinp;
-      AM_SLOAD(kc + KC, more_slabs);                     // branch-free: past the last slab the loads are out-of-range (zeros, no traffic)
-      for (int gi = 0; gi < ng; ++gi) {
-        const int buf = gi & 1;
-        const bool more = gi + 1 < ng;
-        // next group's weights (or group 0 of the next slab) fly while this group's MFMAs issue (branch-free:
-        // a conditional load makes hipcc drain vmcnt at the join)
-        AM_WLOAD(wr, more ? gi + 1 : 0, more ? kc : kc + KC, more || more_slabs);
+      // One weight group = TG taps: straight-line (padding taps multiply zero weights), no per-tap branch, so the fragment reads of
+      // tap t+1 can be scheduled under the MFMAs of tap t
+      auto mma_group = [&](const int gi, const int buf) __attribute__((always_inline)) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);                     // the MFMA cluster of a weight group issues ahead of the other wave's staging / address work (+1.5-3.5 %)
-        // straight-line over the TG taps of the group (padding taps multiply zero weights): no per-tap branch, so the
-        // fragment reads of tap t+1 can be scheduled under the MFMAs of tap t
         if constexpr (HR) {
           // h-runs: taps 3r, 3r+1, 3r+2 of the group differ only by one h-row of the source brick, and subtile j IS h-row j of the
           // wave's d-plane (4x4x16 brick): fragment row j+th serves (subtile j, tap th) -- 6 row reads per run instead of 12
@@ -260,24 +261,49 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
           }
         } else {
 #pragma unroll
-        for (int tl = 0; tl < TG; ++tl) {
-          const int tt = gi * TG + tl;
-          const int tob = AM_TAP(tt) & 0xFFFFF;
-          u32x4 af[NS];
+          for (int tl = 0; tl < TG; ++tl) {
+            const int tt = gi * TG + tl;
+            const int tob = AM_TAP(tt) & 0xFFFFF;
+            u32x4 af[NS];
 #pragma unroll
-          for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
+            for (int i = 0; i < NS; ++i) af[i] = *(const u32x4*)(ldsW + buf * WBUF + tl * NT * ROWB + aoff[i]);
 #pragma unroll
-          for (int j = 0; j < VS; ++j) {
-            // (16-wide bricks with one d-plane per wave: subtile j is h-row j, so its offset is bb[0] + j rows -- no register per subtile)
-            const u32x4 bf = *(const u32x4*)(lds + ((BW == 16 && MV / 4 == BH * BW) ? bb[0] + j * (EW * LROWB) : bb[j]) + tob);
+            for (int j = 0; j < VS; ++j) {
+              // (16-wide bricks with one d-plane per wave: subtile j is h-row j, so its offset is bb[0] + j rows -- no register per subtile)
+              const u32x4 bf = *(const u32x4*)(lds + ((BW == 16 && MV / 4 == BH * BW) ? bb[0] + j * (EW * LROWB) : bb[j]) + tob);
 #pragma unroll
-            for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+            }
           }
-        }
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more) { if (!AM_DBG(a, 32)) { AM_WSTORE(wr, buf ^ 1); } if (!AM_DBG(a, 16)) __syncthreads(); }
+      };
+      // Load pipeline of a slab.  Every group is the same straight line: issue the NEXT group's weight loads (group 0 of the next
+      // slab after the last group; out of range -- zeros, no traffic -- past the last slab), run this group's MFMAs, wait for the
+      // weights, store them into the other LDS buffer, barrier.  There is no path from an un-waited load back to the loop head (with
+      // `if (more)` around the store, or lane-masked stores, the compiler saw one and drained `vmcnt` at the head: on entry that wait
+      // retired the next slab's source loads issued a moment earlier, before the slab's first MFMA -- their whole latency exposed once
+      // per slab and workgroup).  `vmcnt` retires loads IN ORDER, so the place of the slab loads in the issue order decides how long
+      // they may fly: group 0 is peeled and issues them AFTER group 1's weight loads -- the counted wait for those weights at the end
+      // of group 0 (vmcnt(NIT + 2) ...) leaves them outstanding, and the wait at the end of group 1 retires them: two groups of MFMAs
+      // (96-192 of them) of cover.
+      {
+        const bool more = ng > 1;
+        AM_WLOAD(wr, more ? 1 : 0, more ? kc : kc + KC, more || more_slabs);
+        AM_SLOAD(kc + KC, more_slabs);                     // branch-free: past the last slab the loads are out-of-range (zeros, no traffic)
+        mma_group(0, bufp);
+        if (!AM_DBG(a, 32)) { AM_WSTORE(wr, bufp ^ 1); }
+        if (!AM_DBG(a, 16)) __syncthreads();
+        bufp ^= 1;
+      }
+      for (int gi = 1; gi < ng; ++gi) {
+        const bool more = gi + 1 < ng;
+        AM_WLOAD(wr, more ? gi + 1 : 0, more ? kc : kc + KC, more || more_slabs);
+        mma_group(gi, bufp);
+        if (!AM_DBG(a, 32)) { AM_WSTORE(wr, bufp ^ 1); }
+        if (!AM_DBG(a, 16)) __syncthreads();
+        bufp ^= 1;
       }
     }
   }
@@ -487,7 +513,10 @@ int dispatch_nit(Plan& P, int shape, hipStream_t st) {
     } else return -7;
   }
   if (P.tgs == 2) {                              // multi-unit plans: sub-bricks of at most (BD+1)(BH+1)(BW+1) voxels
-    if (shape == 3) return n <= 12 ? launch<T, 4, 8, 16, NS, 12, 2>(P, st) : -3;     // 512-voxel bricks (dense transposed convs)
+    if (shape == 3) {                                                                  // 512-voxel bricks (dense transposed convs, bf16)
+      if constexpr (sizeof(T) == 2) return n <= 12 ? launch<T, 4, 8, 16, NS, 12, 2>(P, st) : -3;
+      else return -3;
+    }
     if (shape == 2) return n <= 4 ? launch<T, 4, 4, 4, NS, 4, 2>(P, st) : -3;
     if (shape == 1) return n <= 4 ? launch<T, 4, 4, 16, NS, 4, 2>(P, st) : n <= 7 ? launch<T, 4, 4, 16, NS, 7, 2>(P, st) : -3;
     return n <= 4 ? launch<T, 4, 8, 8, NS, 4, 2>(P, st) : n <= 7 ? launch<T, 4, 8, 8, NS, 7, 2>(P, st) : -3;
@@ -567,7 +596,7 @@ extern "C" int am_conv3d_partials_rows(int mode, int dtype, int ksize, int strid
   const int os = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
   const int qd = (Do + os - 1) / os, qh = (Ho + os - 1) / os, qw = (Wo + os - 1) / os;
   int bd, bh, bw, nt;
-  pick_tiling(os, B, qd, qh, qw, Cout, out_sparse != 0, out_bshift, &bd, &bh, &bw, &nt);
+  pick_tiling(os, B, qd, qh, qw, Cout, out_sparse != 0, out_bshift, &bd, &bh, &bw, &nt, dtype == AM_DT_BF16);   // (512-voxel bricks: bf16 only, as in conv3d_impl)
   *rows = B * ((qd + bd - 1) / bd) * ((qh + bh - 1) / bh) * ((qw + bw - 1) / bw) * (os == 2 ? 8 : 1);
   // upper bound over the kernels a launch of this shape may take (am_conv3d reports the rows it actually wrote)
   const int rw = conv_rw_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse, out_bshift, n_active);
@@ -611,7 +640,7 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
 generic:
 #endif
   const int os_ = (mode == AM_CONV_DGRAD) ? stride : (mode == AM_CONVT_FWD ? 2 : 1);
-  bool big_ok = true;
+  bool big_ok = dtype == AM_DT_BF16;             // 512-voxel transposed-conv bricks: bf16 only (the fp32 instantiation needs 258 VGPRs and spills)
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_CV_NOBIG"); if (e_ && atoi(e_)) big_ok = false; }
 #endif
