@@ -190,6 +190,11 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((const T*)a.x + ((size_t)b * a.Di + dbase) * plane_elems), 0, (int)(left < 0x7fffff00ull ? left : 0x7fffff00ull), 0x00020000);
 
+    // the first weight group's loads go out BEFORE the staging plan is computed (they do not depend on it): their latency runs under
+    // the plan's ~300 vector instructions instead of behind them
+    u32x4 stg[NIT], wr[WIT];
+    AM_WLOAD(wr, 0, 0, true);
+
     // ---- per-thread staging plan for this unit's source brick: byte offset of this thread's chunk in each of its rows ----
     unsigned soff[NIT];
     const int mW = a.mdiv_w[un], mHW = a.mdiv_hw[un], EHW = EH * EW;
@@ -217,9 +222,7 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
     // Software pipeline over the channel slabs: the source brick of slab k+1 and the first weight group of slab k+1 are
     // loaded into registers while the MFMAs of slab k issue (HBM latency of every slab but the first is hidden), and are
     // written to LDS behind the barrier that ends slab k.
-    u32x4 stg[NIT], wr[WIT];
     AM_SLOAD(0, true);
-    AM_WLOAD(wr, 0, 0, true);
     int bufp = 0;                                        // LDS weight buffer of the CURRENT group (toggles every group, across slabs)
     for (int kc = 0; kc < a.Cinp; kc += KC) {
       // (every group ends with a barrier: all fragment reads of the previous slab / unit are done)
