@@ -28,6 +28,7 @@
 // (16 bytes) per lane and (optionally) leaves per-workgroup per-channel partial sums (sum, sum of squares) for the norm
 // that follows -- no extra pass over y.
 #include <mutex>
+#include <type_traits>
 #include <stdlib.h>
 #include "common.h"
 #include "../../include/anatomask_hip.h"
@@ -40,7 +41,9 @@ namespace {
 // NB: the norm-backward-reduce variant (am_conv3d_nbred, bf16): the tile of the norm's input that the epilogue needs is fetched at
 // the START of the workgroup (32 more registers) -- loaded in the epilogue its HBM latency is exposed once per workgroup, which
 // for a one-slab data gradient (3.5 us of MFMAs) ate everything the fused reduce saves.
-template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false>
+// HT: the unit's LAST weight group holds exactly TG / 2 taps (k3 s1 with the 32-channel output tile: 27 taps = 4 groups of 6 + 3) and runs
+// a cluster of TG / 2 taps -- compile time, no branch inside the MFMA cluster: the padded form issued 30 tap slots for 27 taps.
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false, bool HT = false>
 __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
@@ -237,16 +240,17 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
       const bool more_slabs = kc + KC < a.Cinp;
       // One weight group = TG taps: straight-line (padding taps multiply zero weights), no per-tap branch, so the fragment reads of
       // tap t+1 can be scheduled under the MFMAs of tap t
-      auto mma_group = [&](const int gi, const int buf) __attribute__((always_inline)) {
+      auto mma_group = [&](const int gi, const int buf, auto half_tag) __attribute__((always_inline)) {
+        constexpr int NTP = decltype(half_tag)::value ? TG / 2 : TG;      // taps of this cluster
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);                     // the MFMA cluster of a weight group issues ahead of the other wave's staging / address work (+1.5-3.5 %)
         if constexpr (HR) {
           // h-runs: taps 3r, 3r+1, 3r+2 of the group differ only by one h-row of the source brick, and subtile j IS h-row j of the
           // wave's d-plane (4x4x16 brick): fragment row j+th serves (subtile j, tap th) -- 6 row reads per run instead of 12
-          static_assert(TG % 3 == 0 && BD == 4 && BH == 4 && BW == 16 && VS == 4, "h-run reuse needs the 4x4x16 brick and 3-tap runs");
+          static_assert(TG % 3 == 0 && NTP % 3 == 0 && BD == 4 && BH == 4 && BW == 16 && VS == 4, "h-run reuse needs the 4x4x16 brick and 3-tap runs");
           const int ewb = EW * LROWB;
 #pragma unroll
-          for (int tr = 0; tr < TG / 3; ++tr) {
+          for (int tr = 0; tr < NTP / 3; ++tr) {
             const int tob = AM_TAP(gi * TG + tr * 3) & 0xFFFFF;
             u32x4 brow[VS + 2];
 #pragma unroll
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
           }
         } else {
 #pragma unroll
-          for (int tl = 0; tl < TG; ++tl) {
+          for (int tl = 0; tl < NTP; ++tl) {
             const int tt = gi * TG + tl;
             const int tob = AM_TAP(tt) & 0xFFFFF;
             u32x4 af[NS];
@@ -295,15 +299,29 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
         const bool more = ng > 1;
         AM_WLOAD(wr, more ? 1 : 0, more ? kc : kc + KC, more || more_slabs);
         AM_SLOAD(kc + KC, more_slabs);                     // branch-free: past the last slab the loads are out-of-range (zeros, no traffic)
-        mma_group(0, bufp);
+        mma_group(0, bufp, std::false_type{});
         if (!AM_DBG(a, 32)) { AM_WSTORE(wr, bufp ^ 1); }
         if (!AM_DBG(a, 16)) __syncthreads();
         bufp ^= 1;
       }
+      if constexpr (HT) {                                  // (host: one unit, ng >= 2, the last group holds TG / 2 taps)
+        for (int gi = 1; gi + 1 < ng; ++gi) {
+          AM_WLOAD(wr, gi + 1, kc, true);
+          mma_group(gi, bufp, std::false_type{});
+          if (!AM_DBG(a, 32)) { AM_WSTORE(wr, bufp ^ 1); }
+          if (!AM_DBG(a, 16)) __syncthreads();
+          bufp ^= 1;
+        }
+        AM_WLOAD(wr, 0, kc + KC, more_slabs);
+        mma_group(ng - 1, bufp, std::true_type{});
+        if (!AM_DBG(a, 32)) { AM_WSTORE(wr, bufp ^ 1); }
+        if (!AM_DBG(a, 16)) __syncthreads();
+        bufp ^= 1;
+      } else
       for (int gi = 1; gi < ng; ++gi) {
         const bool more = gi + 1 < ng;
         AM_WLOAD(wr, more ? gi + 1 : 0, more ? kc : kc + KC, more || more_slabs);
-        mma_group(gi, bufp);
+        mma_group(gi, bufp, std::false_type{});
         if (!AM_DBG(a, 32)) { AM_WSTORE(wr, bufp ^ 1); }
         if (!AM_DBG(a, 16)) __syncthreads();
         bufp ^= 1;
@@ -491,10 +509,10 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
   }
 }
 
-template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false>
+template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false, bool HT = false>
 int launch(Plan& P, hipStream_t st) {
   ConvArgs& a = P.a;
-  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS, HR, NB>;
+  auto kern = conv_igemm_kernel<T, BD, BH, BW, NS, NIT, TGS, HR, NB, HT>;
   static PerDeviceOnce lds_cap;                   // per instantiation and device: lift the 48 KB dynamic-LDS default to the CU's 160 KB
   lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   if (P.lds > 160 * 1024) return -3;
@@ -527,6 +545,13 @@ int dispatch_nit(Plan& P, int shape, hipStream_t st) {
   if (shape == 2) {                              // 4x4x4 brick: tiny grids only (more workgroups)
     if (n <= 4) return launch<T, 4, 4, 4, NS, 4>(P, st);
     return -3;
+  }
+  // 32-channel output tile (TG = 6) on a 27-tap unit: 4 full groups + a half group (kernel variant HT), bf16
+  const bool ht = NS == 2 && sizeof(T) == 2 && P.a.nunit == 1 && P.a.tap_begin[1] == 27;
+  if constexpr (NS == 2 && sizeof(T) == 2) {
+    if (ht && shape == 1 && n > 7 && n <= 11)
+      return P.a.hreuse ? launch<T, 4, 4, 16, NS, 11, 3, true, false, true>(P, st) : launch<T, 4, 4, 16, NS, 11, 3, false, false, true>(P, st);
+    if (ht && shape == 0 && n > 7 && n <= 11) return launch<T, 4, 8, 8, NS, 11, 3, false, false, true>(P, st);
   }
   if (shape == 1) {                              // 4x4x16: every 16-lane fragment is 16 consecutive voxels (conflict-free reads)
     if (n <= 4) return launch<T, 4, 4, 16, NS, 4>(P, st);
