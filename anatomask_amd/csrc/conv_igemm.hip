@@ -60,15 +60,31 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
-  const int cls = blockIdx.z;
-  int bid = blockIdx.x;
+  // Workgroups that read the SAME source brick -- the output-channel tiles of a brick, and for two-class-stride plans (OS == 2:
+  // transposed conv, strided data gradient) its 8 output-parity classes -- live next to each other in blockIdx.x:
+  //   linear id = ((brick / 8) * nsib + sibling) * 8 + brick % 8,   sibling = ytile * nclass + class,
+  // so a brick's siblings have ids that differ by multiples of 8 (the same XCD under round-robin dispatch -- speed only) and are
+  // dispatched back to back: the source is fetched into that L2 once.  (As grid.y / grid.z they ran tile-major / class-major: the whole
+  // grid of class 0, then class 1, ... -- rocprofv3 counted 4.96 GB fetched by the ConvT 64->64 @128^3 launch for a 0.54 GB source and
+  // 3.2 GB by 128->128 @64^3, two channel tiles, for 1.07 GB.)
+  int cls = 0, ytile = 0, bid = blockIdx.x;
+  {
+    const int nsib = a.nclass * a.ny;
+    if (nsib > 1) {
+      const int t = bid >> 3, sib = t % nsib;
+      cls = sib % a.nclass; ytile = sib / a.nclass;
+      bid = ((t / nsib) << 3) + (bid & 7);
+      if (bid >= a.B * a.nbd * a.nbh * a.nbw) return;    // (grid padded to whole groups of 8 bricks)
+    }
+  }
+  const int brick = bid;
   const int bw_ = bid % a.nbw; bid /= a.nbw;
   const int bh_ = bid % a.nbh; bid /= a.nbh;
   const int bd_ = bid % a.nbd; const int b = bid / a.nbd;
   const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
-  const int co0 = blockIdx.y * NT;
-  float* part = a.partials ? a.partials + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * a.Cout) * 2 : nullptr;
+  const int co0 = ytile * NT;
+  float* part = a.partials ? a.partials + ((size_t)((size_t)cls * (a.B * a.nbd * a.nbh * a.nbw) + brick) * a.Cout) * 2 : nullptr;
 #ifdef AM_ABLATE
   // timing experiment (tools build): delay every second set of 256 workgroups of the FIRST dispatch round, so that the two
   // workgroups that share a CU do not run their prologue / main loop / epilogue phases in lockstep (AM_CV_DBG bits 4096.., n x s_sleep 127)
@@ -516,7 +532,10 @@ int launch(Plan& P, hipStream_t st) {
   static PerDeviceOnce lds_cap;                   // per instantiation and device: lift the 48 KB dynamic-LDS default to the CU's 160 KB
   lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   if (P.lds > 160 * 1024) return -3;
-  dim3 grid(a.B * a.nbd * a.nbh * a.nbw, (a.Cout + 16 * NS - 1) / (16 * NS), a.nclass);
+  const unsigned nbrick = (unsigned)(a.B * a.nbd * a.nbh * a.nbw);
+  a.ny = (a.Cout + 16 * NS - 1) / (16 * NS);
+  const unsigned nsib = (unsigned)(a.ny * a.nclass);
+  dim3 grid(nsib > 1 ? ((nbrick + 7) / 8) * 8 * nsib : nbrick, 1, 1);       // (channel tiles and parity classes folded into x, see the kernel)
   AM_LAUNCH(kern, grid, dim3(256), P.lds, st, a);
   AM_CHECK_LAUNCH();
   return 0;

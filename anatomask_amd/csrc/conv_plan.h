@@ -12,10 +12,11 @@ struct ConvArgs {
   // partial rows then hold (sum g, sum g * nb_x) with g = y * act'(.) instead of (sum y, sum y^2)  -- am_conv3d_nbred
   const void* nb_x; const float* nb_scale; const float* nb_shift; int nb_act;
   int B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, Cinp, Coutp;
-  int OS, GS, nclass, nunit;  // output stride (parity classes), global source stride, #classes (grid.z), #units
+  int OS, GS, nclass, nunit;  // output stride (parity classes), global source stride, #classes, #units
+  int ny;                     // output-channel tiles per brick (conv_igemm: folded into blockIdx.x with the classes)
   int nbd, nbh, nbw;          // bricks per dim of the q grid
   int tap_begin[9];           // per unit.  A unit = one dense source sub-brick + the taps that read it:
-                              //   OS == 2 : unit = output parity class (one per workgroup, blockIdx.z)
+                              //   OS == 2 : unit = output parity class (one per workgroup)
                               //   GS == 2 : unit = source parity sub-lattice (all units looped inside the workgroup)
   int upar[8];                // source parity of the unit (pd<<2 | ph<<1 | pw), 0 unless GS == 2
   int taps[64];               // (ud+8) | (uh+8)<<4 | (uw+8)<<8 | widx<<12 | unit<<18 ; u* = shift in sub-lattice voxels
