@@ -41,7 +41,7 @@ struct WgArgs {
   int mdiv_w[8], mdiv_hw[8];  // 2^20-scaled reciprocals of ew and ew*eh
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
-  int split;                  // brick-walk slots per (tile, group)
+  int split, ntile;           // brick-walk slots per (tile, group) ; (cy, cx) channel tiles
   int mask_off, mask_n;       // block-sparse operands: LDS byte offset of the two cached patch-mask arrays (dY's, X's) of ONE sample, bytes each (0: not cached)
   int walk, seg_len, nseg;    // walk 1: d-fastest segments of seg_len bricks, columns interleaved over the slots of an XCD (see the kernel)
   float* det_ws;              // deterministic mode: [split][k^3][Cy][Cx] per-slot partial sums (plain stores), folded in slot order
@@ -96,17 +96,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
   const int wx = wave % NWX, wk = wave / NWX;            // cx tile of this wave ; its share of the k-steps
-  // workgroup id -> (brick-walk slot s, tap group): the groups that walk the SAME bricks get ids that differ by 8, i.e. the
-  // same XCD under round-robin dispatch (shared L2: x and dy are fetched from HBM once, not once per group) -- speed only
-  const int ng_ = a.ngroup;
-  const int blk_ = blockIdx.x / (8 * ng_), rem_ = blockIdx.x % (8 * ng_);
+  // workgroup id -> (brick-walk slot s, tap group, channel tile): the workgroups that walk the SAME bricks -- the tap groups and
+  // the (cy, cx) tiles of one slot -- get ids that differ by 8, i.e. the same XCD under round-robin dispatch, and are dispatched
+  // back to back, so they walk in step and x / dy come from HBM once per slot instead of once per group and tile (speed only)
+  const int ng_ = a.ngroup, nsib_ = ng_ * a.ntile;
+  const int blk_ = blockIdx.x / (8 * nsib_), rem_ = blockIdx.x % (8 * nsib_);
+  const int sib_ = rem_ >> 3, tile_ = sib_ / ng_;
   // (fewer than 8 slots -- layers whose tiles alone fill the chip: the live slots rotate with the tile index, or every live
   // workgroup would sit on XCD 0)
-  const int slot = blk_ * 8 + ((rem_ & 7) + (a.split < 8 ? 8 - (blockIdx.y & 7) : 0)) % 8;
+  const int slot = blk_ * 8 + ((rem_ & 7) + (a.split < 8 ? 8 - (tile_ & 7) : 0)) % 8;
   if (slot >= a.split) return;
-  const int grp = a.zmap[rem_ >> 3];
+  const int grp = a.zmap[sib_ - tile_ * ng_];
   const int ncxt = (a.Cx + KT - 1) / KT;
-  const int cy0 = (blockIdx.y / ncxt) * CT, cx0 = (blockIdx.y % ncxt) * KT;
+  const int cy0 = (tile_ / ncxt) * CT, cx0 = (tile_ % ncxt) * KT;
   const int pd = (a.pofs[grp] >> 2) & 1, ph = (a.pofs[grp] >> 1) & 1, pw = a.pofs[grp] & 1;
   const int ED = a.ed[grp], EH = a.eh[grp], EW = a.ew[grp];
   const int nvox = ED * EH * EW;
@@ -523,7 +525,8 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WG_SEG"); if (e_ && atoi(e_) > 0) { a.seg_len = atoi(e_) < a.nbd ? atoi(e_) : a.nbd; a.nseg = (a.nbd + a.seg_len - 1) / a.seg_len; } }
 #endif
-  dim3 grid(((split + 7) / 8) * 8 * a.ngroup, ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT), 1);
+  a.ntile = ((a.Cy + CT - 1) / CT) * ((a.Cx + KT - 1) / KT);
+  dim3 grid((unsigned)(((split + 7) / 8) * 8 * a.ngroup * a.ntile), 1, 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a);
   AM_CHECK_LAUNCH();
   if (a.det_ws) {
