@@ -42,6 +42,7 @@ struct WgArgs {
   int pofs[8];                // parity of dY voxels per group: pd<<2|ph<<1|pw
   MaskView x_mask, y_mask;
   int split, ntile;           // brick-walk slots per (tile, group) ; (cy, cx) channel tiles
+  int y_uni;                  // block-sparse dY whose bricks each lie inside ONE patch, grid = whole bricks: one mask lookup per brick
   int mask_off, mask_n;       // block-sparse operands: LDS byte offset of the two cached patch-mask arrays (dY's, X's) of ONE sample, bytes each (0: not cached)
   int walk, seg_len, nseg;    // walk 1: d-fastest segments of seg_len bricks, columns interleaved over the slots of an XCD (see the kernel)
   float* det_ws;              // deterministic mode: [split][k^3][Cy][Cx] per-slot partial sums (plain stores), folded in slot order
@@ -76,7 +77,10 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
 // S2 (stride-2 conv k3, bf16): the X brick is staged at FULL resolution ((2 BH + 1) x (2 BW + 1) voxels of one plane) and the fragment
 // reads step two voxel rows per q -- the 9 (kh, kw) taps of a d-tap share one staged brick and one dY brick, instead of 8 parity
 // sub-lattice units that each re-stage dY for 1-8 taps.
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false>
+// PF: the loads of the next live brick are issued BEFORE the contraction of the current one and land in the staging registers while
+// the matrix cores run (variants with registers to spare: the small bricks of the block-sparse stride-2 layers, whose 36 MFMAs per
+// wave and brick cannot hide a memory round trip behind the other workgroup of the CU).
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false, bool PF = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int CT = 16 * MI, KT = 16 * NWX, KS = 4 / NWX;
@@ -186,112 +190,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int c0 = (int)((long)ncol * (slot & 7) / 8), ncx = (int)((long)ncol * ((slot & 7) + 1) / 8) - c0;
   const int nu = ncx * a.nseg;
   // (two nested counted loops: the flat `for (;;)` form of this walk made hipcc spill 120 VGPRs)
-  int mask_b = -1;                                       // sample whose patch masks sit in LDS
-  const int u_end = a.walk ? nu : (slot >> 3) + 1, u_inc = a.walk ? S8 : u_end;     // walk 0: exactly one pass (u_inc >= 1 always)
-  for (int u = slot >> 3; u < u_end; u += u_inc) {
-  int nstep = brick1 - brick0;
-  if (a.walk) {
-    const int seg = u / ncx, col = c0 + u % ncx;
-    bw_ = col % nbw_; bh_ = (col / nbw_) % nbh_; b = col / (nbw_ * nbh_);
-    bd_ = seg * a.seg_len - 1;
-    nstep = nbd_ - seg * a.seg_len < a.seg_len ? nbd_ - seg * a.seg_len : a.seg_len;
-  }
-  for (int step = 0; step < nstep; ++step) {
-    if (a.walk) ++bd_;
-    else if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
-    const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
-    // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
-    const int i0d = q0d * a.QS + a.mind[grp] * GS_ + upd, i0h = q0h * a.QS + a.minh[grp] * GS_ + uph, i0w = q0w * a.QS + a.minw[grp] * GS_ + upw;
-    const int o0d = q0d * OS_ + pd, o0h = q0h * OS_ + ph, o0w = q0w * OS_ + pw;
-    // descriptors anchored at the first d-plane of this brick (32-bit offsets span a few planes only: any tensor size works)
-    const int yd0 = o0d < Dy_ ? o0d : Dy_, xd0 = i0d < 0 ? 0 : (i0d > Dx_ ? Dx_ : i0d);
-    const int ybaseB = ((((o0d - yd0) * Hy_ + o0h) * Wy_ + o0w) * a.Cy) * (int)sizeof(T);   // brick origin relative to plane yd0 of sample b
-    const int xbaseB = ((((i0d - xd0) * Hx_ + i0h) * Wx_ + i0w) * a.Cx) * (int)sizeof(T);
-    const size_t yleft = (size_t)(Dy_ - yd0) * yplane * sizeof(T), xleft = (size_t)(Dx_ - xd0) * xplane * sizeof(T);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + ((size_t)b * Dy_ + yd0) * yplane), 0,
-                                                                        (int)(yleft < 0x7fffff00ull ? yleft : 0x7fffff00ull), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + ((size_t)b * Dx_ + xd0) * xplane), 0,
-                                                                        (int)(xleft < 0x7fffff00ull ? xleft : 0x7fffff00ull), 0x00020000);
-    // interior brick of a dense tensor (wave-uniform): every row in range, the row offsets are used as they are
-    const bool interior = !masked && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + (ED - 1) * GS_ < Dx_ &&
-                          i0h + (EH - 1) * GS_ < Hx_ && i0w + (EW - 1) * GS_ < Wx_ && o0d + (BD - 1) * OS_ < Dy_ && o0h + (BH - 1) * OS_ < Hy_ &&
-                          o0w + (BW - 1) * OS_ < Wy_;
-    unsigned yo[NITY], xo[NITX];
-#pragma unroll
-    for (int it = 0; it < NITY; ++it) yo[it] = yoffB[it];
-#pragma unroll
-    for (int it = 0; it < NITX; ++it) xo[it] = xoffB[it];
-    if (!interior) {
-      if (!masked) {                                     // border brick of a dense tensor: range tests only, branch-free
-#pragma unroll
-        for (int it = 0; it < NITY; ++it) {
-          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
-          if (!(od < Dy_ && oh < Hy_ && ow < Wy_)) yo[it] = OOB;
-        }
-#pragma unroll
-        for (int it = 0; it < NITX; ++it) {
-          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
-          if (!((unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_)) xo[it] = OOB;
-        }
-      } else if (a.mask_n) {                             // block-sparse operands, the sample's patch masks cached in LDS
-        // (a global lookup per row puts two dependent memory round trips -- dY rows, then X rows -- in front of the brick's
-        // loads, and one in front of every skipped brick: the sparse levels ran at 6 us per brick for 0.6 us of MFMAs)
-        uint8_t* ldsMy = lds + a.mask_off;
-        uint8_t* ldsMx = ldsMy + a.mask_n;
-        if (b != mask_b) {                               // (uniform) first brick of a sample
-          __syncthreads();
-          for (int i = tid; i < a.mask_n; i += 256) {
-            ldsMy[i] = a.y_mask.m ? a.y_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
-            ldsMx[i] = a.x_mask.m ? a.x_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
-          }
-          __syncthreads();
-          mask_b = b;
-        }
-        const int ybs = a.y_mask.bs, xbs = a.x_mask.bs, mfh = a.y_mask.fh, mfw = a.y_mask.fw;
-        unsigned yany = 0;
-#pragma unroll
-        for (int it = 0; it < NITY; ++it) {
-          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
-          const bool inr = yo[it] != OOB && od < Dy_ && oh < Hy_ && ow < Wy_;
-          const bool ok = inr && ldsMy[inr ? ((od >> ybs) * mfh + (oh >> ybs)) * mfw + (ow >> ybs) : 0] != 0;
-          if (!ok) yo[it] = OOB;
-          yany |= ok ? 1u : 0u;
-        }
-        if (a.y_mask.m && !__syncthreads_or(yany != 0)) continue;    // nothing active in this brick (block-sparse dY)
-#pragma unroll
-        for (int it = 0; it < NITX; ++it) {
-          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
-          const bool inr = xo[it] != OOB && (unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_;
-          if (!(inr && ldsMx[inr ? ((id >> xbs) * mfh + (ih >> xbs)) * mfw + (iw >> xbs) : 0] != 0)) xo[it] = OOB;
-        }
-      } else {                                           // (masks too large for LDS: global patch-mask lookups per row)
-        unsigned yany = 0;
-#pragma unroll
-        for (int it = 0; it < NITY; ++it) {
-          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
-          const bool ok = yo[it] != OOB && od < Dy_ && oh < Hy_ && ow < Wy_ && a.y_mask.active(b, od, oh, ow);
-          if (!ok) yo[it] = OOB;
-          yany |= ok ? 1u : 0u;
-        }
-        if (a.y_mask.m && !__syncthreads_or(yany != 0)) continue;    // nothing active in this brick (block-sparse dY)
-#pragma unroll
-        for (int it = 0; it < NITX; ++it) {
-          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
-          const bool ok = xo[it] != OOB && (unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_ &&
-                          a.x_mask.active(b, id, ih, iw);
-          if (!ok) xo[it] = OOB;
-        }
-      }
-    }
-    u32x4 ys[NITY], xs[NITX];
-    // buffer loads: per-lane 32-bit byte offset (row offset + the brick's scalar origin, which may be negative for halo rows that
-    // are then OOB-marked); hardware zero-fill for OOB rows
-#pragma unroll
-    for (int it = 0; it < NITY; ++it)
-      ys[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (yo[it] == OOB || AM_DBG(a, 4)) ? OOB : yo[it] + (unsigned)ybaseB, 0, 0));
-#pragma unroll
-    for (int it = 0; it < NITX; ++it)
-      xs[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo[it] == OOB || AM_DBG(a, 4)) ? OOB : xo[it] + (unsigned)xbaseB, 0, 0));
+  u32x4 ys[NITY], xs[NITX];                              // staging registers of one brick (dY rows, X rows)
+  bool have = false;                                     // PF: ys / xs hold a brick that has not been contracted yet
+  auto stage_to_lds = [&]() {
     __syncthreads();                                     // previous brick's fragment reads are done
 #pragma unroll
     for (int it = 0; it < NITY; ++it)
@@ -300,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     for (int it = 0; it < NITX; ++it)
       if (tid / CPRX + it * VPI_X < nvox && !AM_DBG(a, 8)) *(u32x4*)(ldsX + xdst0 + it * VPI_X * RSX) = xs[it];
     __syncthreads();
-
+  };
+  auto contract = [&]() {
     // ---- contract over the brick's voxels ----
     if (!AM_DBG(a, 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
@@ -369,7 +271,151 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       }
     }
     if (!AM_DBG(a, 32)) __builtin_amdgcn_s_setprio(0);
+  };
+  int mask_b = -1;                                       // sample whose patch masks sit in LDS
+  const int u_end = a.walk ? nu : (slot >> 3) + 1, u_inc = a.walk ? S8 : u_end;     // walk 0: exactly one pass (u_inc >= 1 always)
+  for (int u = slot >> 3; u < u_end; u += u_inc) {
+  int nstep = brick1 - brick0;
+  if (a.walk) {
+    const int seg = u / ncx, col = c0 + u % ncx;
+    bw_ = col % nbw_; bh_ = (col / nbw_) % nbh_; b = col / (nbw_ * nbh_);
+    bd_ = seg * a.seg_len - 1;
+    nstep = nbd_ - seg * a.seg_len < a.seg_len ? nbd_ - seg * a.seg_len : a.seg_len;
   }
+  for (int step = 0; step < nstep; ++step) {
+    if (a.walk) ++bd_;
+    else if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
+    const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
+    // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
+    const int i0d = q0d * a.QS + a.mind[grp] * GS_ + upd, i0h = q0h * a.QS + a.minh[grp] * GS_ + uph, i0w = q0w * a.QS + a.minw[grp] * GS_ + upw;
+    const int o0d = q0d * OS_ + pd, o0h = q0h * OS_ + ph, o0w = q0w * OS_ + pw;
+    // descriptors anchored at the first d-plane of this brick (32-bit offsets span a few planes only: any tensor size works)
+    const int yd0 = o0d < Dy_ ? o0d : Dy_, xd0 = i0d < 0 ? 0 : (i0d > Dx_ ? Dx_ : i0d);
+    const int ybaseB = ((((o0d - yd0) * Hy_ + o0h) * Wy_ + o0w) * a.Cy) * (int)sizeof(T);   // brick origin relative to plane yd0 of sample b
+    const int xbaseB = ((((i0d - xd0) * Hx_ + i0h) * Wx_ + i0w) * a.Cx) * (int)sizeof(T);
+    const size_t yleft = (size_t)(Dy_ - yd0) * yplane * sizeof(T), xleft = (size_t)(Dx_ - xd0) * xplane * sizeof(T);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(yg + ((size_t)b * Dy_ + yd0) * yplane), 0,
+                                                                        (int)(yleft < 0x7fffff00ull ? yleft : 0x7fffff00ull), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xg + ((size_t)b * Dx_ + xd0) * xplane), 0,
+                                                                        (int)(xleft < 0x7fffff00ull ? xleft : 0x7fffff00ull), 0x00020000);
+    // interior brick of a dense tensor (wave-uniform): every row in range, the row offsets are used as they are
+    const bool interior = !masked && i0d >= 0 && i0h >= 0 && i0w >= 0 && i0d + (ED - 1) * GS_ < Dx_ &&
+                          i0h + (EH - 1) * GS_ < Hx_ && i0w + (EW - 1) * GS_ < Wx_ && o0d + (BD - 1) * OS_ < Dy_ && o0h + (BH - 1) * OS_ < Hy_ &&
+                          o0w + (BW - 1) * OS_ < Wy_;
+    unsigned yo[NITY], xo[NITX];
+#pragma unroll
+    for (int it = 0; it < NITY; ++it) yo[it] = yoffB[it];
+#pragma unroll
+    for (int it = 0; it < NITX; ++it) xo[it] = xoffB[it];
+    if (!interior) {
+      if (!masked) {                                     // border brick of a dense tensor: range tests only, branch-free
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
+          if (!(od < Dy_ && oh < Hy_ && ow < Wy_)) yo[it] = OOB;
+        }
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
+          if (!((unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_)) xo[it] = OOB;
+        }
+      } else if (a.mask_n) {                             // block-sparse operands, the sample's patch masks cached in LDS
+        // (a global lookup per row puts two dependent memory round trips -- dY rows, then X rows -- in front of the brick's
+        // loads, and one in front of every skipped brick: the sparse levels ran at 6 us per brick for 0.6 us of MFMAs)
+        uint8_t* ldsMy = lds + a.mask_off;
+        uint8_t* ldsMx = ldsMy + a.mask_n;
+        if (b != mask_b) {                               // (uniform) first brick of a sample
+          __syncthreads();
+          for (int i = tid; i < a.mask_n; i += 256) {
+            ldsMy[i] = a.y_mask.m ? a.y_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
+            ldsMx[i] = a.x_mask.m ? a.x_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
+          }
+          __syncthreads();
+          mask_b = b;
+        }
+        const int ybs = a.y_mask.bs, xbs = a.x_mask.bs, mfh = a.y_mask.fh, mfw = a.y_mask.fw;
+        // The lookups are UNCONDITIONAL LDS reads (index 0 for rows out of range), all issued before the first one is used: the
+        // branchy per-row form cost one LDS round trip + ~30 instructions per row, 11 rows per brick -- three quarters of the
+        // block-sparse launches' time went into deciding what to load (profiles/r03_experiments.md).
+        if (a.y_uni) {
+          // (uniform) the dY brick lies inside ONE patch of a grid of whole bricks: one lookup decides, no vote, no row tests
+          const int alive = ldsMy[((o0d >> ybs) * mfh + (o0h >> ybs)) * mfw + (o0w >> ybs)];
+          if (!__builtin_amdgcn_readfirstlane(alive)) continue;
+        } else if (a.y_mask.m) {
+          uint8_t my[NITY];
+#pragma unroll
+          for (int it = 0; it < NITY; ++it) {
+            const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
+            const bool inr = yo[it] != OOB && od < Dy_ && oh < Hy_ && ow < Wy_;
+            my[it] = ldsMy[inr ? ((od >> ybs) * mfh + (oh >> ybs)) * mfw + (ow >> ybs) : 0];
+            if (!inr) yo[it] = OOB;
+          }
+          unsigned yany = 0;
+#pragma unroll
+          for (int it = 0; it < NITY; ++it) {
+            if (my[it] == 0) yo[it] = OOB;
+            yany |= yo[it] != OOB ? 1u : 0u;
+          }
+          if (!__syncthreads_or(yany != 0)) continue;    // nothing active in this brick (block-sparse dY)
+        } else {
+#pragma unroll
+          for (int it = 0; it < NITY; ++it) {
+            const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
+            if (!(od < Dy_ && oh < Hy_ && ow < Wy_)) yo[it] = OOB;
+          }
+        }
+        uint8_t mx[NITX];
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
+          const bool inr = xo[it] != OOB && (unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_;
+          mx[it] = ldsMx[inr ? ((id >> xbs) * mfh + (ih >> xbs)) * mfw + (iw >> xbs) : 0];
+          if (!inr) xo[it] = OOB;
+        }
+#pragma unroll
+        for (int it = 0; it < NITX; ++it)
+          if (mx[it] == 0) xo[it] = OOB;
+      } else {                                           // (masks too large for LDS: global patch-mask lookups per row)
+        unsigned yany = 0;
+#pragma unroll
+        for (int it = 0; it < NITY; ++it) {
+          const int od = o0d + (yq[it] & 255) * OS_, oh = o0h + ((yq[it] >> 8) & 255) * OS_, ow = o0w + (yq[it] >> 16) * OS_;
+          const bool ok = yo[it] != OOB && od < Dy_ && oh < Hy_ && ow < Wy_ && a.y_mask.active(b, od, oh, ow);
+          if (!ok) yo[it] = OOB;
+          yany |= ok ? 1u : 0u;
+        }
+        if (a.y_mask.m && !__syncthreads_or(yany != 0)) continue;    // nothing active in this brick (block-sparse dY)
+#pragma unroll
+        for (int it = 0; it < NITX; ++it) {
+          const int id = i0d + (xq[it] & 255) * GS_, ih = i0h + ((xq[it] >> 8) & 255) * GS_, iw = i0w + (xq[it] >> 16) * GS_;
+          const bool ok = xo[it] != OOB && (unsigned)id < (unsigned)Dx_ && (unsigned)ih < (unsigned)Hx_ && (unsigned)iw < (unsigned)Wx_ &&
+                          a.x_mask.active(b, id, ih, iw);
+          if (!ok) xo[it] = OOB;
+        }
+      }
+    }
+    // buffer loads: per-lane 32-bit byte offset (row offset + the brick's scalar origin, which may be negative for halo rows that
+    // are then OOB-marked); hardware zero-fill for OOB rows
+    if constexpr (PF) {
+      if (have) { stage_to_lds(); }                      // the previous live brick's rows have landed: registers -> LDS
+    }
+#pragma unroll
+    for (int it = 0; it < NITY; ++it)
+      ys[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (yo[it] == OOB || AM_DBG(a, 4)) ? OOB : yo[it] + (unsigned)ybaseB, 0, 0));
+#pragma unroll
+    for (int it = 0; it < NITX; ++it)
+      xs[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo[it] == OOB || AM_DBG(a, 4)) ? OOB : xo[it] + (unsigned)xbaseB, 0, 0));
+    if constexpr (PF) {
+      if (have) contract();                              // ... and this brick's loads fly while the previous one is contracted
+      have = true;
+    } else {
+      stage_to_lds();
+      contract();
+    }
+  }
+  }
+  if constexpr (PF) {
+    if (have) { stage_to_lds(); contract(); }
   }
 
   // ---- flush: D row = cy 4g+r, col = cx r16 ----
@@ -454,13 +500,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(WgArgs a, int ntap
 // two rounds costs a third round with the chip empty (measured: 1026 workgroups 2.24 ms, 1008 workgroups 1.77 ms).
 constexpr int AM_WG_ROUNDS = 2;
 
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false>
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false, bool PF = false>
 int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipStream_t st) {
-  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX, S2>;
+  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX, S2, PF>;
   constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
   constexpr int CT = 16 * MI, KT = 16 * NWX;
   size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
   a.mask_off = 0; a.mask_n = 0;
+  {
+    const int pq = 1 << a.y_mask.bs;                 // patch edge in dY voxels
+    a.y_uni = a.y_mask.m && a.OS == 1 && pq % BD == 0 && pq % BH == 0 && pq % BW == 0 && a.Dy % BD == 0 && a.Hy % BH == 0 && a.Wy % BW == 0;
+  }
   if (a.x_mask.m || a.y_mask.m) {                 // one sample's patch masks ride along in LDS when they are small (8^3 .. 12^3 patches)
     const MaskView& mv = a.y_mask.m ? a.y_mask : a.x_mask;
     const int n = mv.fd * mv.fh * mv.fw;
@@ -582,7 +632,10 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   // q-brick per staging round: bf16 (k-steps of 32 voxels) 2x4x16 / 2x8x8 = 128 voxels, ~55 KB of LDS so two workgroups
   // share a CU and overlap each other's staging;  f32 (k-steps of 4): 2x8x8.
   int bd = 2, bh = 8, bw = 8;
-  if (bf && Qw >= 16) { bh = 4; bw = 16; }
+  // block-sparse dY with patches 8 voxels wide: the 8x8 brick lies inside ONE patch (60 % of the bricks are skipped on one lookup; a
+  // 16-wide brick spans two patches, is empty only 36 % of the time and needs a mask test per row)
+  const bool patch8 = y_mask && (1 << y_bshift) == 8 && Hy % 8 == 0 && Wy % 8 == 0 && Dy % 2 == 0;
+  if (bf && Qw >= 16 && !(patch8 && Cx > 32 && Cy > 32)) { bh = 4; bw = 16; }
   // dense k3 s1 with 64-wide tiles: one-plane 1x8x16 bricks -- the X brick of a tap group has no d-halo at all (10x18 voxels
   // for 8x16: 1.41x, against 1.69x for 2x4x16) and the d-fastest walk re-reads each plane from L2
   bool plane_brick = bf && Qw >= 16 && Qh >= 8 && mode == AM_CONV_FWD && k == 3 && stride == 1 && !x_mask && !y_mask && (Cx > 32 || Cy > 32);
@@ -590,7 +643,7 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   { const char* e_ = getenv("AM_WG_PLANE"); if (e_ && !atoi(e_)) plane_brick = false; }
 #endif
   if (plane_brick) { bd = 1; bh = 8; bw = 16; }
-  if (s2full) { bd = 1; bh = 4; bw = 16; }
+  if (s2full) { bd = 1; bh = 4; bw = 16; if (patch8) { bh = 8; bw = 8; } }
   // 32-channel operands: 32-wide tiles (MI = 2 cy tiles / NWX = 2 cx waves, the other waves split the voxels)
   int mi = 4, nwx = 4;
   if (s2full) nwx = 2;                                    // 32-channel X tiles: the 9 x 33 full-resolution rows stay at 96 bytes
@@ -651,12 +704,13 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     const int tiles = ((Cy + 16 * mi - 1) / (16 * mi)) * ((Cx + 16 * nwx - 1) / (16 * nwx)) * a.ngroup;
     int rc = -2;
 #define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, tiles, nbrick, det_slots, st)
-    if (s2full) rc = launch<bf16_t, 1, 4, 16, 9, 5, 4, 2, true>(a, maxvox, tiles, nbrick, det_slots, st);
+    if (s2full) rc = bw == 8 ? launch<bf16_t, 1, 8, 8, 9, 5, 4, 2, true, true>(a, maxvox, tiles, nbrick, det_slots, st)
+                             : launch<bf16_t, 1, 4, 16, 9, 5, 4, 2, true, true>(a, maxvox, tiles, nbrick, det_slots, st);
     else if (bf && bd == 1 && ntap == 9 && (mi == 2 || nwx == 2)) {
       if (mi == 2) rc = launch<bf16_t, 1, 8, 16, 9, 6, 2, 4>(a, maxvox, tiles, nbrick, det_slots, st);
       else rc = launch<bf16_t, 1, 8, 16, 9, 3, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
     } else if (bf && bw == 16 && (mi == 2 || nwx == 2)) {
-      if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+      if (ntap == 9 && mi == 2 && nwx == 2) rc = launch<bf16_t, 4, 4, 16, 9, 7, 2, 2, false, true>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 9 && mi == 2) rc = launch<bf16_t, 2, 4, 16, 9, 7, 2, 4>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 9) rc = launch<bf16_t, 2, 4, 16, 9, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 8) rc = launch<bf16_t, 2, 4, 16, 8, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);

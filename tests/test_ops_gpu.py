@@ -119,6 +119,39 @@ def test_conv_wgrad_narrow_channels_wide_grid(ops, case, sparse):
     close(dw.cpu(), w.grad, TOL[dtype], "conv wgrad (narrow channels)")
 
 
+@pytest.mark.parametrize("case", [(64, 64, 3, 1, 3, (2, 2, 2)), (32, 32, 3, 1, 4, (1, 1, 2)), (64, 64, 3, 1, 2, (2, 4, 8)), (64, 96, 3, 1, 1, (4, 8, 8)),
+                                  (32, 64, 3, 2, 3, (1, 2, 2)), (64, 128, 3, 2, 2, (2, 4, 4)), (128, 64, 3, 2, 1, (4, 4, 8)), (64, 64, 1, 2, 3, (1, 2, 2))])
+@pytest.mark.parametrize("det", [False, True])
+def test_conv_wgrad_block_sparse_ignores_inactive_voxels(ops, case, det):
+    """Block-sparse weight gradients at the patch widths of the encoder levels (dY patches 16 / 8 / 4 / 2 voxels wide): bricks inside
+    one patch are kept or skipped on ONE mask lookup (8-wide patches take 8x8 bricks for that), bricks that span patches test every
+    staged row.  The inactive voxels of X and dY hold NaN here: nothing may be read from them."""
+    cin, cout, k, s, bs_out, f = case
+    dtype = torch.bfloat16
+    B = 2
+    so = tuple(v << bs_out for v in f)
+    si = tuple(v * s for v in so)
+    bs_in = bs_out + (1 if s == 2 else 0)
+    mask = mk_mask(B, f, max(1, (f[0] * f[1] * f[2] * 2) // 5), seed=41)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    mx, my = O.upsample_mask(mask, si).float(), O.upsample_mask(mask, so).float()
+    x = q(rnd(B, cin, *si, seed=42), dtype) * mx
+    dy = q(rnd(B, cout, *so, seed=43), dtype) * my
+    w = torch.zeros(cout, cin, k, k, k, requires_grad=True)
+    F.conv3d(x, w, None, stride=s, padding=k // 2).backward(dy)
+    xd, dyd = to_cl(x, dtype), to_cl(dy, dtype)
+    xd = torch.where(to_cl(mx.expand_as(x), dtype) > 0, xd, torch.full_like(xd, float("nan")))
+    dyd = torch.where(to_cl(my.expand_as(dy), dtype) > 0, dyd, torch.full_like(dyd, float("nan")))
+    ops.DETERMINISTIC_WGRAD = det
+    try:
+        dwp = ops.conv3d_wgrad(ops.CONV_FWD, xd, dyd, k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out)
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
+    dw = torch.zeros(cout, cin, k, k, k, device=DEV)
+    ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+    close(dw.cpu(), w.grad, TOL[dtype], "block-sparse conv wgrad, NaN in the inactive voxels")
+
+
 @pytest.mark.parametrize("case", [(64, 64, (5, 20, 40), 3), (96, 64, (9, 8, 16), 1), (64, 32, (7, 12, 24), 2), (40, 72, (33, 9, 17), 1), (96, 96, (4, 8, 32), 2), (128, 96, (3, 16, 16), 1)])
 @pytest.mark.parametrize("det", [False, True])
 def test_conv_wgrad_plane_bricks_ragged(ops, case, det):
