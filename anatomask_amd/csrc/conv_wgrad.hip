@@ -273,6 +273,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     if (!AM_DBG(a, 32)) __builtin_amdgcn_s_setprio(0);
   };
   int mask_b = -1;                                       // sample whose patch masks sit in LDS
+  uint8_t* const ldsMy = lds + a.mask_off;               // (mask_n != 0 only)
+  uint8_t* const ldsMx = ldsMy + a.mask_n;
+  auto load_masks = [&]() {
+    __syncthreads();
+    for (int i = tid; i < a.mask_n; i += 256) {
+      ldsMy[i] = a.y_mask.m ? a.y_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
+      ldsMx[i] = a.x_mask.m ? a.x_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
+    }
+    __syncthreads();
+    mask_b = b;
+  };
   const int u_end = a.walk ? nu : (slot >> 3) + 1, u_inc = a.walk ? S8 : u_end;     // walk 0: exactly one pass (u_inc >= 1 always)
   for (int u = slot >> 3; u < u_end; u += u_inc) {
   int nstep = brick1 - brick0;
@@ -286,6 +297,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     if (a.walk) ++bd_;
     else if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
+    if (a.y_uni && a.mask_n) {
+      // (uniform) block-sparse dY whose brick lies inside ONE patch of a grid of whole bricks: one lookup keeps or skips the brick,
+      // before anything else is computed for it (60 % of the visits end here)
+      if (b != mask_b) load_masks();
+      const int alive = ldsMy[(((q0d + pd) >> a.y_mask.bs) * a.y_mask.fh + ((q0h + ph) >> a.y_mask.bs)) * a.y_mask.fw + ((q0w + pw) >> a.y_mask.bs)];
+      if (!__builtin_amdgcn_readfirstlane(alive)) continue;
+    }
     // X brick origin in global voxels: sub-lattice index (q0 + min shift) * GS + parity of the unit
     const int i0d = q0d * a.QS + a.mind[grp] * GS_ + upd, i0h = q0h * a.QS + a.minh[grp] * GS_ + uph, i0w = q0w * a.QS + a.minw[grp] * GS_ + upw;
     const int o0d = q0d * OS_ + pd, o0h = q0h * OS_ + ph, o0w = q0w * OS_ + pw;
@@ -322,25 +340,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       } else if (a.mask_n) {                             // block-sparse operands, the sample's patch masks cached in LDS
         // (a global lookup per row puts two dependent memory round trips -- dY rows, then X rows -- in front of the brick's
         // loads, and one in front of every skipped brick: the sparse levels ran at 6 us per brick for 0.6 us of MFMAs)
-        uint8_t* ldsMy = lds + a.mask_off;
-        uint8_t* ldsMx = ldsMy + a.mask_n;
-        if (b != mask_b) {                               // (uniform) first brick of a sample
-          __syncthreads();
-          for (int i = tid; i < a.mask_n; i += 256) {
-            ldsMy[i] = a.y_mask.m ? a.y_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
-            ldsMx[i] = a.x_mask.m ? a.x_mask.m[(size_t)b * a.mask_n + i] : (uint8_t)1;
-          }
-          __syncthreads();
-          mask_b = b;
-        }
+        if (b != mask_b) load_masks();                   // (uniform) first brick of a sample
         const int ybs = a.y_mask.bs, xbs = a.x_mask.bs, mfh = a.y_mask.fh, mfw = a.y_mask.fw;
         // The lookups are UNCONDITIONAL LDS reads (index 0 for rows out of range), all issued before the first one is used: the
         // branchy per-row form cost one LDS round trip + ~30 instructions per row, 11 rows per brick -- three quarters of the
         // block-sparse launches' time went into deciding what to load (profiles/r03_experiments.md).
         if (a.y_uni) {
-          // (uniform) the dY brick lies inside ONE patch of a grid of whole bricks: one lookup decides, no vote, no row tests
-          const int alive = ldsMy[((o0d >> ybs) * mfh + (o0h >> ybs)) * mfw + (o0w >> ybs)];
-          if (!__builtin_amdgcn_readfirstlane(alive)) continue;
+          // (decided at the top of the step: one lookup per brick, no vote, no row tests)
         } else if (a.y_mask.m) {
           uint8_t my[NITY];
 #pragma unroll

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void voxel_norm_bwd_kernel(const T* __restrict
 // ---- pooling: thread = (active output voxel, channel chunk)
 template <typename T, int OP>   // OP 0 = max (ties: first in (d, h, w) scan order, as torch), 1 = average
 __global__ __launch_bounds__(256) void pool3d_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int* __restrict__ idx, VoxGeo go, int Di,
-                                                         int Hi, int Wi, int k, int st, int pad, int count_include_pad, MaskView min) {
+                                                         int Hi, int Wi, int k, int st, int pad, int dil, int count_include_pad, MaskView min) {
   constexpr int EPC = TT<T>::EPC;
   const int CPV = go.C / EPC;
   const long n = go.nvox * CPV;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void pool3d_fwd_kernel(const T* __restrict__ x
     for (int j = 0; j < EPC; ++j) { acc[j] = OP == 0 ? -INFINITY : 0.f; am[j] = -1; }
     int cnt = 0;
     for (int td = 0; td < k; ++td) for (int th = 0; th < k; ++th) for (int tw = 0; tw < k; ++tw) {
-      const int id = od * st - pad + td, ih = oh * st - pad + th, iw = ow * st - pad + tw;
+      const int id = od * st - pad + td * dil, ih = oh * st - pad + th * dil, iw = ow * st - pad + tw * dil;
       if ((unsigned)id >= (unsigned)Di || (unsigned)ih >= (unsigned)Hi || (unsigned)iw >= (unsigned)Wi) continue;
       ++cnt;
       float f[EPC];
@@ -260,7 +260,9 @@ __global__ __launch_bounds__(256) void pool3d_fwd_kernel(const T* __restrict__ x
       }
     }
     if (OP == 1) {
-      const float div = count_include_pad ? (float)(k * k * k) : (float)cnt;
+      // count_include_pad: the window clipped to the PADDED extent (torch: a ceil_mode window may hang over the padding's end)
+      auto ext = [&](int o, int n_) { const int a = o * st - pad, hi_ = a + k > n_ + pad ? n_ + pad : a + k; return hi_ - a; };
+      const float div = count_include_pad ? (float)(ext(od, Di) * ext(oh, Hi) * ext(ow, Wi)) : (float)cnt;
 #pragma unroll
       for (int j = 0; j < EPC; ++j) acc[j] /= div;
     }
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(256) void pool3d_fwd_kernel(const T* __restrict__ x
 // gather form of the pooling backward (no atomics): thread = (active input voxel, chunk), loops over the windows that cover it
 template <typename T, int OP>
 __global__ __launch_bounds__(256) void pool3d_bwd_kernel(const T* __restrict__ dy, const int* __restrict__ idx, T* __restrict__ dx, VoxGeo gi,
-                                                         int Do, int Ho, int Wo, int k, int st, int pad, int count_include_pad, MaskView mout) {
+                                                         int Do, int Ho, int Wo, int k, int st, int pad, int dil, int count_include_pad, MaskView mout) {
   constexpr int EPC = TT<T>::EPC;
   const int CPV = gi.C / EPC;
   const long n = gi.nvox * CPV;
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(256) void pool3d_bwd_kernel(const T* __restrict__ d
     float acc[EPC];
 #pragma unroll
     for (int j = 0; j < EPC; ++j) acc[j] = 0.f;
-    auto lo = [&](int p) { const int a = p + pad - k + 1; return a <= 0 ? 0 : (a + st - 1) / st; };
+    // (dilated max windows: a superset of the windows that hold the voxel -- the argmax comparison picks the real ones)
+    auto lo = [&](int p) { const int a = p + pad - (k - 1) * dil; return a <= 0 ? 0 : (a + st - 1) / st; };
     auto hi = [&](int p, int n_) { const int a = (p + pad) / st; return a < n_ - 1 ? a : n_ - 1; };
     for (int od = lo(d); od <= hi(d, Do); ++od) for (int oh = lo(h); oh <= hi(h, Ho); ++oh) for (int ow = lo(w); ow <= hi(w, Wo); ++ow) {
       if (!mout.active(b, od, oh, ow)) continue;
@@ -298,9 +301,12 @@ __global__ __launch_bounds__(256) void pool3d_bwd_kernel(const T* __restrict__ d
 #pragma unroll
         for (int j = 0; j < EPC; ++j) if (idx[vo * gi.C + c * EPC + j] == li) acc[j] += gy[j];
       } else {
-        float div = (float)(k * k * k);
+        float div;
         if (!count_include_pad) {
           auto ext = [&](int o, int n_) { const int a = o * st - pad, lo_ = a < 0 ? 0 : a, hi_ = a + k > n_ ? n_ : a + k; return hi_ - lo_; };
+          div = (float)(ext(od, gi.D) * ext(oh, gi.H) * ext(ow, gi.W));
+        } else {
+          auto ext = [&](int o, int n_) { const int a = o * st - pad, hi_ = a + k > n_ + pad ? n_ + pad : a + k; return hi_ - a; };
           div = (float)(ext(od, gi.D) * ext(oh, gi.H) * ext(ow, gi.W));
         }
 #pragma unroll
@@ -818,12 +824,25 @@ int am_voxel_norm_bwd(int dtype, int kind, const void* x, const void* dy, void* 
   return 0;
 }
 
+// output extent of a torch pooling layer (floor, or ceil_mode: the last window must start inside the input or its left padding)
+static int pool_out(int n, int k, int s, int p, int dil, int ceil_mode) {
+  const int num = n + 2 * p - dil * (k - 1) - 1;
+  if (num < 0) return 0;
+  int o = (ceil_mode ? (num + s - 1) / s : num / s) + 1;
+  if (ceil_mode && (o - 1) * s >= n + p) --o;
+  return o;
+}
+
 int am_pool3d_fwd(int dtype, int op, const void* x, void* y, int32_t* argmax, int B, int Di, int Hi, int Wi, int C, int ksize, int stride,
-                  int pad, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift, int fd, int fh,
-                  int fw, const int32_t* active_list, int n_active, void* stream) {
+                  int pad, int dilation, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift,
+                  int fd, int fh, int fw, const int32_t* active_list, int n_active, void* stream) {
   CHK_C(C);
-  if ((op != 0 && op != 1) || ksize < 1 || ksize > 7 || stride < 1 || pad < 0 || 2 * pad > ksize) return -2;
-  if (Do != (Di + 2 * pad - ksize) / stride + 1 || Ho != (Hi + 2 * pad - ksize) / stride + 1 || Wo != (Wi + 2 * pad - ksize) / stride + 1) return -2;
+  if ((op != 0 && op != 1) || ksize < 1 || ksize > 7 || stride < 1 || pad < 0 || 2 * pad > ksize || dilation < 1 || (op == 1 && dilation != 1)) return -2;
+  {                                                        // (Do, Ho, Wo) = torch's floor OR ceil_mode extents, all three by the same rule
+    bool okf = Do == pool_out(Di, ksize, stride, pad, dilation, 0) && Ho == pool_out(Hi, ksize, stride, pad, dilation, 0) && Wo == pool_out(Wi, ksize, stride, pad, dilation, 0);
+    bool okc = Do == pool_out(Di, ksize, stride, pad, dilation, 1) && Ho == pool_out(Hi, ksize, stride, pad, dilation, 1) && Wo == pool_out(Wi, ksize, stride, pad, dilation, 1);
+    if (!okf && !okc) return -2;
+  }
   if (!list_ok(mask, active_list, n_active)) return -2;
   const VoxGeo go = mkvox(B, Do, Ho, Wo, C, mask ? active_list : nullptr, n_active, out_bshift);
   if (go.nvox == 0) return 0;
@@ -832,20 +851,20 @@ int am_pool3d_fwd(int dtype, int op, const void* x, void* y, int32_t* argmax, in
   const int nb = nblocks(go.nvox * (C / epc));
   hipStream_t st = (hipStream_t)stream;
   if (op == 0)
-    DISPATCH_T(dtype, AM_LAUNCH((pool3d_fwd_kernel<float, 0>), dim3(nb), dim3(256), 0, st, (const float*)x, (float*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, count_include_pad, mi),
-               AM_LAUNCH((pool3d_fwd_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, count_include_pad, mi));
+    DISPATCH_T(dtype, AM_LAUNCH((pool3d_fwd_kernel<float, 0>), dim3(nb), dim3(256), 0, st, (const float*)x, (float*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, dilation, count_include_pad, mi),
+               AM_LAUNCH((pool3d_fwd_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, dilation, count_include_pad, mi));
   else
-    DISPATCH_T(dtype, AM_LAUNCH((pool3d_fwd_kernel<float, 1>), dim3(nb), dim3(256), 0, st, (const float*)x, (float*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, count_include_pad, mi),
-               AM_LAUNCH((pool3d_fwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, count_include_pad, mi));
+    DISPATCH_T(dtype, AM_LAUNCH((pool3d_fwd_kernel<float, 1>), dim3(nb), dim3(256), 0, st, (const float*)x, (float*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, dilation, count_include_pad, mi),
+               AM_LAUNCH((pool3d_fwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, argmax, go, Di, Hi, Wi, ksize, stride, pad, dilation, count_include_pad, mi));
   AM_CHECK_LAUNCH();
   return 0;
 }
 
 int am_pool3d_bwd(int dtype, int op, const void* dy, const int32_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int C, int ksize,
-                  int stride, int pad, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift,
-                  int fd, int fh, int fw, const int32_t* active_list, int n_active, void* stream) {
+                  int stride, int pad, int dilation, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift,
+                  int out_bshift, int fd, int fh, int fw, const int32_t* active_list, int n_active, void* stream) {
   CHK_C(C);
-  if ((op != 0 && op != 1) || (op == 0 && !argmax) || ksize < 1 || ksize > 7 || stride < 1) return -2;
+  if ((op != 0 && op != 1) || (op == 0 && !argmax) || ksize < 1 || ksize > 7 || stride < 1 || dilation < 1 || (op == 1 && dilation != 1)) return -2;
   if (!list_ok(mask, active_list, n_active)) return -2;
   const VoxGeo gi = mkvox(B, Di, Hi, Wi, C, mask ? active_list : nullptr, n_active, in_bshift);
   if (gi.nvox == 0) return 0;
@@ -854,11 +873,11 @@ int am_pool3d_bwd(int dtype, int op, const void* dy, const int32_t* argmax, void
   const int nb = nblocks(gi.nvox * (C / epc));
   hipStream_t st = (hipStream_t)stream;
   if (op == 0)
-    DISPATCH_T(dtype, AM_LAUNCH((pool3d_bwd_kernel<float, 0>), dim3(nb), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, gi, Do, Ho, Wo, ksize, stride, pad, count_include_pad, mo),
-               AM_LAUNCH((pool3d_bwd_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, gi, Do, Ho, Wo, ksize, stride, pad, count_include_pad, mo));
+    DISPATCH_T(dtype, AM_LAUNCH((pool3d_bwd_kernel<float, 0>), dim3(nb), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, gi, Do, Ho, Wo, ksize, stride, pad, dilation, count_include_pad, mo),
+               AM_LAUNCH((pool3d_bwd_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, gi, Do, Ho, Wo, ksize, stride, pad, dilation, count_include_pad, mo));
   else
-    DISPATCH_T(dtype, AM_LAUNCH((pool3d_bwd_kernel<float, 1>), dim3(nb), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, gi, Do, Ho, Wo, ksize, stride, pad, count_include_pad, mo),
-               AM_LAUNCH((pool3d_bwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, gi, Do, Ho, Wo, ksize, stride, pad, count_include_pad, mo));
+    DISPATCH_T(dtype, AM_LAUNCH((pool3d_bwd_kernel<float, 1>), dim3(nb), dim3(256), 0, st, (const float*)dy, argmax, (float*)dx, gi, Do, Ho, Wo, ksize, stride, pad, dilation, count_include_pad, mo),
+               AM_LAUNCH((pool3d_bwd_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dy, argmax, (bf16_t*)dx, gi, Do, Ho, Wo, ksize, stride, pad, dilation, count_include_pad, mo));
   AM_CHECK_LAUNCH();
   return 0;
 }

@@ -167,31 +167,40 @@ class SparseGRN(nn.Module):
 # ------------------------------------------------------------------ pooling
 class _PoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_cl, op, k, s, p, cip):
+    def forward(ctx, x_cl, op, k, s, p, cip, dil=1, ceil_mode=False):
         mi = current_mask(x_cl.device)
         B, Di, Hi, Wi, C = x_cl.shape
-        Do, Ho, Wo = ((Di + 2 * p - k) // s + 1, (Hi + 2 * p - k) // s + 1, (Wi + 2 * p - k) // s + 1)
+        Do, Ho, Wo = (_pool_out(n, k, s, p, dil, ceil_mode) for n in (Di, Hi, Wi))
         bi, bo = _bshift(mi, Di), _bshift(mi, Do)
         _check_list(mi)
         y = torch.zeros(B, Do, Ho, Wo, C, device=x_cl.device, dtype=x_cl.dtype)
         idx = torch.empty(B, Do, Ho, Wo, C, device=x_cl.device, dtype=torch.int32) if op == 0 else None
         mp, fd, fh, fw = ops._mk(mi)
-        _lib().pool3d_fwd(ops._dt(x_cl), op, x_cl.data_ptr(), y.data_ptr(), ops._p(idx), B, Di, Hi, Wi, C, k, s, p, int(cip), Do, Ho, Wo,
+        _lib().pool3d_fwd(ops._dt(x_cl), op, x_cl.data_ptr(), y.data_ptr(), ops._p(idx), B, Di, Hi, Wi, C, k, s, p, dil, int(cip), Do, Ho, Wo,
                           mp, bi, bo, fd, fh, fw, *_al(mi), _s())
         ctx.save_for_backward(idx if idx is not None else torch.empty(0))
-        ctx.cfg = (mi, op, k, s, p, cip, (B, Di, Hi, Wi, C), (Do, Ho, Wo), bi, bo, x_cl.dtype)
+        ctx.cfg = (mi, op, k, s, p, dil, cip, (B, Di, Hi, Wi, C), (Do, Ho, Wo), bi, bo, x_cl.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
-        mi, op, k, s, p, cip, (B, Di, Hi, Wi, C), (Do, Ho, Wo), bi, bo, dt = ctx.cfg
+        mi, op, k, s, p, dil, cip, (B, Di, Hi, Wi, C), (Do, Ho, Wo), bi, bo, dt = ctx.cfg
         dy = dy.contiguous()
         dx = torch.zeros(B, Di, Hi, Wi, C, device=dy.device, dtype=dt)
         mp, fd, fh, fw = ops._mk(mi)
-        _lib().pool3d_bwd(ops._dt(dx), op, dy.data_ptr(), idx.data_ptr() if op == 0 else None, dx.data_ptr(), B, Di, Hi, Wi, C, k, s, p, int(cip),
+        _lib().pool3d_bwd(ops._dt(dx), op, dy.data_ptr(), idx.data_ptr() if op == 0 else None, dx.data_ptr(), B, Di, Hi, Wi, C, k, s, p, dil, int(cip),
                           Do, Ho, Wo, mp, bi, bo, fd, fh, fw, *_al(mi), _s())
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None, None
+
+
+def _pool_out(n, k, s, p, dil, ceil_mode):
+    """Output extent of torch's pooling layers (ceil_mode: the last window must start inside the input or its left padding)."""
+    num = n + 2 * p - dil * (k - 1) - 1
+    o = (-(-num // s) if ceil_mode else num // s) + 1
+    if ceil_mode and (o - 1) * s >= n + p:
+        o -= 1
+    return o
 
 
 def _one(v):
@@ -205,20 +214,22 @@ class SparseMaxPooling(nn.MaxPool3d):
     """encoder3D.py:31-32 (sp_conv_forward :12-15): MaxPool3d, then the output is masked."""
 
     def forward(self, x):
-        if self.ceil_mode or _one(self.dilation) != 1 or self.return_indices:
-            raise NotImplementedError("SparseMaxPooling: ceil_mode / dilation / return_indices are not supported")
+        if self.return_indices:
+            raise NotImplementedError("SparseMaxPooling: return_indices is not supported (sp_conv_forward could not mask a tuple either)")
         k = _one(self.kernel_size)
-        return _nc(_PoolFn.apply(_cl(x), 0, k, _one(self.stride if self.stride is not None else k), _one(self.padding), True))
+        return _nc(_PoolFn.apply(_cl(x), 0, k, _one(self.stride if self.stride is not None else k), _one(self.padding), True, _one(self.dilation),
+                                 bool(self.ceil_mode)))
 
 
 class SparseAvgPooling(nn.AvgPool3d):
     """encoder3D.py:35-36."""
 
     def forward(self, x):
-        if self.ceil_mode or self.divisor_override is not None:
-            raise NotImplementedError("SparseAvgPooling: ceil_mode / divisor_override are not supported")
+        if self.divisor_override is not None:
+            raise NotImplementedError("SparseAvgPooling: divisor_override is not supported")
         k = _one(self.kernel_size)
-        return _nc(_PoolFn.apply(_cl(x), 1, k, _one(self.stride if self.stride is not None else k), _one(self.padding), self.count_include_pad))
+        return _nc(_PoolFn.apply(_cl(x), 1, k, _one(self.stride if self.stride is not None else k), _one(self.padding), self.count_include_pad, 1,
+                                 bool(self.ceil_mode)))
 
 
 class _AdaptiveAvgFn(torch.autograd.Function):
@@ -591,20 +602,41 @@ class _PointwiseLinear(nn.Linear):
         return _ConvFn.apply(x_cl, self.weight[:, :, None, None, None], self.bias, 1, 1)
 
 
+class DropPath(nn.Module):
+    """Stochastic depth per sample, as `timm.models.layers.DropPath` which encoder3D.py:4,253,275 uses (timm is a third-party package
+    that is not in /root/reference; this restates its published definition): in training a sample's residual branch is dropped with
+    probability `drop_prob` and the kept ones are scaled by 1 / (1 - drop_prob); identity in eval mode.  The draw comes from torch's
+    generator of the tensor's device (one value per sample), so a seeded run repeats."""
+
+    def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
+        super().__init__()
+        self.drop_prob, self.scale_by_keep = float(drop_prob), scale_by_keep
+
+    def forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        r = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            r.div_(keep)
+        return x * r
+
+    def extra_repr(self):
+        return f"drop_prob={round(self.drop_prob, 3):0.3f}"
+
+
 class SparseConvNeXtBlock(nn.Module):
-    """encoder3D.py:235-276.  drop_path > 0 is not supported (the reference's pretraining scripts build their backbones with 0)."""
+    """encoder3D.py:235-276."""
 
     def __init__(self, dim, drop_path=0., layer_scale_init_value=1e-6, sparse=True, ks=7):
         super().__init__()
-        if drop_path > 0.:
-            raise NotImplementedError("SparseConvNeXtBlock: drop_path > 0")
         self.dwconv = SparseConv3d(dim, dim, kernel_size=ks, padding=ks // 2, groups=dim)
         self.norm = SparseConvNeXtLayerNorm(dim, eps=1e-6, sparse=sparse)
         self.pwconv1 = _PointwiseLinear(dim, 4 * dim)
         self.act = nn.GELU()
         self.pwconv2 = _PointwiseLinear(4 * dim, dim)
         self.gamma = nn.Parameter(layer_scale_init_value * torch.ones((dim)), requires_grad=True) if layer_scale_init_value > 0 else None
-        self.drop_path = nn.Identity()
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
         self.sparse = sparse
 
     def forward(self, x):
@@ -617,7 +649,8 @@ class SparseConvNeXtBlock(nn.Module):
         h = self.pwconv1(h)
         h = _GeluFn.apply(h)
         h = self.pwconv2(h)
-        return _nc(_ScaleResidualFn.apply(h, inp, self.gamma))
+        # input + drop_path(gamma * h * mask): the per-sample factor commutes with the scale and the mask (encoder3D.py:266-275)
+        return _nc(_ScaleResidualFn.apply(self.drop_path(h), inp, self.gamma))
 
 
 # ------------------------------------------------------------------ converter

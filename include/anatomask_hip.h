@@ -258,17 +258,19 @@ int am_voxel_norm_bwd(int dtype, int kind, const void* x, const void* dy, void* 
                       const float* gamma, float eps, float* dgamma_accum, float* dbeta_accum, const uint8_t* mask, int bshift,
                       const int32_t* active_list, int n_active, void* stream);
 
-/* SparseMaxPooling / SparseAvgPooling (encoder3D.py:31-36): nn.MaxPool3d / nn.AvgPool3d (cubic kernel, dilation 1, no ceil_mode) of
- * the zero-filled tensor, output written at active output voxels.  op 0 = max (argmax: int32 [.. Do Ho Wo C] input voxel index inside
+/* SparseMaxPooling / SparseAvgPooling (encoder3D.py:31-36): nn.MaxPool3d / nn.AvgPool3d (cubic kernel; max: any dilation) of the
+ * zero-filled tensor, output written at active output voxels.  (Do, Ho, Wo) are torch's extents for ceil_mode False or True (the
+ * caller chooses; a ceil_mode window that hangs over the end sees only what exists, and an average with count_include_pad divides by
+ * the window clipped to the padded extent, as torch does).  op 0 = max (argmax: int32 [.. Do Ho Wo C] input voxel index inside
  * the sample, first maximum in scan order like torch; needed by the backward), 1 = average.  The mask is shared: in_bshift /
  * out_bshift are the block shifts at the input / output resolution.  bwd is a gather over the windows covering each active INPUT voxel
  * (no atomics). */
 int am_pool3d_fwd(int dtype, int op, const void* x, void* y, int32_t* argmax, int B, int Di, int Hi, int Wi, int C, int ksize, int stride,
-                  int pad, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift, int fd, int fh,
-                  int fw, const int32_t* active_list, int n_active, void* stream);
-int am_pool3d_bwd(int dtype, int op, const void* dy, const int32_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int C, int ksize,
-                  int stride, int pad, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift,
+                  int pad, int dilation, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift, int out_bshift,
                   int fd, int fh, int fw, const int32_t* active_list, int n_active, void* stream);
+int am_pool3d_bwd(int dtype, int op, const void* dy, const int32_t* argmax, void* dx, int B, int Di, int Hi, int Wi, int C, int ksize,
+                  int stride, int pad, int dilation, int count_include_pad, int Do, int Ho, int Wo, const uint8_t* mask, int in_bshift,
+                  int out_bshift, int fd, int fh, int fw, const int32_t* active_list, int n_active, void* stream);
 
 /* Depthwise convolution k in {3, 5, 7}, stride 1, padding k/2 (SparseConvNeXtBlock.dwconv encoder3D.py:247 under sp_conv_forward
  * :12-15; MedNeXt blocks): w fp32 [C][k^3] (torch (C,1,k,k,k)).  data_grad = 1: the data gradient (x = dy, taps mirrored, no bias).

@@ -87,6 +87,50 @@ def test_avg_pool_fixture(SL, name, k, s, p, cip):
     run_fixture(name, SL.SparseAvgPooling(k, s, p, count_include_pad=cip))
 
 
+@pytest.mark.parametrize("case", [("max", 3, 2, 1, 1, True, (9, 10, 11), None), ("max", 2, 2, 0, 2, False, (12, 9, 10), None), ("max", 3, 1, 1, 2, True, (7, 8, 9), None),
+                                  ("avg", 3, 2, 1, 1, True, (9, 10, 12), True), ("avg", 3, 2, 1, 1, True, (9, 10, 12), False), ("avg", 2, 2, 0, 1, True, (7, 9, 8), True),
+                                  ("max", 2, 2, 0, 1, True, (16, 16, 16), "mask"), ("max", 2, 2, 1, 2, False, (16, 16, 16), "mask"), ("avg", 2, 2, 0, 1, True, (16, 16, 16), "mask")])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pooling_ceil_mode_and_dilation(SL, case, dtype):
+    """nn.MaxPool3d / nn.AvgPool3d options the reference's sparse pooling classes inherit (encoder3D.py:31-36 are the torch layers with
+    sp_conv_forward :12-15 = torch forward, then the mask): ceil_mode (ragged extents: the last window hangs over the end), dilated
+    max windows, both count_include_pad settings; dense tensors and block-sparse ones (where the extents allow a mask at all)."""
+    op, k, s, p, dil, ceil, size, opt = case
+    masked = opt == "mask"
+    torch.manual_seed(5)
+    B, C = 2, 16
+    x = torch.randn(B, C, *size)
+    if dtype == torch.bfloat16:
+        x = x.bfloat16().float()
+    if masked:
+        active = torch.rand(B, 1, 4, 4, 4) < 0.5
+        active[0, 0, 0, 0, 0] = True
+        set_active(active)
+        x = x * up(active, size).float()
+    else:
+        from anatomask_amd import modules
+        modules._cur_active = None
+    if op == "max":
+        ref, mod = torch.nn.MaxPool3d(k, s, p, dilation=dil, ceil_mode=ceil), SL.SparseMaxPooling(k, s, p, dilation=dil, ceil_mode=ceil)
+    else:
+        cip = True if masked else opt
+        ref, mod = torch.nn.AvgPool3d(k, s, p, ceil_mode=ceil, count_include_pad=cip), SL.SparseAvgPooling(k, s, p, ceil_mode=ceil, count_include_pad=cip)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    mo = up(active, yr.shape[2:]).float() if masked else torch.ones(1)
+    yr = yr * mo
+    g = torch.randn_like(yr)
+    (yr * g).sum().backward()
+    xd = x.to(DEV, dtype).requires_grad_(True)
+    y = mod(xd)
+    assert y.shape == yr.shape, (y.shape, yr.shape)
+    (y * g.to(DEV, dtype)).sum().backward()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert ((y.detach().float().cpu() - yr.detach()) * mo).abs().max().item() <= tol * max(1.0, yr.abs().max().item())
+    mi_ = up(active, size).float() if masked else torch.ones(1)
+    assert ((xd.grad.float().cpu() - xr.grad) * mi_).abs().max().item() <= (1e-5 if dtype == torch.float32 else 3e-2) * max(1.0, xr.grad.abs().max().item())
+
+
 def test_batch_norm_fixture(SL):
     bn = load_params(SL.SparseBatchNorm3d(16), "bn_train")
     run_fixture("bn_train", bn)
@@ -126,6 +170,36 @@ def test_adaptive_avg_pool_fixture(SL):
 def test_sparse_conv_fixture(SL, name, args):
     cout = 24 if name == "conv3s2" else 16
     run_fixture(name, load_params(SL.SparseConv3d(16, cout, **args), name), tol=5e-5, gtol=2e-4)
+
+
+def test_convnext_block_drop_path(SL):
+    """drop_path > 0 (encoder3D.py:253,275: `input + self.drop_path(x)`, timm's per-sample stochastic depth): eval mode is the plain
+    block (the reference fixture); in training each sample's branch is y0 - x scaled by its own draw in {0, 1 / keep}, the draw repeats
+    under a seed, and the gradient of a dropped sample is the identity path alone."""
+    blk = load_params(SL.SparseConvNeXtBlock(16, drop_path=0.5, layer_scale_init_value=0.5, ks=7), "convnext")
+    assert isinstance(blk.drop_path, SL.DropPath)
+    run_fixture("convnext", blk, tol=5e-5, gtol=3e-4, train=False)                 # eval: DropPath is the identity
+    active = t("active"); set_active(active)
+    x = t("convnext.x").repeat(4, 1, 1, 1, 1).to(DEV)                             # 8 samples: both outcomes of the draw occur
+    set_active(active.repeat(4, 1, 1, 1, 1))
+    blk.eval()
+    with torch.no_grad():
+        y0 = blk(x)
+    blk.train()
+    torch.manual_seed(123)
+    r = torch.empty(8, 1, 1, 1, 1, device=DEV).bernoulli_(0.5) / 0.5               # what DropPath will draw
+    assert 0 < int((r == 0).sum()) < 8
+    torch.manual_seed(123)
+    xg = x.clone().requires_grad_(True)
+    y = blk(xg)
+    m = up(active.repeat(4, 1, 1, 1, 1), x.shape[2:]).float().to(DEV)
+    want = x + r * (y0 - x)
+    assert ((y.detach() - want) * m).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    (y * m).sum().backward()
+    dropped = (r == 0).view(-1)
+    assert torch.equal((xg.grad * m)[dropped], m.expand_as(xg.grad)[dropped])      # dy flows through the identity path only
+    torch.manual_seed(123)
+    assert torch.equal(blk(x.clone()), y.detach())
 
 
 def test_convnext_block_fixture(SL):
