@@ -648,6 +648,8 @@ extern "C" int am_conv3d_partials_rows(int mode, int dtype, int ksize, int strid
   // upper bound over the kernels a launch of this shape may take (am_conv3d reports the rows it actually wrote)
   const int rw = conv_rw_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse, out_bshift, n_active);
   if (rw > *rows) *rows = rw;
+  const int rg = conv_gather_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse, out_bshift, n_active);
+  if (rg > *rows) *rows = rg;
   return 0;
 }
 
@@ -680,6 +682,12 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
     if (rc < 0) return rc;
     if (rc == 1) {
       if (partial_rows_written) *partial_rows_written = conv_rw_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_mask != nullptr, out_bshift, n_active);
+      return 0;
+    }
+    const int rg = conv_gather_launch(mode, dtype, ksize, stride, a, active_list, n_active, stream);   // deep block-sparse levels: rows = active voxels
+    if (rg < 0) return rg;
+    if (rg == 1) {
+      if (partial_rows_written) *partial_rows_written = conv_gather_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_mask != nullptr, out_bshift, n_active);
       return 0;
     }
   }

@@ -135,4 +135,9 @@ int conv_rw_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a, cons
 int conv_rw_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, int out_sparse, int out_bshift,
                  int n_active);   // partial-sum rows such a launch writes, or 0 when the shape does not qualify
 
+// voxel-list gather kernel (conv_gather.hip): k3 s1 forward / data gradient of block-sparse tensors whose patches are at most 2^3 voxels
+int conv_gather_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a, const int* active_list, int n_active, void* stream);
+int conv_gather_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, int out_sparse, int out_bshift,
+                     int n_active);   // partial-sum rows such a launch writes, or 0 when the shape does not qualify
+
 }  // namespace amconv

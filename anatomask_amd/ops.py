@@ -205,8 +205,9 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     Do, Ho, Wo = out_spatial
     mk = in_mask or out_mask
     mp, fd, fh, fw = _mk(mk)
-    # thin block-sparse layers (Cin <= 32) run on the resident-weight kernel, which walks the active-patch list
-    alp, aln = _al(out_mask) if (out_mask is not None and out_mask is in_mask and Cin <= 32 and x.dtype == torch.bfloat16) else (None, 0)
+    # the active-patch list: thin block-sparse layers (Cin <= 32) run on the resident-weight kernel, which walks the active bricks, and the
+    # levels whose patches are smaller than a brick on the voxel-list gather kernel (conv_gather.hip)
+    alp, aln = _al(out_mask) if (out_mask is not None and out_mask is in_mask and x.dtype == torch.bfloat16) else (None, 0)
     if norm_bwd is not None:
         xp, st, nact = norm_bwd
         assert x.dtype == torch.bfloat16 and xp.dtype == torch.bfloat16 and tuple(xp.shape) == (B, Do, Ho, Wo, Cout) and bias is None
