@@ -1,4 +1,4 @@
-// k3 stride-1 convolution (forward / data gradient) of a block-sparse tensor whose patches are SMALLER than a brick, bf16, gfx950.
+// k3 convolution (forward stride 1 / 2, data gradient stride 1) of a block-sparse tensor whose patches are SMALLER than a brick, bf16, gfx950.
 // Ref: P/encoder3D.py:12-15 (sp_conv_forward: dense conv of the zero-filled tensor, output masked) at the deep encoder levels, where
 // a patch of the mask is 4^3 or 2^3 voxels or ONE voxel (STUNet levels 2-4: 128-1536 channels on 8^3-48^3 grids).
 //
@@ -33,6 +33,7 @@ struct GaArgs {
   int ntile, ny;         // voxel tiles, output-channel tiles
   int nkg;               // stages per tap = Cin / KG
   int ntap;
+  int S;                 // source stride: 1, or 2 (strided forward conv: the source grid is twice the output grid, its patches twice as wide)
   int shift[27];         // per tap: (ud + 1) | (uh + 1) << 2 | (uw + 1) << 4 | widx << 8
 };
 
@@ -55,12 +56,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
   const int ytile = t8 % r.ny, tile = (t8 / r.ny) * 8 + (blockIdx.x & 7);
   if (tile >= r.ntile) return;
   const int co0 = ytile * NT;
-  const int D = a.Di, H = a.Hi, W = a.Wi;
-  const int bs = r.bs, pm = (1 << bs) - 1;
+  const int D = a.Di, H = a.Hi, W = a.Wi;                 // source grid
+  const int bs = r.bs, pm = (1 << bs) - 1, S = r.S;
   const int cinB = a.Cin * 2;
 
   // ---- this lane's voxels (one per subtile): linear index, and which of the 27 neighbours exist (in range AND in an active patch)
-  int vlin[VS];
+  int vlin[VS], vout[VS];                                  // linear index of the tap-centre voxel in the source grid / of the output voxel
   bool valid[VS];
   unsigned nb[VS];
   {
@@ -74,11 +75,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
       const int loc = i & ((1 << (3 * bs)) - 1);
       const int b = (pk >> 24) & 255;
       const int d = (((pk >> 16) & 255) << bs) | (loc >> (2 * bs)), h = (((pk >> 8) & 255) << bs) | ((loc >> bs) & pm), w = ((pk & 255) << bs) | (loc & pm);
-      vlin[j] = ((b * D + d) * H + h) * W + w;
+      vout[j] = ((b * a.Do + d) * a.Ho + h) * a.Wo + w;
+      vlin[j] = ((b * D + S * d) * H + S * h) * W + S * w;
       inr[j] = 0;
 #pragma unroll
       for (int c = 0; c < 27; ++c) {                       // unconditional mask-byte loads, all in flight at once
-        const int nd = d + c / 9 - 1, nh = h + (c / 3) % 3 - 1, nw = w + c % 3 - 1;
+        const int nd = S * d + c / 9 - 1, nh = S * h + (c / 3) % 3 - 1, nw = S * w + c % 3 - 1;
         const bool ok = valid[j] && (unsigned)nd < (unsigned)D && (unsigned)nh < (unsigned)H && (unsigned)nw < (unsigned)W;
         mb[j][c] = a.in_mask.peek(b, nd, nh, nw, ok);
         inr[j] |= ok ? 1u << c : 0u;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
       typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
       typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
       const bfx4 p0 = __builtin_convertvector(o0, bfx4), p1 = __builtin_convertvector(o1, bfx4);   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
-      if (wr && !AM_DBG(a, 1)) *(bfx8*)(yg + (size_t)vlin[j] * a.Cout + co) = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+      if (wr && !AM_DBG(a, 1)) *(bfx8*)(yg + (size_t)vout[j] * a.Cout + co) = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
       // what was stored, for the statistics below
       acc[2 * h][j] = wr ? __builtin_convertvector(p0, f32x4) : f32x4{0.f, 0.f, 0.f, 0.f};
       acc[2 * h + 1][j] = wr ? __builtin_convertvector(p1, f32x4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -225,10 +227,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
 
 struct GaGeo { int bs, M, ntile, ny, ns, ksl; };
 
-// which launches take this kernel: bf16 k3 s1 forward / data gradient, the same block-sparse mask on both sides with patches of
-// at most 2^3 voxels at this level, whole 64-channel tiles on both sides, no fused epilogue, a tensor below 2 GB (32-bit row offsets)
+// which launches take this kernel: bf16 k3 forward (stride 1 or 2) / stride-1 data gradient, the same block-sparse mask on both sides
+// with output patches of at most 4^3 voxels, 128-channel source groups and 64-channel output tiles, no fused epilogue, tensors below
+// 2 GB (32-bit row offsets)
 bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, bool sparse, int bshift, int n_active) {
-  if (dtype != AM_DT_BF16 || k != 3 || stride != 1 || (mode != AM_CONV_FWD && mode != AM_CONV_DGRAD)) return false;
+  if (dtype != AM_DT_BF16 || k != 3 || !((stride == 1 && (mode == AM_CONV_FWD || mode == AM_CONV_DGRAD)) || (stride == 2 && mode == AM_CONV_FWD))) return false;
   if (!sparse || n_active <= 0) return false;
   int max_bs = 2;                                          // patches of 4^3, 2^3 voxels and single voxels (8^3 and 16^3 patches hold whole bricks)
   int wide = -1;                                           // 128-channel tiles: -1 = when they still give every CU a workgroup
@@ -238,7 +241,7 @@ bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do
 #endif
   if (bshift < 0 || bshift > max_bs) return false;
   if (Cin % 128 || Cout % 64) return false;
-  if ((size_t)B * Do * Ho * Wo * (size_t)(Cin > Cout ? Cin : Cout) * 2 >= 0x7fffff00ull) return false;
+  if ((size_t)B * Do * Ho * Wo * (size_t)(Cin * stride * stride * stride > Cout ? Cin * stride * stride * stride : Cout) * 2 >= 0x7fffff00ull) return false;
   G.bs = bshift;
   G.M = n_active << (3 * bshift);
   G.ntile = (G.M + 127) / 128;
@@ -278,27 +281,22 @@ int conv_gather_rows(int mode, int dtype, int ksize, int stride, int B, int Do, 
 // returns 1 when it took the launch, 0 when the shape does not qualify, < 0 on error
 int conv_gather_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, const int* active_list, int n_active, void* stream) {
   const bool sparse = a0.out_mask.m != nullptr;
-  if (!sparse || a0.in_mask.m != a0.out_mask.m || a0.in_mask.bs != a0.out_mask.bs || !active_list) return 0;
+  const int S = mode == AM_CONV_FWD ? stride : 1;
+  if (!sparse || a0.in_mask.m != a0.out_mask.m || a0.in_mask.bs != a0.out_mask.bs + (S == 2 ? 1 : 0) || !active_list) return 0;
   if (a0.accumulate || a0.ep_scale || a0.ep_res || a0.ep_act != AM_ACT_NONE || a0.nb_x) return 0;
-  if (a0.Di != a0.Do || a0.Hi != a0.Ho || a0.Wi != a0.Wo) return 0;
+  if (a0.Di != a0.Do * S || a0.Hi != a0.Ho * S || a0.Wi != a0.Wo * S) return 0;
   if (a0.in_mask.fd > 255 || a0.in_mask.fh > 255 || a0.in_mask.fw > 255 || a0.B > 255) return 0;
   GaGeo G;
   if (!ga_geometry(G, mode, dtype, ksize, stride, a0.B, a0.Do, a0.Ho, a0.Wo, a0.Cin, a0.Cout, sparse, a0.out_mask.bs, n_active)) return 0;
-  Plan P;
-  P.a = a0;
-  P.bd = 4; P.bh = 4; P.bw = 16; P.nt_tile = 64;          // (only the tap table of the plan is used: shifts and weight indices)
-  const int rc = build_plan(P, mode, ksize, stride);
-  if (rc) return rc;
-  ConvArgs& a = P.a;
+  ConvArgs& a = a0;
   GaArgs r;
-  r.plist = active_list; r.M = G.M; r.bs = G.bs; r.ntile = G.ntile; r.ny = G.ny;
-  r.ntap = a.tap_begin[a.nunit];
-  if (r.ntap != 27) return 0;
+  r.plist = active_list; r.M = G.M; r.bs = G.bs; r.ntile = G.ntile; r.ny = G.ny; r.ntap = 27; r.S = S;
+  // tap t = (td, th, tw) of the 3^3 kernel: the forward conv reads source voxel S * q + t - 1, the data gradient q + 1 - t (P/encoder3D.py
+  // :12-15 is F.conv3d with padding 1; its gradient wrt the input correlates dy with the flipped kernel); weight slice = t in both packings
   for (int t = 0; t < 27; ++t) {
-    const int tp = a.taps[t];
-    const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8;
-    if (ud < -1 || ud > 1 || uh < -1 || uh > 1 || uw < -1 || uw > 1) return 0;
-    r.shift[t] = (ud + 1) | ((uh + 1) << 2) | ((uw + 1) << 4) | (((tp >> 12) & 63) << 8);
+    const int td = t / 9, th = (t / 3) % 3, tw = t % 3;
+    const int ud = mode == AM_CONV_FWD ? td - 1 : 1 - td, uh = mode == AM_CONV_FWD ? th - 1 : 1 - th, uw = mode == AM_CONV_FWD ? tw - 1 : 1 - tw;
+    r.shift[t] = (ud + 1) | ((uh + 1) << 2) | ((uw + 1) << 4) | (t << 8);
   }
   hipStream_t st = (hipStream_t)stream;
   if (G.ns == 8) return ga_launch<8, 4>(a, r, st);

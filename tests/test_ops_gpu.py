@@ -373,43 +373,47 @@ def _conv_case(ops, dtype, cin, cout, k, s, so, B, sparse, bs_out, det=False, se
         close(dw.cpu(), wr.grad, TOL[dtype], f"conv wgrad (det={d})")
 
 
-@pytest.mark.parametrize("case", [(256, 256, (4, 4, 4), 1, 2), (128, 192, (5, 6, 7), 0, 3), (512, 256, (3, 4, 5), 1, 2), (384, 128, (6, 5, 4), 0, 1), (256, 64, (2, 2, 3), 1, 1),
-                                  (128, 128, (3, 3, 4), 2, 2), (128, 128, (6, 6, 5), 2, 8), (128, 384, (3, 2, 2), 2, 16)])
+@pytest.mark.parametrize("case", [(256, 256, (4, 4, 4), 1, 2, 1), (128, 192, (5, 6, 7), 0, 3, 1), (512, 256, (3, 4, 5), 1, 2, 1), (384, 128, (6, 5, 4), 0, 1, 1), (256, 64, (2, 2, 3), 1, 1, 1),
+                                  (128, 128, (3, 3, 4), 2, 2, 1), (128, 128, (6, 6, 5), 2, 8, 1), (128, 384, (3, 2, 2), 2, 16, 1),
+                                  (128, 256, (4, 3, 5), 0, 2, 2), (256, 128, (3, 3, 3), 1, 2, 2), (128, 64, (2, 3, 2), 2, 1, 2)])
 def test_conv_gather_small_patches(ops, case):
-    """Levels whose patches are 4^3 / 2^3 voxels or one voxel run on the voxel-list gather kernel (conv_gather.hip: rows of the implicit GEMM =
-    the active voxels of the active-patch list, source fragments gathered per tap): forward and data gradient against F.conv3d of the
-    zero-filled tensor (P/encoder3D.py:12-15), bias, the (sum, sum of squares) rows of the stored values, NaN in every inactive voxel;
-    ragged last voxel tile, 128- and 256-channel stages, 64- and 128-channel tiles (the latter from 256 workgroups up: the B=8 case),
-    several samples per tile."""
-    cin, cout, f, bs, B = case
+    """Levels whose patches are 4^3 / 2^3 voxels or one voxel run on the voxel-list gather kernel (conv_gather.hip: rows of the implicit
+    GEMM = the active voxels of the active-patch list, source fragments gathered per tap): forward (stride 1 and 2) and data gradient
+    against F.conv3d of the zero-filled tensor (P/encoder3D.py:12-15), bias, the (sum, sum of squares) rows of the stored values, NaN in
+    every inactive voxel; ragged last voxel tile, 128- and 256-channel stages, 64- and 128-channel tiles (the latter from 256 workgroups
+    up: the B=8 case), several samples per tile."""
+    cin, cout, f, bs, B, stride = case
     dtype = torch.bfloat16
-    sp = tuple(v << bs for v in f)
+    so = tuple(v << bs for v in f)
+    si = tuple(v * stride for v in so)
+    bs_in = bs + (1 if stride == 2 else 0)
     mask = mk_mask(B, f, max(1, (f[0] * f[1] * f[2] * 2) // 5), seed=71)
     mi = ops.MaskInfo.from_bool(mask, DEV)
-    m = O.upsample_mask(mask, sp).float()
-    x = q(rnd(B, cin, *sp, seed=72), dtype) * m
+    m_in, m_out = O.upsample_mask(mask, si).float(), O.upsample_mask(mask, so).float()
+    x = q(rnd(B, cin, *si, seed=72), dtype) * m_in
     w = q(rnd(cout, cin, 3, 3, 3, seed=73, scale=1.0 / np.sqrt(cin * 27)), dtype)
     bias = rnd(cout, seed=74)
-    dy = q(rnd(B, cout, *sp, seed=75), dtype) * m
+    dy = q(rnd(B, cout, *so, seed=75), dtype) * m_out
     xr = x.clone().requires_grad_(True)
-    yr = F.conv3d(xr, w, bias, padding=1) * m
+    yr = F.conv3d(xr, w, bias, stride=stride, padding=1) * m_out
     yr.backward(dy)
-    nan = lambda t, c: torch.where(to_cl(m.expand(B, c, *sp), dtype) > 0, t, torch.full_like(t, float("nan")))
+    nan = lambda t, mm: torch.where(to_cl(mm.expand(B, t.shape[-1], *mm.shape[2:]), dtype) > 0, t, torch.full_like(t, float("nan")))
     wd = w.to(DEV)
-    y, part = ops.conv3d(ops.CONV_FWD, nan(to_cl(x, dtype), cin), ops.pack_weight(wd, dtype, False, False), bias.to(DEV), sp, 3, 1,
-                         in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs, want_partials=True,
-                         out=torch.full((B, *sp, cout), float("nan"), device=DEV, dtype=dtype))
+    y, part = ops.conv3d(ops.CONV_FWD, nan(to_cl(x, dtype), m_in), ops.pack_weight(wd, dtype, False, False), bias.to(DEV), so, 3, stride,
+                         in_mask=mi, in_bshift=bs_in, out_mask=mi, out_bshift=bs, want_partials=True,
+                         out=torch.full((B, *so, cout), float("nan"), device=DEV, dtype=dtype))
     n_vox = int(mask.sum()) << (3 * bs)
     assert part.rows == (n_vox + 127) // 128                 # one row per tile of 128 active voxels: the gather kernel took the launch
-    close(from_cl(y), yr.detach(), TOL[dtype], "gather conv fwd", m)
-    assert torch.isnan(from_cl(y)[(m == 0).expand_as(yr)]).all()           # inactive voxels are never written
+    close(from_cl(y), yr.detach(), TOL[dtype], "gather conv fwd", m_out)
+    assert torch.isnan(from_cl(y)[(m_out == 0).expand_as(yr)]).all()       # inactive voxels are never written
     ys = torch.nan_to_num(y.float()).cpu()                   # the stored bf16 values
     rows = part.t[:part.rows].double().sum(0).cpu()
     want = torch.stack([ys.double().sum((0, 1, 2, 3)), (ys.double() ** 2).sum((0, 1, 2, 3))], 1)
     assert torch.allclose(rows, want, rtol=2e-4, atol=1e-3), (rows - want).abs().max()
-    dx = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), cout), ops.pack_weight(wd, dtype, False, True), None, sp, 3, 1,
-                    in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs)
-    close(from_cl(dx), xr.grad, TOL[dtype], "gather conv dgrad", m)
+    if stride == 1:
+        dx = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), m_out), ops.pack_weight(wd, dtype, False, True), None, si, 3, 1,
+                        in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs)
+        close(from_cl(dx), xr.grad, TOL[dtype], "gather conv dgrad", m_in)
 
 
 @pytest.mark.parametrize("case", [
