@@ -55,7 +55,8 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               const void* ep_res /* NULL or a tensor shaped like y that is added (x = x + to_dec[i], P/decoder3D.py:59) */,
               int ep_act /* AM_ACT_*: applied last */,
               const int32_t* active_list, int n_active /* am_mask_compact of the patch mask, or NULL / 0: lets thin block-sparse layers
-              (Cin <= 32) run on persistent workgroups that walk only the active bricks with all weights resident in LDS */,
+              (Cin <= 32) run on persistent workgroups that walk only the active bricks with all weights resident in LDS, and the
+              levels whose patches are at most 4^3 voxels on the voxel-list gather kernel (rows = active voxels; conv_gather.hip) */,
               int* partial_rows_written /* NULL or (host) the number of partials rows this launch wrote (<= am_conv3d_partials_rows) */,
               void* stream);
 /* am_conv3d whose output y is the gradient wrt a = act(nb_x * nb_scale + nb_shift) -- the output of a norm + activation
