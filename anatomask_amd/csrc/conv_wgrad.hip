@@ -642,6 +642,13 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   // 16-wide brick spans two patches, is empty only 36 % of the time and needs a mask test per row)
   const bool patch8 = y_mask && (1 << y_bshift) == 8 && Hy % 8 == 0 && Wy % 8 == 0 && Dy % 2 == 0;
   if (bf && Qw >= 16 && !(patch8 && Cx > 32 && Cy > 32)) { bh = 4; bw = 16; }
+  // ... with patches 4 voxels wide: the 4x4x4 brick IS the patch (64 voxels, two k-steps: short, but the 2x4x16 brick spans four patches,
+  // is live 87 % of the time for 40 % of its voxels and tests the mask per row)
+  bool patch4 = bf && y_mask && (1 << y_bshift) == 4 && Dy % 4 == 0 && Hy % 4 == 0 && Wy % 4 == 0 && mode == AM_CONV_FWD && k == 3 && stride == 1 && Cx > 32 && Cy > 32;
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_PATCH4"); if (e_ && !atoi(e_)) patch4 = false; }
+#endif
+  if (patch4) { bd = 4; bh = 4; bw = 4; }
   // dense k3 s1 with 64-wide tiles: one-plane 1x8x16 bricks -- the X brick of a tap group has no d-halo at all (10x18 voxels
   // for 8x16: 1.41x, against 1.69x for 2x4x16) and the d-fastest walk re-reads each plane from L2
   bool plane_brick = bf && Qw >= 16 && Qh >= 8 && mode == AM_CONV_FWD && k == 3 && stride == 1 && !x_mask && !y_mask && (Cx > 32 || Cy > 32);
@@ -723,6 +730,8 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
       else if (ntap == 4) rc = launch<bf16_t, 2, 4, 16, 4, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 2) rc = launch<bf16_t, 2, 4, 16, 2, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
       else rc = launch<bf16_t, 2, 4, 16, 1, 4, 4, 2>(a, maxvox, tiles, nbrick, det_slots, st);
+    } else if (bf && bw == 4) {
+      rc = ntap == 9 ? launch<bf16_t, 4, 4, 4, 9, 5>(a, maxvox, tiles, nbrick, det_slots, st) : -2;
     } else if (bf && bw == 16) {
       if (ntap == 9 && bd == 1) rc = launch<bf16_t, 1, 8, 16, 9, 6>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
