@@ -7,6 +7,7 @@ cp $src/bench.json profiles/${tag}_bench.json
 cp $src/bench_stunet_L_160_m07_b4.json profiles/${tag}_bench_stunet_L_160_m07_b4.json
 cp $src/bench_stunet_H_192_recompute_b2.json profiles/${tag}_bench_stunet_H_192_recompute_b2.json
 grep -v amdgpu.ids $src/conv_census.txt > profiles/${tag}_conv_census.txt
+grep -v amdgpu.ids $src/conv_census_stunet_L_160_m07_b4.txt > profiles/${tag}_conv_census_stunet_L_160_m07_b4.txt
 grep -v amdgpu.ids $src/phase_times_b16.txt > profiles/${tag}_phase_times_b16.txt
 { grep -v amdgpu.ids $src/pytest.txt | tail -12; echo "--- smoke"; tail -2 $src/smoke.txt; } > profiles/${tag}_gpu_tests.txt
 cp $(ls $src/step/*/*_kernel_stats.csv | head -1) profiles/${tag}_step_kernel_stats_b16.csv

@@ -14,6 +14,7 @@ from anatomask_amd.trainer import AnatoMaskTrainer  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda:0")
 SIZE, PATCH, MR = os.environ.get("AM_CENSUS_SIZE", "B"), int(os.environ.get("AM_CENSUS_PATCH", "128")), float(os.environ.get("AM_CENSUS_MASK", "0.6"))
+ACT = 1.0 - MR                                   # active fraction: block-sparse launches are credited with the active voxels' flops
 kw = M.STUNET_CONFIGS[SIZE]                      # AM_CENSUS_SIZE=L AM_CENSUS_PATCH=160 AM_CENSUS_MASK=0.7 python tools/conv_census.py 4
 torch.manual_seed(0)
 model = M.build_spark(kw["dims"], kw["depth"], kw["width"], (PATCH,) * 3, MR, compute_dtype=torch.bfloat16).to(dev)
@@ -44,7 +45,7 @@ def conv3d(mode, x, w, bias, out_spatial, ksize, stride, in_mask=None, in_bshift
     else:
         vox, taps = Bq * Do * Ho * Wo, 8
     sparse = (in_mask or out_mask) is not None
-    rec.append((f"{MODES[mode]} k{ksize}s{stride} {Cin}->{Cout} @{Do}{'s' if sparse else ''}", 2.0 * vox * taps * Cin * Cout * (0.4 if sparse else 1.0), e0, e1))
+    rec.append((f"{MODES[mode]} k{ksize}s{stride} {Cin}->{Cout} @{Do}{'s' if sparse else ''}", 2.0 * vox * taps * Cin * Cout * (ACT if sparse else 1.0), e0, e1))
     return r
 
 
@@ -60,7 +61,7 @@ def conv3d_wgrad(mode, x, dy, ksize, stride, x_mask=None, x_bshift=0, y_mask=Non
         fl = 2.0 * Bq * Dy * Hy * Wy * ksize ** 3 * Cx * Cy
     else:
         fl = 2.0 * Bq * Dy * Hy * Wy * 8 * Cx * Cy
-    rec.append((f"wgrad {'convT' if mode != ops.CONV_FWD else ''} k{ksize}s{stride} {Cx}->{Cy} @{Dy}{'s' if sparse else ''}", fl * (0.4 if sparse else 1.0), e0, e1))
+    rec.append((f"wgrad {'convT' if mode != ops.CONV_FWD else ''} k{ksize}s{stride} {Cx}->{Cy} @{Dy}{'s' if sparse else ''}", fl * (ACT if sparse else 1.0), e0, e1))
     return r
 
 
@@ -82,7 +83,7 @@ for name, fl, a, b in rec:
     n, T, F = agg.get(name, (0, 0.0, 0.0))
     agg[name] = (n + 1, T + t, F + fl)
 tot = sum(v[1] for v in agg.values())
-print(f"{'launch (s = block-sparse, FLOPs x0.4)':48s} {'n':>3s} {'ms':>8s} {'%':>6s} {'TFLOP/s':>8s}")
+print(f"{'launch (s = block-sparse, FLOPs x' + format(ACT, '.1f') + ')':48s} {'n':>3s} {'ms':>8s} {'%':>6s} {'TFLOP/s':>8s}")
 for name, (n, T, F) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print(f"{name:48s} {n:3d} {T:8.3f} {100 * T / tot:6.1f} {F / T / 1e9:8.0f}")
 print(f"{'total':48s} {len(rec):3d} {tot:8.3f}        {sum(v[2] for v in agg.values()) / tot / 1e9:8.0f}")

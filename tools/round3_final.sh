@@ -12,6 +12,7 @@ timeout 900 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/ben
 timeout 900 python3 bench.py --size L --patch 160 --mask-ratio 0.7 --batch 4 --steps 8 --warmup 3 --no-h2d > $out/bench_stunet_L_160_m07_b4.json 2> $out/bench_L.err; tail -c 900 $out/bench_stunet_L_160_m07_b4.json
 timeout 900 python3 bench.py --size H --patch 192 --batch 2 --recompute --steps 5 --warmup 2 --no-h2d > $out/bench_stunet_H_192_recompute_b2.json 2> $out/bench_H.err; tail -c 900 $out/bench_stunet_H_192_recompute_b2.json
 timeout 600 python3 tools/conv_census.py 16 > $out/conv_census.txt 2>&1; tail -3 $out/conv_census.txt
+AM_CENSUS_SIZE=L AM_CENSUS_PATCH=160 AM_CENSUS_MASK=0.7 timeout 600 python3 tools/conv_census.py 4 > $out/conv_census_stunet_L_160_m07_b4.txt 2>&1; tail -1 $out/conv_census_stunet_L_160_m07_b4.txt
 timeout 300 python3 tools/phase_times.py 16 > $out/phase_times_b16.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/step -- python3 $root/tools/step_run.py 16 20 1 > $out/step.log 2>&1
