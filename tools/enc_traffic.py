@@ -1,7 +1,7 @@
 """HBM traffic of the student sparse-encoder forward from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs of
 tools/encoder_profile.py, kernel trace only beside them; MI355X_MICROARCH.md "HBM": both counters are in KB, FETCH_SIZE reports half of
 the bytes of wide coalesced reads on gfx950 and is doubled here).
-usage: python tools/enc_traffic.py <fetch dir> <write dir> <batch> [trace dir with kernel_trace.csv for durations]"""
+usage: python tools/enc_traffic.py <fetch dir> <write dir> <batch> [size B|L|H] [patch] [mask ratio]"""
 import collections
 import csv
 import glob
@@ -41,11 +41,14 @@ for i in range(n):
     w = sum(float(x[i]["Counter_Value"]) for x in W) / len(W) * 1e3
     e = fam.setdefault(k, [0, 0.0, 0.0]); e[0] += 1; e[1] += f; e[2] += w
     tot_f += f; tot_w += w
-algo = 1105.3e6 * B
-print(f"# HBM traffic of the student sparse-encoder forward, STUNet-B 128^3 bf16 mask 0.6, B={B} (rocprofv3 --pmc, mean of {len(F)} forwards, {n} launches each)\n")
+SIZE = sys.argv[4] if len(sys.argv) > 4 else "B"
+PATCH, MR = (sys.argv[5] if len(sys.argv) > 5 else "128"), (sys.argv[6] if len(sys.argv) > 6 else "0.6")
+per_vol = {"S": 36.1e6, "B": 1105.3e6, "L": 6135e6, "H": 30622e6}[SIZE]
+algo = per_vol * B
+print(f"# HBM traffic of the student sparse-encoder forward, STUNet-{SIZE} {PATCH}^3 bf16 mask {MR}, B={B} (rocprofv3 --pmc, mean of {len(F)} forwards, {n} launches each)\n")
 print("| kernel | launches | fetched (2 x FETCH_SIZE) MB | written (WRITE_SIZE) MB |\n|---|---|---|---|")
 for k, (c, f, w) in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
     print(f"| `{k}` | {c} | {f / 1e6:.1f} | {w / 1e6:.1f} |")
 print(f"| **total** | {n} | **{tot_f / 1e6:.1f}** | **{tot_w / 1e6:.1f}** |\n")
 print(f"fetched + written = {(tot_f + tot_w) / 1e9:.3f} GB per forward = {(tot_f + tot_w) / algo:.2f} x the algorithmic {algo / 1e9:.3f} GB "
-      f"(SURVEY.md 8d: 1 105.3 MB per volume).")
+      f"(SURVEY.md 8d: {per_vol / 1e6:.1f} MB per volume).")
