@@ -662,6 +662,9 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   if (s2full) nwx = 2;                                    // 32-channel X tiles: the 9 x 33 full-resolution rows stay at 96 bytes
   else if (bf && bw == 16 && mode == AM_CONV_FWD && (k == 3 || stride == 2)) {
     if (Cy <= 32 && stride == 1) mi = 2;
+#ifdef AM_ABLATE
+    { const char* e_ = getenv("AM_WG_MI2"); if (e_ && atoi(e_) && stride == 1 && k == 3 && !x_mask && !y_mask) mi = 2; }   // tools: 32-wide cy tiles everywhere (161 VGPRs: room for a streaming wave beside two weight-gradient waves per SIMD)
+#endif
     // dY channel counts that 64-wide tiles pad by a quarter or more (STUNet-H: 96 -> 128): 32-wide cy tiles (three for 96, no padding)
     if (Cy > 64 && stride == 1 && ((Cy + 63) / 64 * 64 - Cy) * 4 >= Cy) mi = 2;
     if (Cx <= 32) nwx = 2;
