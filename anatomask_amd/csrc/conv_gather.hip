@@ -27,14 +27,17 @@ using namespace amconv;
 namespace {
 
 struct GaArgs {
-  const int* plist;      // active-patch list: b << 24 | pd << 16 | ph << 8 | pw
-  int M;                 // active voxels = n_active << (3 * bs)
-  int bs;                // patch edge = 1 << bs voxels at this level
+  const int* plist;      // active-patch list: b << 24 | pd << 16 | ph << 8 | pw; nullptr = a dense tensor (rows = all voxels of the enumeration grid)
+  int M;                 // rows per class: active voxels = n_active << (3 * bs), or B * D * H * W of the enumeration grid
+  int bs;                // patch edge = 1 << bs voxels of the enumeration grid
   int ntile, ny;         // voxel tiles, output-channel tiles
   int nkg;               // stages per tap = Cin / KG
-  int ntap;
-  int S;                 // source stride: 1, or 2 (strided forward conv: the source grid is twice the output grid, its patches twice as wide)
-  int shift[27];         // per tap: (ud + 1) | (uh + 1) << 2 | (uw + 1) << 4 | widx << 8
+  int S;                 // source stride: 1, or 2 (strided forward conv: the source grid is twice the enumeration grid, its patches twice as wide)
+  int OS, ncls;          // output stride 2 (transposed conv, strided data gradient): the enumeration grid is the COARSE (source) grid, every
+                         //   coarse voxel q yields the 8 output voxels 2q + parity; a workgroup computes ONE parity class (its own taps)
+  int Ed, Eh, Ew;        // enumeration grid
+  int cbeg[9];           // taps of class c: [cbeg[c], cbeg[c + 1])
+  int shift[64];         // per tap: (ud + 1) | (uh + 1) << 2 | (uw + 1) << 4 | widx << 8   (u = shift of the source voxel on the source grid)
 };
 
 typedef bf16_t T;
@@ -52,10 +55,12 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, r16 = lane & 15;
   // channel tiles of a voxel tile are neighbours in blockIdx.x on one XCD (they gather the same source rows): see conv_igemm.hip
-  const int t8 = blockIdx.x >> 3;
-  const int ytile = t8 % r.ny, tile = (t8 / r.ny) * 8 + (blockIdx.x & 7);
+  const int t8 = blockIdx.x >> 3, nsib = r.ny * r.ncls;
+  const int sib = t8 % nsib, cls = sib % r.ncls, ytile = sib / r.ncls, tile = (t8 / nsib) * 8 + (blockIdx.x & 7);
   if (tile >= r.ntile) return;
   const int co0 = ytile * NT;
+  const int t0 = r.cbeg[cls], ntap = r.cbeg[cls + 1] - t0;    // this class's taps
+  const int OS = r.OS, pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
   const int D = a.Di, H = a.Hi, W = a.Wi;                 // source grid
   const int bs = r.bs, pm = (1 << bs) - 1, S = r.S;
   const int cinB = a.Cin * 2;
@@ -71,18 +76,24 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
     for (int j = 0; j < VS; ++j) {
       const int i = tile * MT + wave * (16 * VS) + j * 16 + r16;
       valid[j] = i < r.M;
-      const int pk = r.plist[valid[j] ? i >> (3 * bs) : 0];
-      const int loc = i & ((1 << (3 * bs)) - 1);
-      const int b = (pk >> 24) & 255;
-      const int d = (((pk >> 16) & 255) << bs) | (loc >> (2 * bs)), h = (((pk >> 8) & 255) << bs) | ((loc >> bs) & pm), w = ((pk & 255) << bs) | (loc & pm);
-      vout[j] = ((b * a.Do + d) * a.Ho + h) * a.Wo + w;
+      int b, d, h, w;
+      if (r.plist) {
+        const int pk = r.plist[valid[j] ? i >> (3 * bs) : 0];
+        const int loc = i & ((1 << (3 * bs)) - 1);
+        b = (pk >> 24) & 255;
+        d = (((pk >> 16) & 255) << bs) | (loc >> (2 * bs)); h = (((pk >> 8) & 255) << bs) | ((loc >> bs) & pm); w = ((pk & 255) << bs) | (loc & pm);
+      } else {                                             // dense: row i = voxel i of the enumeration grid
+        const int ii = valid[j] ? i : 0;
+        w = ii % r.Ew; h = (ii / r.Ew) % r.Eh; d = (ii / (r.Ew * r.Eh)) % r.Ed; b = ii / (r.Ew * r.Eh * r.Ed);
+      }
+      vout[j] = ((b * a.Do + OS * d + pd) * a.Ho + OS * h + ph) * a.Wo + OS * w + pw;
       vlin[j] = ((b * D + S * d) * H + S * h) * W + S * w;
       inr[j] = 0;
 #pragma unroll
       for (int c = 0; c < 27; ++c) {                       // unconditional mask-byte loads, all in flight at once
         const int nd = S * d + c / 9 - 1, nh = S * h + (c / 3) % 3 - 1, nw = S * w + c % 3 - 1;
         const bool ok = valid[j] && (unsigned)nd < (unsigned)D && (unsigned)nh < (unsigned)H && (unsigned)nw < (unsigned)W;
-        mb[j][c] = a.in_mask.peek(b, nd, nh, nw, ok);
+        mb[j][c] = a.in_mask.m ? a.in_mask.peek(b, nd, nh, nw, ok) : (uint8_t)1;
         inr[j] |= ok ? 1u << c : 0u;
       }
     }
@@ -118,11 +129,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
     for (int j = 0; j < VS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 fa[KSL][VS], fb[KSL][VS], wreg[WIT];
-  const int nstage = r.ntap * r.nkg;
+  const int nstage = ntap * r.nkg;
 
   // loads of stage (tap t, channel group kg): weights -> wreg, source fragments -> F.  ok false: nothing (zeros, no traffic)
   auto issue = [&](u32x4 (&F)[KSL][VS], int t, int kg, bool ok) __attribute__((always_inline)) {
-    const int sh = r.shift[ok ? t : 0];
+    const int sh = r.shift[t0 + (ok ? t : 0)];
     const int ud = (sh & 3) - 1, uh = ((sh >> 2) & 3) - 1, uw = ((sh >> 4) & 3) - 1, widx = sh >> 8;
     const int bit = (ud + 1) * 9 + (uh + 1) * 3 + (uw + 1);
     const int dlinB = ((ud * H + uh) * W + uw) * cinB;    // (uniform) byte shift of the tap's neighbour row
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
   // ---- epilogue: D row 4g+r of tile i = channel crow(16i+4g+r), col = voxel r16 (as conv_igemm.hip)
   T* __restrict__ yg = (T*)a.y;
   constexpr int NH = NS / 2;
-  float* part = a.partials ? a.partials + (size_t)tile * a.Cout * 2 : nullptr;
+  float* part = a.partials ? a.partials + ((size_t)cls * r.ntile + tile) * a.Cout * 2 : nullptr;
 #pragma unroll
   for (int j = 0; j < VS; ++j) {
 #pragma unroll
@@ -192,6 +203,11 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
       if (a.bias && co < a.Cout) { o0 += *(const f32x4*)(a.bias + co); o1 += *(const f32x4*)(a.bias + co + 4); }
       typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
       typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+      if (a.accumulate && wr) {                            // y += conv (the data gradient that lands on a tensor which already holds one)
+        typedef __attribute__((ext_vector_type(8))) float f32x8_;
+        const f32x8_ f = __builtin_convertvector(*(const bfx8*)(yg + (size_t)vout[j] * a.Cout + co), f32x8_);
+        o0 += f32x4{f[0], f[1], f[2], f[3]}; o1 += f32x4{f[4], f[5], f[6], f[7]};
+      }
       const bfx4 p0 = __builtin_convertvector(o0, bfx4), p1 = __builtin_convertvector(o1, bfx4);   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
       if (wr && !AM_DBG(a, 1)) *(bfx8*)(yg + (size_t)vout[j] * a.Cout + co) = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
       // what was stored, for the statistics below
@@ -225,30 +241,56 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
   }
 }
 
-struct GaGeo { int bs, M, ntile, ny, ns, ksl; };
+struct GaGeo { int bs, M, ntile, ny, ns, ksl, S, OS, ncls, Ed, Eh, Ew; };
 
-// which launches take this kernel: bf16 k3 forward (stride 1 or 2) / stride-1 data gradient, the same block-sparse mask on both sides
-// with output patches of at most 4^3 voxels, 128-channel source groups and 64-channel output tiles, no fused epilogue, tensors below
-// 2 GB (32-bit row offsets)
-bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, bool sparse, int bshift, int n_active) {
-  if (dtype != AM_DT_BF16 || k != 3 || !((stride == 1 && (mode == AM_CONV_FWD || mode == AM_CONV_DGRAD)) || (stride == 2 && mode == AM_CONV_FWD))) return false;
-  if (!sparse || n_active <= 0) return false;
+// Which launches take this kernel (bf16, k3 / transposed k4, 128-channel source groups, 64-channel output tiles, no fused epilogue,
+// tensors below 2 GB for the 32-bit row offsets):
+//   * block-sparse, the same mask on both sides, output patches of at most 4^3 voxels: forward stride 1 / 2, data gradient stride 1 / 2
+//     (the strided data gradient enumerates the COARSE voxels and computes the 8 output parities as 8 classes of workgroups),
+//   * dense transposed convs (k4 s2) on grids that the bricks of conv_igemm pad by 1.3x or more (10^3, 12^3, 20^3: STUNet-L / H decoders).
+// (Do, Ho, Wo) is the launch's output grid.
+bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, bool sparse, int out_bshift, int n_active) {
+  if (dtype != AM_DT_BF16) return false;
+  const bool fwd = mode == AM_CONV_FWD && k == 3 && (stride == 1 || stride == 2);
+  const bool dg1 = mode == AM_CONV_DGRAD && k == 3 && stride == 1, dg2 = mode == AM_CONV_DGRAD && k == 3 && stride == 2;
+  const bool ct = mode == AM_CONVT_FWD && k == 4 && stride == 2;
+  if (!fwd && !dg1 && !dg2 && !ct) return false;
+  if (Cin % 128 || Cout % 64) return false;
+  G.S = fwd ? stride : 1;
+  G.OS = (dg2 || ct) ? 2 : 1;
+  G.ncls = G.OS == 2 ? 8 : 1;
+  if (G.OS == 2 && ((Do | Ho | Wo) & 1)) return false;
+  G.Ed = Do / G.OS; G.Eh = Ho / G.OS; G.Ew = Wo / G.OS;    // enumeration grid (= the source grid unless S == 2)
+  const size_t src_vox = (size_t)B * G.Ed * G.Eh * G.Ew * G.S * G.S * G.S, out_vox = (size_t)B * Do * Ho * Wo;
+  if (src_vox * Cin * 2 >= 0x7fffff00ull || out_vox * Cout * 2 >= 0x7fffff00ull || out_vox >= 0x7fffffffull) return false;
   int max_bs = 2;                                          // patches of 4^3, 2^3 voxels and single voxels (8^3 and 16^3 patches hold whole bricks)
   int wide = -1;                                           // 128-channel tiles: -1 = when they still give every CU a workgroup
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_GA_MAXBS"); if (e_) max_bs = atoi(e_); }      // tools: -1 disables the kernel
   { const char* e_ = getenv("AM_GA_WIDE"); if (e_) wide = atoi(e_); }
 #endif
-  if (bshift < 0 || bshift > max_bs) return false;
-  if (Cin % 128 || Cout % 64) return false;
-  if ((size_t)B * Do * Ho * Wo * (size_t)(Cin * stride * stride * stride > Cout ? Cin * stride * stride * stride : Cout) * 2 >= 0x7fffff00ull) return false;
-  G.bs = bshift;
-  G.M = n_active << (3 * bshift);
+  if (max_bs < 0) return false;
+  if (sparse) {
+    if (ct || n_active <= 0) return false;
+    G.bs = out_bshift - (G.OS == 2 ? 1 : 0);               // patch edge on the enumeration grid
+    // (the strided data gradient: coarse patches of at most 2^3 -- with 4^3 its one-to-eight-tap class workgroups measured slower than the bricks)
+    if (G.bs < 0 || G.bs > (dg2 && max_bs > 1 ? 1 : max_bs)) return false;
+    G.M = n_active << (3 * G.bs);
+  } else {
+    if (!ct) return false;                                 // dense k3 convs stay on the brick kernels (h-run reuse beats the padding there)
+    // padding of conv_igemm's bricks on this q grid: the better of 4 x 8 x 8 and 4 x 4 x 16
+    auto up = [](int v, int m) { return (v + m - 1) / m * m; };
+    const double vol = (double)G.Ed * G.Eh * G.Ew;
+    const double p8 = up(G.Ed, 4) * (double)up(G.Eh, 8) * up(G.Ew, 8) / vol, p16 = up(G.Ed, 4) * (double)up(G.Eh, 4) * up(G.Ew, 16) / vol;
+    if ((p8 < p16 ? p8 : p16) < 1.3) return false;
+    G.bs = 0;
+    G.M = B * G.Ed * G.Eh * G.Ew;
+  }
   G.ntile = (G.M + 127) / 128;
   // 128-channel tiles halve the gather traffic per MFMA (the kernel is bound by the caches' bandwidth: 1 KB gathered per 4 MFMAs with
   // 64-channel tiles) -- 1.4-1.5x on the 4^3- and 2^3-patch levels; with fewer than 256 of them (one-voxel patches: a few thousand
   // active voxels) the 64-channel tiles' second workgroup per voxel tile is worth more (profiles/r03_t_gather_ab.txt)
-  const bool w8 = wide < 0 ? (long)G.ntile * (Cout / 128) >= 256 : wide != 0;
+  const bool w8 = wide < 0 ? (long)G.ntile * G.ncls * (Cout / 128) >= 256 : wide != 0;
   G.ns = (w8 && Cout % 128 == 0) ? 8 : 4;
   G.ny = Cout / (16 * G.ns);
   G.ksl = G.ns == 8 ? 4 : (Cin % 256 == 0 ? 8 : 4);
@@ -262,7 +304,7 @@ int ga_launch(ConvArgs& a, GaArgs& r, hipStream_t st) {
   static PerDeviceOnce lds_cap;
   lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   r.nkg = a.Cin / (32 * KSL);
-  dim3 grid((unsigned)(((r.ntile + 7) / 8) * 8 * r.ny), 1, 1);
+  dim3 grid((unsigned)(((r.ntile + 7) / 8) * 8 * r.ny * r.ncls), 1, 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a, r);
   AM_CHECK_LAUNCH();
   return 1;
@@ -275,28 +317,51 @@ namespace amconv {
 int conv_gather_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, int out_sparse, int out_bshift,
                      int n_active) {
   GaGeo G;
-  return ga_geometry(G, mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse != 0, out_bshift, n_active) ? G.ntile : 0;
+  return ga_geometry(G, mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse != 0, out_bshift, n_active) ? G.ntile * G.ncls : 0;
 }
 
 // returns 1 when it took the launch, 0 when the shape does not qualify, < 0 on error
 int conv_gather_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, const int* active_list, int n_active, void* stream) {
   const bool sparse = a0.out_mask.m != nullptr;
-  const int S = mode == AM_CONV_FWD ? stride : 1;
-  if (!sparse || a0.in_mask.m != a0.out_mask.m || a0.in_mask.bs != a0.out_mask.bs + (S == 2 ? 1 : 0) || !active_list) return 0;
-  if (a0.accumulate || a0.ep_scale || a0.ep_res || a0.ep_act != AM_ACT_NONE || a0.nb_x) return 0;
-  if (a0.Di != a0.Do * S || a0.Hi != a0.Ho * S || a0.Wi != a0.Wo * S) return 0;
-  if (a0.in_mask.fd > 255 || a0.in_mask.fh > 255 || a0.in_mask.fw > 255 || a0.B > 255) return 0;
+  if (sparse != (a0.in_mask.m != nullptr) || (sparse && (a0.in_mask.m != a0.out_mask.m || !active_list))) return 0;
+  if (a0.ep_scale || a0.ep_res || a0.ep_act != AM_ACT_NONE || a0.nb_x) return 0;
+  if (sparse && (a0.in_mask.fd > 255 || a0.in_mask.fh > 255 || a0.in_mask.fw > 255 || a0.B > 255)) return 0;
   GaGeo G;
   if (!ga_geometry(G, mode, dtype, ksize, stride, a0.B, a0.Do, a0.Ho, a0.Wo, a0.Cin, a0.Cout, sparse, a0.out_mask.bs, n_active)) return 0;
+  if (a0.accumulate && a0.partials) return 0;
+  // grids and block shifts must be those the geometry assumed: source grid = S x the enumeration grid, output grid = OS x it
+  if (a0.Di != G.Ed * G.S || a0.Hi != G.Eh * G.S || a0.Wi != G.Ew * G.S) return 0;
+  if (sparse && a0.in_mask.bs != G.bs + (G.S == 2 ? 1 : 0)) return 0;
   ConvArgs& a = a0;
   GaArgs r;
-  r.plist = active_list; r.M = G.M; r.bs = G.bs; r.ntile = G.ntile; r.ny = G.ny; r.ntap = 27; r.S = S;
-  // tap t = (td, th, tw) of the 3^3 kernel: the forward conv reads source voxel S * q + t - 1, the data gradient q + 1 - t (P/encoder3D.py
-  // :12-15 is F.conv3d with padding 1; its gradient wrt the input correlates dy with the flipped kernel); weight slice = t in both packings
-  for (int t = 0; t < 27; ++t) {
-    const int td = t / 9, th = (t / 3) % 3, tw = t % 3;
-    const int ud = mode == AM_CONV_FWD ? td - 1 : 1 - td, uh = mode == AM_CONV_FWD ? th - 1 : 1 - th, uw = mode == AM_CONV_FWD ? tw - 1 : 1 - tw;
-    r.shift[t] = (ud + 1) | ((uh + 1) << 2) | ((uw + 1) << 4) | (t << 8);
+  r.plist = sparse ? active_list : nullptr; r.M = G.M; r.bs = G.bs; r.ntile = G.ntile; r.ny = G.ny; r.S = G.S; r.OS = G.OS; r.ncls = G.ncls;
+  r.Ed = G.Ed; r.Eh = G.Eh; r.Ew = G.Ew;
+  if (G.OS == 1) {
+    // tap t = (td, th, tw) of the 3^3 kernel: the forward conv reads source voxel S * q + t - 1, the data gradient q + 1 - t (P/encoder3D.py
+    // :12-15 is F.conv3d with padding 1; its gradient wrt the input correlates dy with the flipped kernel); weight slice = t in both packings
+    for (int t = 0; t < 27; ++t) {
+      const int td = t / 9, th = (t / 3) % 3, tw = t % 3;
+      const int ud = mode == AM_CONV_FWD ? td - 1 : 1 - td, uh = mode == AM_CONV_FWD ? th - 1 : 1 - th, uw = mode == AM_CONV_FWD ? tw - 1 : 1 - tw;
+      r.shift[t] = (ud + 1) | ((uh + 1) << 2) | ((uw + 1) << 4) | (t << 8);
+    }
+    r.cbeg[0] = 0;
+    for (int c = 1; c <= 8; ++c) r.cbeg[c] = 27;
+  } else {
+    // two-class-stride plans: conv_plan.h lists, per output parity class, the taps and their source shifts on the coarse grid
+    Plan P;
+    P.a = a0;
+    P.bd = 4; P.bh = 4; P.bw = 16; P.nt_tile = 64;        // (only the tap table of the plan is used)
+    const int rc = build_plan(P, mode, ksize, stride);
+    if (rc) return rc;
+    if (P.a.OS != 2 || P.a.tap_begin[8] > 64) return 0;
+    for (int c = 0; c <= 8; ++c) r.cbeg[c] = P.a.tap_begin[c];
+    for (int c = 0; c < 8; ++c) if (r.cbeg[c + 1] == r.cbeg[c]) return 0;
+    for (int t = 0; t < P.a.tap_begin[8]; ++t) {
+      const int tp = P.a.taps[t];
+      const int ud = (tp & 15) - 8, uh = ((tp >> 4) & 15) - 8, uw = ((tp >> 8) & 15) - 8;
+      if (ud < -1 || ud > 1 || uh < -1 || uh > 1 || uw < -1 || uw > 1) return 0;
+      r.shift[t] = (ud + 1) | ((uh + 1) << 2) | ((uw + 1) << 4) | (((tp >> 12) & 63) << 8);
+    }
   }
   hipStream_t st = (hipStream_t)stream;
   if (G.ns == 8) return ga_launch<8, 4>(a, r, st);

@@ -410,10 +410,14 @@ def test_conv_gather_small_patches(ops, case):
     rows = part.t[:part.rows].double().sum(0).cpu()
     want = torch.stack([ys.double().sum((0, 1, 2, 3)), (ys.double() ** 2).sum((0, 1, 2, 3))], 1)
     assert torch.allclose(rows, want, rtol=2e-4, atol=1e-3), (rows - want).abs().max()
-    if stride == 1:
-        dx = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), m_out), ops.pack_weight(wd, dtype, False, True), None, si, 3, 1,
-                        in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs)
-        close(from_cl(dx), xr.grad, TOL[dtype], "gather conv dgrad", m_in)
+    # data gradient (stride 2: the 8 output parities of every coarse voxel are 8 classes of workgroups), plain and accumulating
+    wb = ops.pack_weight(wd, dtype, False, True)
+    dx = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), m_out), wb, None, si, 3, stride, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs_in)
+    close(from_cl(dx), xr.grad, TOL[dtype], "gather conv dgrad", m_in)
+    base = q(rnd(B, cin, *si, seed=76), dtype) * m_in
+    dx2 = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), m_out), wb, None, si, 3, stride, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs_in,
+                     out=nan(to_cl(base, dtype), m_in), accumulate=True)
+    close(from_cl(dx2), xr.grad + base, 2 * TOL[dtype], "gather conv dgrad, accumulating", m_in)
 
 
 @pytest.mark.parametrize("case", [
@@ -447,7 +451,8 @@ def test_conv_large_model_shapes(ops, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("case", [(64, 64, (5, 20, 20), 1), (96, 48, (3, 24, 24), 1), (128, 128, (5, 10, 10), 2), (64, 32, (6, 12, 12), 1), (32, 32, (10, 40, 40), 1)])
+@pytest.mark.parametrize("case", [(64, 64, (5, 20, 20), 1), (96, 48, (3, 24, 24), 1), (128, 128, (5, 10, 10), 2), (64, 32, (6, 12, 12), 1), (32, 32, (10, 40, 40), 1),
+                                  (256, 128, (6, 12, 12), 1), (128, 192, (10, 10, 10), 2), (384, 64, (3, 5, 20), 3)])     # (>= 128 input channels on ragged grids: the forward runs on conv_gather.hip)
 def test_conv_transpose_large_model_grids(ops, dtype, case):
     """ConvTranspose3d on the q grids of STUNet-L 160^3 (10, 20, 40) and STUNet-H 192^3 (12, 24): conv_igemm.hip brick_shape picks the
     brick that pads the (h, w) plane less (4x8x8 on 20 / 24, 4x4x16 on 40) -- forward, data gradient, weight gradient."""
