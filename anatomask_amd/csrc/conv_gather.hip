@@ -247,7 +247,8 @@ struct GaGeo { int bs, M, ntile, ny, ns, ksl, S, OS, ncls, Ed, Eh, Ew; };
 // tensors below 2 GB for the 32-bit row offsets):
 //   * block-sparse, the same mask on both sides, output patches of at most 4^3 voxels: forward stride 1 / 2, data gradient stride 1 / 2
 //     (the strided data gradient enumerates the COARSE voxels and computes the 8 output parities as 8 classes of workgroups),
-//   * dense transposed convs (k4 s2) on grids that the bricks of conv_igemm pad by 1.3x or more (10^3, 12^3, 20^3: STUNet-L / H decoders).
+//   * dense transposed convs (k4 s2) on grids that the bricks of conv_igemm pad by 1.3x or more (10^3, 12^3, 20^3: STUNet-L / H decoders),
+//     dense k3 s1 convs from 1.5x (20-wide grids).
 // (Do, Ho, Wo) is the launch's output grid.
 bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, bool sparse, int out_bshift, int n_active) {
   if (dtype != AM_DT_BF16) return false;
@@ -277,12 +278,16 @@ bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do
     if (G.bs < 0 || G.bs > (dg2 && max_bs > 1 ? 1 : max_bs)) return false;
     G.M = n_active << (3 * G.bs);
   } else {
-    if (!ct) return false;                                 // dense k3 convs stay on the brick kernels (h-run reuse beats the padding there)
-    // padding of conv_igemm's bricks on this q grid: the better of 4 x 8 x 8 and 4 x 4 x 16
+    // padding of conv_igemm's bricks on this q grid: the better of 4 x 8 x 8 and 4 x 4 x 16 (k3 s1 plans always take the 16-wide brick)
     auto up = [](int v, int m) { return (v + m - 1) / m * m; };
     const double vol = (double)G.Ed * G.Eh * G.Ew;
     const double p8 = up(G.Ed, 4) * (double)up(G.Eh, 8) * up(G.Ew, 8) / vol, p16 = up(G.Ed, 4) * (double)up(G.Eh, 4) * up(G.Ew, 16) / vol;
-    if ((p8 < p16 ? p8 : p16) < 1.3) return false;
+    double dense_k3 = 1.5;                                 // padding from which dense k3 s1 convs come here: 20-wide grids (1.6x: +6-10 %); at 1.33x (24-wide) the bricks' h-run reuse still wins on some shapes
+#ifdef AM_ABLATE
+    { const char* e_ = getenv("AM_GA_DENSEK3"); if (e_) dense_k3 = atof(e_); }
+#endif
+    if (ct) { if ((p8 < p16 ? p8 : p16) < 1.3) return false; }
+    else if (!((fwd && stride == 1) || dg1) || p16 < dense_k3) return false;
     G.bs = 0;
     G.M = B * G.Ed * G.Eh * G.Ew;
   }

@@ -424,7 +424,7 @@ def test_conv_gather_small_patches(ops, case):
     # cin, cout, k, s, output grid, B, sparse, out bshift
     (1536, 1536, 3, 1, (12, 12, 12), 1, True, 0),     # STUNet-H stage 4: 1728 wgrad tiles (slot count of conv_wgrad.hip launch()), one-voxel patches
     (1024, 1024, 3, 1, (10, 10, 10), 2, True, 0),     # STUNet-L stage 4 on its 10^3 grid (ragged 4x8x8 bricks)
-    (1024, 1024, 3, 1, (5, 20, 20), 1, False, 0),     # STUNet-L decoder block 0 convs: dense, 20-wide (plane bricks, 256 tiles x 3 groups)
+    (1024, 1024, 3, 1, (5, 20, 20), 1, False, 0),     # STUNet-L decoder block 0 convs: dense, 20-wide (forward / data gradient on conv_gather.hip's dense rows; weight gradient: plane bricks, 256 tiles x 3 groups)
     (1536, 768, 3, 1, (3, 24, 24), 1, False, 0),      # STUNet-H decoder block 0 second conv: 24-wide
     (768, 1536, 3, 2, (12, 12, 12), 1, True, 0),      # STUNet-H stage 4 strided conv1 (24^3 two-voxel patches -> 12^3 one-voxel patches)
     (512, 1024, 1, 2, (10, 10, 10), 1, True, 0),      # STUNet-L stage 4 1x1 stride-2 shortcut
