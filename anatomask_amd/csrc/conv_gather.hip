@@ -36,6 +36,7 @@ struct GaArgs {
   int OS, ncls;          // output stride 2 (transposed conv, strided data gradient): the enumeration grid is the COARSE (source) grid, every
                          //   coarse voxel q yields the 8 output voxels 2q + parity; a workgroup computes ONE parity class (its own taps)
   int Ed, Eh, Ew;        // enumeration grid
+  int wide;              // dense tensors with a tap window wider than 3^3 (transposed conv's data gradient: 4^3, shifts -1..2): range tests instead of the 27 bits
   int cbeg[9];           // taps of class c: [cbeg[c], cbeg[c + 1])
   int shift[64];         // per tap: (ud + 1) | (uh + 1) << 2 | (uw + 1) << 4 | widx << 8   (u = shift of the source voxel on the source grid)
 };
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
 
   // ---- this lane's voxels (one per subtile): linear index, and which of the 27 neighbours exist (in range AND in an active patch)
   int vlin[VS], vout[VS];                                  // linear index of the tap-centre voxel in the source grid / of the output voxel
+  int cdhw[VS];                                            // its coordinates (d | h << 10 | w << 20): the range test of taps outside the 3^3 bit mask (r.wide)
   bool valid[VS];
   unsigned nb[VS];
   {
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
       }
       vout[j] = ((b * a.Do + OS * d + pd) * a.Ho + OS * h + ph) * a.Wo + OS * w + pw;
       vlin[j] = ((b * D + S * d) * H + S * h) * W + S * w;
+      cdhw[j] = valid[j] ? (S * d) | ((S * h) << 10) | ((S * w) << 20) : 0x3fffffff;   // (an invalid row fails every range test)
       inr[j] = 0;
 #pragma unroll
       for (int c = 0; c < 27; ++c) {                       // unconditional mask-byte loads, all in flight at once
@@ -135,14 +138,19 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
   auto issue = [&](u32x4 (&F)[KSL][VS], int t, int kg, bool ok) __attribute__((always_inline)) {
     const int sh = r.shift[t0 + (ok ? t : 0)];
     const int ud = (sh & 3) - 1, uh = ((sh >> 2) & 3) - 1, uw = ((sh >> 4) & 3) - 1, widx = sh >> 8;
-    const int bit = (ud + 1) * 9 + (uh + 1) * 3 + (uw + 1);
+    const int bit = (ud + 1) * 9 + (uh + 1) * 3 + (uw + 1);   // (taps with a shift of +2 exist only in the range-checked form)
     const int dlinB = ((ud * H + uh) * W + uw) * cinB;    // (uniform) byte shift of the tap's neighbour row
 #pragma unroll
     for (int it = 0; it < WIT; ++it)
       wreg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (ok && !AM_DBG(a, 4)) ? wsrc[it] : OOB, widx * wtapB + kg * (KG * 2), 0));
 #pragma unroll
     for (int j = 0; j < VS; ++j) {
-      const unsigned off = (ok && ((nb[j] >> bit) & 1u) && !AM_DBG(a, 2)) ? (unsigned)(vlin[j] * cinB + dlinB + g * 16) : OOB;
+      bool here;
+      if (r.wide) {                                        // (uniform) dense tensor, window wider than 3^3: the neighbour exists iff it is in range
+        const int nd = (cdhw[j] & 1023) + ud, nh = ((cdhw[j] >> 10) & 1023) + uh, nw = (cdhw[j] >> 20) + uw;
+        here = (unsigned)nd < (unsigned)D && (unsigned)nh < (unsigned)H && (unsigned)nw < (unsigned)W;
+      } else here = ((nb[j] >> bit) & 1u) != 0;
+      const unsigned off = (ok && here && !AM_DBG(a, 2)) ? (unsigned)(vlin[j] * cinB + dlinB + g * 16) : OOB;
 #pragma unroll
       for (int sl = 0; sl < KSL; ++sl)
         F[sl][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, kg * (KG * 2) + sl * 64, 0));
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_gather_kernel(ConvArgs a, GaArgs 
   }
 }
 
-struct GaGeo { int bs, M, ntile, ny, ns, ksl, S, OS, ncls, Ed, Eh, Ew; };
+struct GaGeo { int bs, M, ntile, ny, ns, ksl, S, OS, ncls, Ed, Eh, Ew, wide; };
 
 // Which launches take this kernel (bf16, k3 / transposed k4, 128-channel source groups, 64-channel output tiles, no fused epilogue,
 // tensors below 2 GB for the 32-bit row offsets):
@@ -255,9 +263,10 @@ bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do
   const bool fwd = mode == AM_CONV_FWD && k == 3 && (stride == 1 || stride == 2);
   const bool dg1 = mode == AM_CONV_DGRAD && k == 3 && stride == 1, dg2 = mode == AM_CONV_DGRAD && k == 3 && stride == 2;
   const bool ct = mode == AM_CONVT_FWD && k == 4 && stride == 2;
-  if (!fwd && !dg1 && !dg2 && !ct) return false;
+  const bool ctd = mode == AM_CONVT_DGRAD && k == 4 && stride == 2;     // = a k4 s2 conv of dy: every coarse voxel gathers a 4^3 window of the fine grid
+  if (!fwd && !dg1 && !dg2 && !ct && !ctd) return false;
   if (Cin % 128 || Cout % 64) return false;
-  G.S = fwd ? stride : 1;
+  G.S = (fwd || ctd) ? stride : 1;
   G.OS = (dg2 || ct) ? 2 : 1;
   G.ncls = G.OS == 2 ? 8 : 1;
   if (G.OS == 2 && ((Do | Ho | Wo) & 1)) return false;
@@ -272,7 +281,7 @@ bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do
 #endif
   if (max_bs < 0) return false;
   if (sparse) {
-    if (ct || n_active <= 0) return false;
+    if (ct || ctd || n_active <= 0) return false;
     G.bs = out_bshift - (G.OS == 2 ? 1 : 0);               // patch edge on the enumeration grid
     // (the strided data gradient: coarse patches of at most 2^3 -- with 4^3 its one-to-eight-tap class workgroups measured slower than the bricks)
     if (G.bs < 0 || G.bs > (dg2 && max_bs > 1 ? 1 : max_bs)) return false;
@@ -286,11 +295,12 @@ bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do
 #ifdef AM_ABLATE
     { const char* e_ = getenv("AM_GA_DENSEK3"); if (e_) dense_k3 = atof(e_); }
 #endif
-    if (ct) { if ((p8 < p16 ? p8 : p16) < 1.3) return false; }
+    if (ct || ctd) { if ((p8 < p16 ? p8 : p16) < 1.3 || G.Ed * G.S > 1023 || G.Eh * G.S > 1023 || G.Ew * G.S > 1023) return false; }
     else if (!((fwd && stride == 1) || dg1) || p16 < dense_k3) return false;
     G.bs = 0;
     G.M = B * G.Ed * G.Eh * G.Ew;
   }
+  G.wide = ctd ? 1 : 0;
   G.ntile = (G.M + 127) / 128;
   // 128-channel tiles halve the gather traffic per MFMA (the kernel is bound by the caches' bandwidth: 1 KB gathered per 4 MFMAs with
   // 64-channel tiles) -- 1.4-1.5x on the 4^3- and 2^3-patch levels; with fewer than 256 of them (one-voxel patches: a few thousand
@@ -340,8 +350,13 @@ int conv_gather_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0,
   ConvArgs& a = a0;
   GaArgs r;
   r.plist = sparse ? active_list : nullptr; r.M = G.M; r.bs = G.bs; r.ntile = G.ntile; r.ny = G.ny; r.S = G.S; r.OS = G.OS; r.ncls = G.ncls;
-  r.Ed = G.Ed; r.Eh = G.Eh; r.Ew = G.Ew;
-  if (G.OS == 1) {
+  r.Ed = G.Ed; r.Eh = G.Eh; r.Ew = G.Ew; r.wide = G.wide;
+  if (G.wide) {
+    // the transposed conv's data gradient (P/decoder3D.py:16-17 ConvTranspose3d k4 s2 p1): dx[q] = sum_t W_t dy[2q + t - 1], t in 0..3 per dim
+    for (int t = 0; t < 64; ++t) r.shift[t] = (t / 16) | (((t / 4) % 4) << 2) | ((t % 4) << 4) | (t << 8);      // (ud + 1 = td, ...)
+    r.cbeg[0] = 0;
+    for (int c = 1; c <= 8; ++c) r.cbeg[c] = 64;
+  } else if (G.OS == 1) {
     // tap t = (td, th, tw) of the 3^3 kernel: the forward conv reads source voxel S * q + t - 1, the data gradient q + 1 - t (P/encoder3D.py
     // :12-15 is F.conv3d with padding 1; its gradient wrt the input correlates dy with the flipped kernel); weight slice = t in both packings
     for (int t = 0; t < 27; ++t) {

@@ -40,5 +40,18 @@ for name, B, c, S in [("STUNet-L 1024->1024 @10->20", 4, 1024, 10), ("STUNet-L 5
             out.append(f"{tag} {t * 1e3:.0f} us {2.0 * B * (2 * S) ** 3 * c * c * 8 / t / 1e9:.0f} TF")
     err = (ys[0].float() - ys[1].float()).abs().max().item() / ys[0].float().abs().max().item()
     print(f"{name}: " + " | ".join(out) + f" | max rel diff {err:.1e}", flush=True)
-    del x, ys
+    # its data gradient: a k4 s2 conv of dy (4^3 window of the fine grid per coarse voxel)
+    dy = torch.randn(B, 2 * S, 2 * S, 2 * S, c, device=dev).to(torch.bfloat16)
+    wb = ops.pack_weight(torch.randn(c, c, 4, 4, 4, device=dev) * 0.02, torch.bfloat16, True, True)
+    out, ys = [], []
+    for rep in range(2):
+        for tag, v in (("bricks", "-1"), ("gather", "2")):
+            os.environ["AM_GA_MAXBS"] = v
+            dx = torch.empty(B, S, S, S, c, device=dev, dtype=torch.bfloat16)
+            t = timed(lambda: ops.conv3d(ops.CONVT_DGRAD, dy, wb, None, (S,) * 3, 4, 2, out=dx))
+            ys.append(dx)
+            out.append(f"{tag} {t * 1e3:.0f} us {2.0 * B * (2 * S) ** 3 * c * c * 8 / t / 1e9:.0f} TF")
+    err = (ys[0].float() - ys[1].float()).abs().max().item() / ys[0].float().abs().max().item()
+    print(f"   data gradient: " + " | ".join(out) + f" | max rel diff {err:.1e}", flush=True)
+    del x, ys, dy
 os.environ.pop("AM_GA_MAXBS", None)
