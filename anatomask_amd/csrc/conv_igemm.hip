@@ -703,6 +703,10 @@ generic:
                           &P.bd, &P.bh, &P.bw, &P.nt_tile, big_ok);
   int rc = build_plan(P, mode, ksize, stride);
   if (rc) return rc;
+  // k1 s2 data gradient that ACCUMULATES into y: only output parity (0, 0, 0) has a tap, the other 7 classes add nothing -- launch class 0
+  // alone (as siblings in blockIdx.x the 7 idle classes sat between the live workgroups and the launch ran at the dispatcher's pace:
+  // 64 -> 32 @128^3 took 0.48 ms for 0.1 ms of work)
+  if (a.OS == 2 && accumulate && !partials && a.tap_begin[1] > a.tap_begin[0] && a.tap_begin[8] == a.tap_begin[1]) a.nclass = 1;
   a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;
   a.ep_scale = ep_scale; a.ep_shift = ep_scale ? ep_shift : nullptr; a.ep_res = ep_res; a.ep_act = ep_act;
   a.B = B; a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
