@@ -74,17 +74,27 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
       const int t = bid >> 3, sib = t % nsib;
       cls = sib % a.nclass; ytile = sib / a.nclass;
       bid = ((t / nsib) << 3) + (bid & 7);
-      if (bid >= a.B * a.nbd * a.nbh * a.nbw) return;    // (grid padded to whole groups of 8 bricks)
+      if (bid >= (a.plist ? a.nlive : a.B * a.nbd * a.nbh * a.nbw)) return;    // (grid padded to whole groups of 8 bricks)
     }
   }
   const int brick = bid;
-  const int bw_ = bid % a.nbw; bid /= a.nbw;
-  const int bh_ = bid % a.nbh; bid /= a.nbh;
-  const int bd_ = bid % a.nbd; const int b = bid / a.nbd;
+  int bw_, bh_, bd_, b;
+  if (a.plist) {
+    // live bricks only: (active patch, brick inside it) -- a launch over every brick of the q grid spends a dispatch slot and a mask
+    // round trip on each empty one (60 % of them at mask 0.6, times 8 for the strided data gradient's classes)
+    const int bpp = a.pbd * a.pbh * a.pbw;
+    const int pk = a.plist[bid / bpp], j = bid % bpp;
+    b = (pk >> 24) & 255;
+    bd_ = ((pk >> 16) & 255) * a.pbd + j / (a.pbh * a.pbw); bh_ = ((pk >> 8) & 255) * a.pbh + (j / a.pbw) % a.pbh; bw_ = (pk & 255) * a.pbw + j % a.pbw;
+  } else {
+    bw_ = bid % a.nbw; bid /= a.nbw;
+    bh_ = bid % a.nbh; bid /= a.nbh;
+    bd_ = bid % a.nbd; b = bid / a.nbd;
+  }
   const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
   const int pd = (cls >> 2) & 1, ph = (cls >> 1) & 1, pw = cls & 1;
   const int co0 = ytile * NT;
-  float* part = a.partials ? a.partials + ((size_t)((size_t)cls * (a.B * a.nbd * a.nbh * a.nbw) + brick) * a.Cout) * 2 : nullptr;
+  float* part = a.partials ? a.partials + ((size_t)((size_t)cls * (a.plist ? a.nlive : a.B * a.nbd * a.nbh * a.nbw) + brick) * a.Cout) * 2 : nullptr;
 #ifdef AM_ABLATE
   // timing experiment (tools build): delay every second set of 256 workgroups of the FIRST dispatch round, so that the two
   // workgroups that share a CU do not run their prologue / main loop / epilogue phases in lockstep (AM_CV_DBG bits 4096.., n x s_sleep 127)
@@ -95,7 +105,9 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
 #endif
 
   // ---- skip bricks with no active output voxel (block-sparse outputs) ----
-  if (a.out_mask.m && a.brick_in_patch) {                // (uniform) every voxel of the brick shares the patch of its first voxel
+  if (a.plist) {
+    // (listed bricks are live)
+  } else if (a.out_mask.m && a.brick_in_patch) {         // (uniform) every voxel of the brick shares the patch of its first voxel
     const int od = q0d * a.OS + pd, oh = q0h * a.OS + ph, ow = q0w * a.OS + pw;
     if (!(od < a.Do && oh < a.Ho && ow < a.Wo && a.out_mask.active(b, od, oh, ow))) {
       if (part && tid < NT && co0 + tid < a.Cout) { part[(co0 + tid) * 2] = 0.f; part[(co0 + tid) * 2 + 1] = 0.f; }
@@ -532,7 +544,7 @@ int launch(Plan& P, hipStream_t st) {
   static PerDeviceOnce lds_cap;                   // per instantiation and device: lift the 48 KB dynamic-LDS default to the CU's 160 KB
   lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   if (P.lds > 160 * 1024) return -3;
-  const unsigned nbrick = (unsigned)(a.B * a.nbd * a.nbh * a.nbw);
+  const unsigned nbrick = a.plist ? (unsigned)a.nlive : (unsigned)(a.B * a.nbd * a.nbh * a.nbw);
   a.ny = (a.Cout + 16 * NS - 1) / (16 * NS);
   const unsigned nsib = (unsigned)(a.ny * a.nclass);
   dim3 grid(nsib > 1 ? ((nbrick + 7) / 8) * 8 * nsib : nbrick, 1, 1);       // (channel tiles and parity classes folded into x, see the kernel)
@@ -718,9 +730,20 @@ generic:
   a.in_mask = MaskView{in_mask, fd, fh, fw, in_bshift};
   a.out_mask = MaskView{out_mask, fd, fh, fw, out_bshift};
   a.accumulate = accumulate;
+  a.plist = nullptr; a.pbd = a.pbh = a.pbw = a.nlive = 0;
   {
     const int qblock = out_mask ? ((1 << out_bshift) / a.OS) : 0;
     a.brick_in_patch = qblock > 0 && qblock % P.bd == 0 && qblock % P.bh == 0 && qblock % P.bw == 0;
+    // (the list is am_mask_compact of THIS launch's mask: callers pass it when in_mask == out_mask; whole patches inside the grid)
+    bool listed = a.brick_in_patch && active_list && n_active > 0 && in_mask == out_mask && fd <= 255 && fh <= 255 && fw <= 255 && B <= 255 &&
+                  Qd == fd * qblock && Qh == fh * qblock && Qw == fw * qblock;
+#ifdef AM_ABLATE
+    { const char* e = getenv("AM_CV_NOLIST"); if (e && atoi(e)) listed = false; }
+#endif
+    if (listed) {
+      a.plist = active_list; a.pbd = qblock / P.bd; a.pbh = qblock / P.bh; a.pbw = qblock / P.bw;
+      a.nlive = n_active * a.pbd * a.pbh * a.pbw;
+    }
   }
 #ifdef AM_ABLATE
   { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
@@ -736,7 +759,7 @@ generic:
   // outputs far larger than the 256 MB Infinity Cache bypass it (measured +2.5 % on the 1 GB decoder tensors: the halo re-reads keep L2)
   a.nt_store = ((size_t)B * Do * Ho * Wo * Cout * 2 >= ((size_t)384 << 20) && !accumulate) || AM_DBG(a, 8);
   hipStream_t st = (hipStream_t)stream;
-  if (partial_rows_written) *partial_rows_written = a.B * a.nbd * a.nbh * a.nbw * a.nclass;
+  if (partial_rows_written) *partial_rows_written = (a.plist ? a.nlive : a.B * a.nbd * a.nbh * a.nbw) * a.nclass;
   return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, shape, st) : dispatch<float>(P, shape, st);
 }
 

@@ -28,6 +28,8 @@ struct ConvArgs {
   MaskView in_mask, out_mask;
   int accumulate;
   int brick_in_patch;         // block-sparse output and the q-brick lies inside one patch: one mask lookup decides the whole brick
+  const int* plist;           // ... and the active-patch list is at hand: the grid enumerates the LIVE bricks only (patch = plist[i / bpp], brick i % bpp
+  int pbd, pbh, pbw, nlive;   //   of its pbd x pbh x pbw bricks); nlive = n_active * bpp.  nullptr: every brick of the q grid, empty ones exit
   int hreuse;                 // taps ordered in h-runs of 3 (see build_plan): the HR kernel variant shares fragment rows across a run
   int nt_store;               // non-temporal output stores (outputs far larger than the 256 MB Infinity Cache)
 #ifdef AM_ABLATE
