@@ -734,8 +734,8 @@ generic:
   {
     const int qblock = out_mask ? ((1 << out_bshift) / a.OS) : 0;
     a.brick_in_patch = qblock > 0 && qblock % P.bd == 0 && qblock % P.bh == 0 && qblock % P.bw == 0;
-    // (the list is am_mask_compact of THIS launch's mask: callers pass it when in_mask == out_mask; whole patches inside the grid)
-    bool listed = a.brick_in_patch && active_list && n_active > 0 && in_mask == out_mask && fd <= 255 && fh <= 255 && fw <= 255 && B <= 255 &&
+    // (the list is am_mask_compact of this launch's OUT mask; whole patches inside the grid)
+    bool listed = a.brick_in_patch && active_list && n_active > 0 && fd <= 255 && fh <= 255 && fw <= 255 && B <= 255 &&
                   Qd == fd * qblock && Qh == fh * qblock && Qw == fw * qblock;
 #ifdef AM_ABLATE
     { const char* e = getenv("AM_CV_NOLIST"); if (e && atoi(e)) listed = false; }

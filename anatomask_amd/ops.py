@@ -207,7 +207,8 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     mp, fd, fh, fw = _mk(mk)
     # the active-patch list: thin block-sparse layers (Cin <= 32) run on the resident-weight kernel, which walks the active bricks, and the
     # levels whose patches are smaller than a brick on the voxel-list gather kernel (conv_gather.hip)
-    alp, aln = _al(out_mask) if (out_mask is not None and out_mask is in_mask and x.dtype == torch.bfloat16) else (None, 0)
+    # (the list is that of OUT_mask: launches with a block-sparse output enumerate their live bricks from it)
+    alp, aln = _al(out_mask) if (out_mask is not None and x.dtype == torch.bfloat16) else (None, 0)
     if norm_bwd is not None:
         xp, st, nact = norm_bwd
         assert x.dtype == torch.bfloat16 and xp.dtype == torch.bfloat16 and tuple(xp.shape) == (B, Do, Ho, Wo, Cout) and bias is None

@@ -54,7 +54,8 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               (running statistics, the EMA teacher's decoder: P/decoder3D.py:20-22 under model_ema.ema.eval()) folded into the store */,
               const void* ep_res /* NULL or a tensor shaped like y that is added (x = x + to_dec[i], P/decoder3D.py:59) */,
               int ep_act /* AM_ACT_*: applied last */,
-              const int32_t* active_list, int n_active /* am_mask_compact of the patch mask, or NULL / 0: lets thin block-sparse layers
+              const int32_t* active_list, int n_active /* am_mask_compact of out_mask, or NULL / 0: block-sparse launches whose bricks lie inside
+              the patches then enumerate their live bricks instead of launching (and leaving) the empty ones; it also lets thin block-sparse layers
               (Cin <= 32) run on persistent workgroups that walk only the active bricks with all weights resident in LDS, and the
               levels whose patches are at most 4^3 voxels on the voxel-list gather kernel (rows = active voxels; conv_gather.hip) */,
               int* partial_rows_written /* NULL or (host) the number of partials rows this launch wrote (<= am_conv3d_partials_rows) */,
