@@ -265,7 +265,8 @@ bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do
   const bool ct = mode == AM_CONVT_FWD && k == 4 && stride == 2;
   const bool ctd = mode == AM_CONVT_DGRAD && k == 4 && stride == 2;     // = a k4 s2 conv of dy: every coarse voxel gathers a 4^3 window of the fine grid
   if (!fwd && !dg1 && !dg2 && !ct && !ctd) return false;
-  if (Cin % 128 || Cout % 64) return false;
+  if (Cin % 64 || Cout % 64) return false;
+  if (Cin % 128 && !(fwd && stride == 2)) return false;   // 64-channel sources: the strided forward conv only (level 1 -> 2 of STUNet-B: 321 -> 211 us)
   G.S = (fwd || ctd) ? stride : 1;
   G.OS = (dg2 || ct) ? 2 : 1;
   G.ncls = G.OS == 2 ? 8 : 1;
@@ -306,9 +307,9 @@ bool ga_geometry(GaGeo& G, int mode, int dtype, int k, int stride, int B, int Do
   // 64-channel tiles) -- 1.4-1.5x on the 4^3- and 2^3-patch levels; with fewer than 256 of them (one-voxel patches: a few thousand
   // active voxels) the 64-channel tiles' second workgroup per voxel tile is worth more (profiles/r03_t_gather_ab.txt)
   const bool w8 = wide < 0 ? (long)G.ntile * G.ncls * (Cout / 128) >= 256 : wide != 0;
-  G.ns = (w8 && Cout % 128 == 0) ? 8 : 4;
+  G.ns = (w8 && Cout % 128 == 0 && Cin % 128 == 0) ? 8 : 4;
   G.ny = Cout / (16 * G.ns);
-  G.ksl = G.ns == 8 ? 4 : (Cin % 256 == 0 ? 8 : 4);
+  G.ksl = G.ns == 8 ? 4 : (Cin % 256 == 0 ? 8 : Cin % 128 == 0 ? 4 : 2);     // (64-channel sources: stages of 2 slabs, 32 MFMAs per wave)
   return true;
 }
 
@@ -385,7 +386,7 @@ int conv_gather_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0,
   }
   hipStream_t st = (hipStream_t)stream;
   if (G.ns == 8) return ga_launch<8, 4>(a, r, st);
-  return G.ksl == 8 ? ga_launch<4, 8>(a, r, st) : ga_launch<4, 4>(a, r, st);
+  return G.ksl == 8 ? ga_launch<4, 8>(a, r, st) : G.ksl == 4 ? ga_launch<4, 4>(a, r, st) : ga_launch<4, 2>(a, r, st);
 }
 
 }  // namespace amconv

@@ -375,7 +375,7 @@ def _conv_case(ops, dtype, cin, cout, k, s, so, B, sparse, bs_out, det=False, se
 
 @pytest.mark.parametrize("case", [(256, 256, (4, 4, 4), 1, 2, 1), (128, 192, (5, 6, 7), 0, 3, 1), (512, 256, (3, 4, 5), 1, 2, 1), (384, 128, (6, 5, 4), 0, 1, 1), (256, 64, (2, 2, 3), 1, 1, 1),
                                   (128, 128, (3, 3, 4), 2, 2, 1), (128, 128, (6, 6, 5), 2, 8, 1), (128, 384, (3, 2, 2), 2, 16, 1),
-                                  (128, 256, (4, 3, 5), 0, 2, 2), (256, 128, (3, 3, 3), 1, 2, 2), (128, 64, (2, 3, 2), 2, 1, 2)])
+                                  (128, 256, (4, 3, 5), 0, 2, 2), (256, 128, (3, 3, 3), 1, 2, 2), (128, 64, (2, 3, 2), 2, 1, 2), (64, 128, (3, 3, 2), 2, 2, 2), (192, 64, (2, 2, 5), 1, 1, 2)])
 def test_conv_gather_small_patches(ops, case):
     """Levels whose patches are 4^3 / 2^3 voxels or one voxel run on the voxel-list gather kernel (conv_gather.hip: rows of the implicit
     GEMM = the active voxels of the active-patch list, source fragments gathered per tap): forward (stride 1 and 2) and data gradient
