@@ -537,7 +537,10 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
   if (occ < 1) occ = 1;
   // Workgroup ids go round-robin over the 8 XCDs and gridDim.x is a multiple of 8, so XCD x runs the slots with slot % 8 == x, times
   // `tiles`: choose slots-per-XCD so that no XCD gets one workgroup more than R whole rounds of its resident set
-  const int cap = wg_slots(occ) / 8;                       // resident workgroups per XCD
+  int cap = wg_slots(occ) / 8;                             // resident workgroups per XCD
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_SPARE"); if (e_ && atoi(e_) > 0 && cap > atoi(e_)) cap -= atoi(e_); }   // tools: leave slots free for the other stream's small kernels
+#endif
   int split8 = 0;
   double best = 0.0;
   int R0 = AM_WG_ROUNDS;
