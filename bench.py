@@ -95,12 +95,12 @@ def dominant_kernel_roofline(B, dev, tr, x, C=64, S=128, size="B"):
     achieved = flops / t / 1e12
     algo = (2 * S ** 3 * C * 2 * B) + 27 * C * C * 2
     # HBM bytes per launch from the PMC counters of the SAME launch shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # passes, FETCH_SIZE doubled per the gfx950 correction): profiles/r02_pmc_traffic.md, measured at B=2 for 64 -> 64 @128^3 and
-    # linear in B; no counter pass exists for the other shapes -> null
-    traffic = (605.5e6 + 536.9e6) * B / 2 if (C, S) == (64, 128) else None
+    # passes, FETCH_SIZE doubled per the gfx950 correction, counters in KB = 1024 B): profiles/r03_p_pmc_conv_bench_b16.md, measured
+    # at B=16 for 64 -> 64 @128^3 (4 807.8 MB fetched + 4 295.0 MB written) and linear in B; no counter pass exists for the other shapes -> null
+    traffic = (4807.8e6 + 4295.0e6) * B / 16 if (C, S) == (64, 128) else None
     return {"bound": "mfma", "kernel": f"conv_igemm_kernel<bf16,4,4,16,4,11,3,true> (decoder conv3 {C}->{C} @{S}^3)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
-            "traffic": traffic, "traffic_source": "profiles/r02_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1.06 x algorithmic at B=2, scaled to the bench batch)" if traffic else None,
+            "traffic": traffic, "traffic_source": "profiles/r03_p_pmc_conv_bench_b16.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this launch at B=16: 1.06 x algorithmic; scaled to the bench batch)" if traffic else None,
             "algorithmic_bytes": algo, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops,
             "launch_ms_in_step": None if in_step is None else round(in_step, 4),
             "frac_in_step": None if in_step is None else round(flops / (in_step * 1e-3) / MFMA_BF16_PEAK, 4)}

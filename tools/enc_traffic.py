@@ -37,8 +37,8 @@ fam = collections.OrderedDict()
 tot_f = tot_w = 0.0
 for i in range(n):
     k = short(F[0][i]["Kernel_Name"])
-    f = sum(2.0 * float(x[i]["Counter_Value"]) for x in F) / len(F) * 1e3      # KB -> bytes, x2 (gfx950 FETCH_SIZE)
-    w = sum(float(x[i]["Counter_Value"]) for x in W) / len(W) * 1e3
+    f = sum(2.0 * float(x[i]["Counter_Value"]) for x in F) / len(F) * 1024     # KB (1024 B) -> bytes, x2 (gfx950 FETCH_SIZE)
+    w = sum(float(x[i]["Counter_Value"]) for x in W) / len(W) * 1024
     e = fam.setdefault(k, [0, 0.0, 0.0]); e[0] += 1; e[1] += f; e[2] += w
     tot_f += f; tot_w += w
 SIZE = sys.argv[4] if len(sys.argv) > 4 else "B"

@@ -28,7 +28,7 @@ keys = sorted(set(F) | set(W), key=lambda k: -(2 * F[k][1] + W[k][1]))
 tf = tw = 0.0
 print("| kernel family | launches / step | fetched MB / step (2 x FETCH_SIZE) | written MB / step (WRITE_SIZE) |\n|---|---|---|---|")
 for k in keys:
-    f, w = 2e3 * F[k][1] / steps / 1e6, 1e3 * W[k][1] / steps / 1e6
+    f, w = 2 * 1024 * F[k][1] / steps / 1e6, 1024 * W[k][1] / steps / 1e6      # counters in KB = 1024 B (WRITE_SIZE of a known store pins the unit), FETCH_SIZE doubled
     tf += f; tw += w
     if f + w >= 20:
         print(f"| `{k}` | {F[k][0] / steps:.1f} | {f:.0f} | {w:.0f} |")
