@@ -373,6 +373,53 @@ def _conv_case(ops, dtype, cin, cout, k, s, so, B, sparse, bs_out, det=False, se
         close(dw.cpu(), wr.grad, TOL[dtype], f"conv wgrad (det={d})")
 
 
+@pytest.mark.parametrize("case", [(64, 64, (2, 3, 2), 3, 2, 1), (64, 96, (1, 2, 3), 4, 1, 1), (64, 64, (3, 2, 2), 3, 2, 2), (48, 64, (2, 2, 3), 3, 3, 1)])
+def test_conv_block_sparse_live_brick_grids(ops, case):
+    """Block-sparse launches whose bricks lie inside the patches (8- and 16-wide patches) enumerate their live bricks from the
+    active-patch list (conv_igemm.hip `ConvArgs.plist`): forward (stride 1 / 2) with bias and statistics rows, data gradient plain and
+    accumulating, the k1 s2 shortcut's accumulating data gradient (one live class), non-cubic mask grids, NaN in every inactive voxel."""
+    cin, cout, f, bs, B, stride = case
+    dtype = torch.bfloat16
+    so = tuple(v << bs for v in f)
+    si = tuple(v * stride for v in so)
+    bs_in = bs + (1 if stride == 2 else 0)
+    mask = mk_mask(B, f, max(1, (f[0] * f[1] * f[2] * 2) // 5), seed=81)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    m_in, m_out = O.upsample_mask(mask, si).float(), O.upsample_mask(mask, so).float()
+    x = q(rnd(B, cin, *si, seed=82), dtype) * m_in
+    w = q(rnd(cout, cin, 3, 3, 3, seed=83, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    bias = rnd(cout, seed=84)
+    dy = q(rnd(B, cout, *so, seed=85), dtype) * m_out
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv3d(xr, w, bias, stride=stride, padding=1) * m_out
+    yr.backward(dy)
+    nan = lambda t, mm: torch.where(to_cl(mm.expand(B, t.shape[-1], *mm.shape[2:]), dtype) > 0, t, torch.full_like(t, float("nan")))
+    wd = w.to(DEV)
+    y, part = ops.conv3d(ops.CONV_FWD, nan(to_cl(x, dtype), m_in), ops.pack_weight(wd, dtype, False, False), bias.to(DEV), so, 3, stride,
+                         in_mask=mi, in_bshift=bs_in, out_mask=mi, out_bshift=bs, want_partials=True,
+                         out=torch.full((B, *so, cout), float("nan"), device=DEV, dtype=dtype))
+    close(from_cl(y), yr.detach(), TOL[dtype], "live-brick conv fwd", m_out)
+    assert torch.isnan(from_cl(y)[(m_out == 0).expand_as(yr)]).all()       # inactive voxels are never written
+    ys = torch.nan_to_num(y.float()).cpu()
+    rows = part.t[:part.rows].double().sum(0).cpu()
+    want = torch.stack([ys.double().sum((0, 1, 2, 3)), (ys.double() ** 2).sum((0, 1, 2, 3))], 1)
+    assert torch.allclose(rows, want, rtol=2e-4, atol=1e-3), (rows - want).abs().max()
+    wb = ops.pack_weight(wd, dtype, False, True)
+    dx = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), m_out), wb, None, si, 3, stride, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs_in)
+    close(from_cl(dx), xr.grad, TOL[dtype], "live-brick conv dgrad", m_in)
+    base = q(rnd(B, cin, *si, seed=86), dtype) * m_in
+    dx2 = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), m_out), wb, None, si, 3, stride, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs_in,
+                     out=nan(to_cl(base, dtype), m_in), accumulate=True)
+    close(from_cl(dx2), xr.grad + base, 2 * TOL[dtype], "live-brick conv dgrad, accumulating", m_in)
+    if stride == 2:                                          # the 1x1 stride-2 shortcut's data gradient, accumulated onto dx (engine.backward)
+        w1 = q(rnd(cout, cin, 1, 1, 1, seed=87, scale=1.0 / np.sqrt(cin)), dtype)
+        x1 = x.clone().requires_grad_(True)
+        (F.conv3d(x1, w1, None, stride=2) * m_out).backward(dy)
+        dx3 = ops.conv3d(ops.CONV_DGRAD, nan(to_cl(dy, dtype), m_out), ops.pack_weight(w1.to(DEV), dtype, False, True), None, si, 1, 2,
+                         in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs_in, out=dx.clone(), accumulate=True)
+        close(from_cl(dx3), xr.grad + x1.grad, 2 * TOL[dtype], "k1 s2 dgrad accumulated onto the k3 s2 dgrad", m_in)
+
+
 @pytest.mark.parametrize("case", [(256, 256, (4, 4, 4), 1, 2, 1), (128, 192, (5, 6, 7), 0, 3, 1), (512, 256, (3, 4, 5), 1, 2, 1), (384, 128, (6, 5, 4), 0, 1, 1), (256, 64, (2, 2, 3), 1, 1, 1),
                                   (128, 128, (3, 3, 4), 2, 2, 1), (128, 128, (6, 6, 5), 2, 8, 1), (128, 384, (3, 2, 2), 2, 16, 1),
                                   (128, 256, (4, 3, 5), 0, 2, 2), (256, 128, (3, 3, 3), 1, 2, 2), (128, 64, (2, 3, 2), 2, 1, 2), (64, 128, (3, 3, 2), 2, 2, 2), (192, 64, (2, 2, 5), 1, 1, 2)])
