@@ -662,6 +662,8 @@ extern "C" int am_conv3d_partials_rows(int mode, int dtype, int ksize, int strid
   if (rw > *rows) *rows = rw;
   const int rg = conv_gather_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse, out_bshift, n_active);
   if (rg > *rows) *rows = rg;
+  const int rk = conv_k3_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse);
+  if (rk > *rows) *rows = rk;
   return 0;
 }
 
@@ -690,6 +692,15 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
     { const char* e = getenv("AM_CV_DBG"); a.dbg = e ? atoi(e) : 0; }
     if (getenv("AM_CV_NORW")) goto generic;
 #endif
+    a.plist = nullptr;
+    {                                              // dense k3 s1 at decoder sizes: the persistent LDS-DMA kernel (conv_k3.hip)
+      const int rk = conv_k3_launch(mode, dtype, ksize, stride, a, stream);
+      if (rk < 0) return rk;
+      if (rk == 1) {
+        if (partial_rows_written) *partial_rows_written = conv_k3_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, 0);
+        return 0;
+      }
+    }
     const int rc = nb_x ? 0 : conv_rw_launch(mode, dtype, ksize, stride, a, active_list, n_active, stream);   // (the fused reduce lives in conv_igemm_kernel only)
     if (rc < 0) return rc;
     if (rc == 1) {

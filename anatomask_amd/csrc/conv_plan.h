@@ -142,4 +142,9 @@ int conv_gather_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a, 
 int conv_gather_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, int out_sparse, int out_bshift,
                      int n_active);   // partial-sum rows such a launch writes, or 0 when the shape does not qualify
 
+// dense k3 s1 forward / data gradient, bf16, persistent 8-wave LDS-DMA kernel (conv_k3.hip): 1 when it took the launch, 0 when the shape
+// does not qualify; conv_k3_rows = the partial-sum rows such a launch writes (8 per workgroup), or 0
+int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a, void* stream);
+int conv_k3_rows(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cin, int Cout, int masks);
+
 }  // namespace amconv
