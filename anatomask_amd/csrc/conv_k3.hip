@@ -17,7 +17,7 @@
 //     w-shift) + (compile-time immediate of its d- / h-shift): no vector or scalar instruction per read;
 //   * weights arrive per "run" (the three h-taps of one (d, w) shift: they share 6 fragment rows instead of reading 12) in two 12 KB
 //     slots, the run after next is in flight while the current one is contracted;
-//   * one time slot = [X: fragment reads + DMA issue | Y: 48 MFMAs], barrier, [X: 48 MFMAs | Y: fragment reads], barrier.
+//   * between two barriers (one per run and wave) X runs [fragment reads + DMA issue, 48 MFMAs] and Y [48 MFMAs, fragment reads + DMA issue].
 // Epilogue as conv_igemm.hip (bias, optional eval-mode BatchNorm scale/shift + skip + activation, 16-byte stores); the per-channel
 // (sum, sum of squares) of the STORED values are kept per lane over all bricks of the workgroup and reduced once at the end (8 rows per
 // workgroup), deterministic.
@@ -38,7 +38,8 @@ constexpr int KBRICKB = KNROW * 64;               // 69 120 bytes per slab buffe
 constexpr int KNPIECE = 68;                       // 16-row DMA pieces (1 KB each); the last one is anchored at row 1064 (rewrites 8 rows)
 constexpr int KWSLOT = 3 * 64 * 64;               // one run of weights: 3 taps x 64 couts x 64 B
 constexpr int KLDS_W = 2 * KBRICKB;
-constexpr int KLDS = KLDS_W + 2 * KWSLOT;         // 162 816 of 163 840
+constexpr int KLDS_TAB = KLDS_W + 2 * KWSLOT;     // 162 816: per-channel epilogue constants of the workgroup's channel tile (bias | scale | shift, 64 floats each)
+constexpr int KLDS = KLDS_TAB + 768;              // 163 584 of 163 840
 constexpr int K3_MIN_UNITS = 512;                 // below two units per CU the brick kernel of conv_igemm.hip fills the chip better
 
 struct K3Args {
@@ -56,6 +57,16 @@ struct K3Args {
 
 #define K3_LDSP(off) ((__attribute__((address_space(3))) void*)(lds + (off)))
 
+// wave-uniform values the compiler cannot PROVE uniform (results of the vector ALU's integer division, 64-bit offset chains) must be made
+// provably so before they enter a buffer descriptor: otherwise every buffer operation is wrapped in a "waterfall" loop (v_readfirstlane x 4,
+// compare, s_and_saveexec, op, loop: cdna_hip_programming.md T20 -- the deferred stores took ~800 cycles each that way)
+__device__ __forceinline__ int k3_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename P> __device__ __forceinline__ P* k3_uni_ptr(P* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (P*)(((unsigned long long)hi << 32) | lo);
+}
+
 // (unit, slab) + the unit's brick / channel tile, packed (all wave-uniform: these live in SGPRs across the whole walk)
 struct Item { int u, k, c0, c1; };                  // c0 = bw | bh << 8 | bd << 16 (brick indices), c1 = b | ytile << 8
 #define IT_Q0W(it) (((it).c0 & 255) * KBW)
@@ -64,7 +75,9 @@ struct Item { int u, k, c0, c1; };                  // c0 = bw | bh << 8 | bd <<
 #define IT_B(it) ((it).c1 & 255)
 #define IT_CO0(it) (((it).c1 >> 8) * 64)
 
-template <int NS>
+// EP: the fused store epilogue (eval-mode BatchNorm scale / shift, skip tensor, activation: the teacher's decoder) is its own instantiation --
+// its scale / shift registers would push the plain kernel over 256.  ST: the statistics rows (16 more registers), likewise
+template <int NS, bool EP, bool ST>
 __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   static_assert(NS == 4, "64-channel output tiles");
   constexpr int VS = 4, NT = 16 * NS;
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
     const int bw_ = br % a.nbw; br /= a.nbw;
     const int bh_ = br % a.nbh; br /= a.nbh;
     const int bd_ = br % a.nbd;
-    it.c0 = bw_ | (bh_ << 8) | (bd_ << 16); it.c1 = (br / a.nbd) | (yt << 8);
+    it.c0 = k3_uni(bw_ | (bh_ << 8) | (bd_ << 16)); it.c1 = k3_uni((br / a.nbd) | (yt << 8));
   };
   auto advance = [&](Item& it) {
     if (it.k + 1 < a.nslab) { ++it.k; return; }
@@ -112,7 +125,22 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
 #pragma unroll
   for (int xw = 0; xw < 3; ++xw) bx[xw] = (wave * KPLANE + r16 + xw) * 64 + ((g ^ (((r16 + xw) >> 2) & 1) * 2) << 4);
 
-  // ---- DMA issue (X waves)
+  // source brick, DMA source: piece p = wave + 8 k covers rows 16 p .. 16 p + 15 (the last one, p = 67, rows 1064 .. 1079); waves 0-3 own
+  // 9 pieces, waves 4-7 own 8; lane -> (row, chunk position).  Per piece and lane: the byte offset from the brick's first haloed voxel and
+  // a 6-bit code of the brick faces the row lies on.
+  unsigned pl[9], pbits[2] = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int p = wave + 8 * k;
+    const int row0 = p * 16 < KNROW - 16 ? p * 16 : KNROW - 16;
+    const int rho = row0 + (lane >> 2);
+    const int z = rho / KPLANE, rem = rho - z * KPLANE, yy = rem / KEW, xx = rem - yy * KEW;
+    pl[k] = (unsigned)((((z * a.H + yy) * a.W + xx) * a.Cin + (((lane & 3) ^ (((xx >> 2) & 1) * 2)) * 8)) * 2);
+    const unsigned code = (z == 0 ? 1u : 0u) | (z == KED - 1 ? 2u : 0u) | (yy == 0 ? 4u : 0u) | (yy == KEH - 1 ? 8u : 0u) | (xx == 0 ? 16u : 0u) | (xx == KEW - 1 ? 32u : 0u);
+    pbits[k / 5] |= code << (6 * (k % 5));
+  }
+
+  // ---- DMA issue (weights: X waves; brick pieces: Y waves)
   auto issue_weights = [&](const Item& it, const int run, const int slot) __attribute__((always_inline)) {
     // run = zd * 3 + xw; its taps th = 0..2 are the h-shifts; X wave wq brings cout tile wq of each tap
     const int zd = run / 3, xw = run - zd * 3;
@@ -126,96 +154,117 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, K3_LDSP(KLDS_W + slot * KWSLOT + th * (NT * 64) + wq * 1024), 16, wlane, so, 0, 0);
     }
   };
-  // brick pieces of item `it` into slab buffer `sbuf`: X wave wq owns pieces wq, wq + 4, ... (17 of them); [k0, k1) of those
+  // brick pieces [k0, k1) of this wave for item `it` into slab buffer `sbuf`.  Everything about a piece that depends on the lane only was
+  // computed once (pl[], pbits[]); per piece: 3 vector instructions.
   auto issue_pieces = [&](const Item& it, const int sbuf, const int k0, const int k1) __attribute__((always_inline)) {
     const int q0d = IT_Q0D(it), q0h = IT_Q0H(it), q0w = IT_Q0W(it);
-    int dbase = q0d - 1; dbase = dbase < 0 ? 0 : dbase;
-    // (the lane's (z, y, x) of a piece are lane constants; recomputed per piece -- ~20 vector instructions in a phase that waits for the
-    // other half's MFMAs anyway -- instead of living in 17+ registers for the whole kernel: `lz` is a zero the compiler cannot see through)
-    int lz; asm volatile("v_mov_b32 %0, 0" : "=v"(lz));
-    const size_t plane_elems = (size_t)a.H * a.W * a.Cin;
-    const size_t left = (size_t)(a.D - dbase) * plane_elems * 2;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.x + ((size_t)IT_B(it) * a.D + dbase) * plane_elems), 0, (int)(left < 0x7fffff00ull ? left : 0x7fffff00ull), 0x00020000);
+    // which faces of the haloed brick lie outside the volume (D % 8 == H % 4 == W % 16 == 0): bit 0 z == 0, 1 z == 9, 2 y == 0, 3 y == 5, 4 x == 0, 5 x == 17
+    const unsigned m = (q0d == 0 ? 1u : 0u) | (q0d + KBD == a.D ? 2u : 0u) | (q0h == 0 ? 4u : 0u) | (q0h + KBH == a.H ? 8u : 0u) |
+                       (q0w == 0 ? 16u : 0u) | (q0w + KBW == a.W ? 32u : 0u);
+    // descriptor anchored at the brick's first haloed voxel (before the tensor for the first brick: those lanes are out of range anyway)
+    const long long org = ((((long long)IT_B(it) * a.D + (q0d - 1)) * a.H + (q0h - 1)) * a.W + (q0w - 1)) * (long long)a.Cin;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)k3_uni_ptr(a.x + org), 0, 0x7fffff00, 0x00020000);
 #pragma unroll
     for (int k = k0; k < k1; ++k) {
-      const int p = wq + 4 * k;
-      const int row0 = p * 16 < KNROW - 16 ? p * 16 : KNROW - 16;
-      const int rho = row0 + (lane >> 2) + lz;
-      const int z = rho / KPLANE, rem = rho - z * KPLANE, yy = rem / KEW, xx = rem - yy * KEW;
-      const int d = q0d - 1 + z, h = q0h - 1 + yy, w_ = q0w - 1 + xx;
-      const bool ok = (unsigned)d < (unsigned)a.D && (unsigned)h < (unsigned)a.H && (unsigned)w_ < (unsigned)a.W;
-      unsigned vo = ok ? (unsigned)(((((d - dbase) * a.H + h) * a.W + w_) * a.Cin + (((lane & 3) ^ (((xx >> 2) & 1) * 2)) * 8)) * 2) : OOB;
+      const unsigned bad = pbits[k / 5] & (m << (6 * (k % 5)));
+      unsigned vo = bad ? OOB : pl[k];
 #ifdef AM_ABLATE
       if (a.dbg & 2) vo = OOB;
 #endif
+      const int p = wave + 8 * k;
+      const int row0 = p * 16 < KNROW - 16 ? p * 16 : KNROW - 16;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, K3_LDSP(sbuf * KBRICKB + row0 * 64), 16, vo, (unsigned)(it.k * 64), 0, 0);
     }
   };
 
   // ---- epilogue state
   f32x4 acc[NS][VS];
-  float st1[NS][4], st2[NS][4];                          // per-lane running (sum, sum of squares) of the stored values of channel (tile i, row r)
+  // per-lane running (sum, sum of squares) of the stored values, FOLDED over lane pairs: the even lane of a pair holds channel (tile 2h, row r),
+  // the odd lane channel (tile 2h + 1, row r), each summed over both lanes' voxels -- 16 registers instead of 32 (the unfolded form spilled)
+  float f1[NS / 2][4], f2[NS / 2][4];
 #pragma unroll
-  for (int i = 0; i < NS; ++i)
+  for (int h = 0; h < NS / 2; ++h)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { st1[i][r] = 0.f; st2[i][r] = 0.f; }
-  const bool want_stats = a.partials != nullptr;
+    for (int r = 0; r < 4; ++r) { f1[h][r] = 0.f; f2[h][r] = 0.f; }
+  const unsigned oddm = (lane & 1) ? 0xffffffffu : 0u;
+#ifdef AM_ABLATE
+  const bool want_stats = ST && a.partials != nullptr && !(a.dbg & 32);      // (32: stamps without the statistics work)
+#else
+  const bool want_stats = ST && a.partials != nullptr;
+#endif
   bf16_t* __restrict__ yg = a.y;
   const float act_slope = a.ep_act == AM_ACT_LRELU ? 0.01f : (a.ep_act == AM_ACT_RELU6 ? 0.f : 1.f);
   const float act_hi = a.ep_act == AM_ACT_RELU6 ? 6.f : __builtin_inff();
-  const bool fused = a.ep_scale != nullptr || a.ep_res != nullptr || a.ep_act != AM_ACT_NONE;
+  constexpr bool fused = EP;
   typedef __attribute__((ext_vector_type(4))) __bf16 bfx4;
   typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
   typedef __attribute__((ext_vector_type(8))) float f32x8;
 
-  // per-channel-tile statistics rows: flushed when the workgroup moves to another channel tile and at the end
+  // the wave's statistics row, written once at the end of the walk (the channel tile of a workgroup never changes)
   auto flush_stats = [&](const int co0) __attribute__((always_inline)) {
     float* part = a.partials + ((size_t)blockIdx.x * 8 + wave) * a.Cout * 2;
+#define K3_DPP_ADD(V, CTRL) V += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, V), CTRL, 0xF, 0xF, true))
 #pragma unroll
-    for (int i = 0; i < NS; ++i)
+    for (int h = 0; h < NS / 2; ++h)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float s1 = row16_sum(st1[i][r]), s2 = row16_sum(st2[i][r]);
-        const int c = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4 + r;
-        // (own row, one adder per address: deterministic; the atomic executes at the memory side, behind the prologue's zero fill)
-        if (r16 == 0 && c < a.Cout) { atomicAdd(part + c * 2, s1); atomicAdd(part + c * 2 + 1, s2); }
-        st1[i][r] = 0.f; st2[i][r] = 0.f;
+        float s1 = f1[h][r], s2 = f2[h][r];
+        // sum over the 8 lanes of the 16-lane row that have this lane's parity: xor 2, rotate by 4, rotate by 8
+        K3_DPP_ADD(s1, 0x4E); K3_DPP_ADD(s1, 0x124); K3_DPP_ADD(s1, 0x128);
+        K3_DPP_ADD(s2, 0x4E); K3_DPP_ADD(s2, 0x124); K3_DPP_ADD(s2, 0x128);
+        const int c = co0 + h * 32 + g * 8 + (r16 & 1) * 4 + r;     // (even lane: tile 2h, odd lane: tile 2h + 1)
+        if (r16 < 2) { part[c * 2] = s1; part[c * 2 + 1] = s2; }
       }
+#undef K3_DPP_ADD
   };
 
-  auto epilogue = [&](const int pc0, const int pc1) __attribute__((always_inline)) {
+  // D % 8 == H % 4 == W % 16 == Cout % 64 == 0 (k3_qualifies): every voxel / channel of a unit is in range, so the stores are unpredicated
+  // buffer stores -- descriptor anchored at the wave's first output voxel (scalar), lane constant offset, per-row scalar offset: no
+  // vector address arithmetic at all (the first version spent ~3 000 cycles per unit and wave half on 64-bit address math and store predicates).
+  // The stores themselves are DEFERRED: a finished unit is converted to its stored form (8 x 16 bytes per lane, `pk`) in the phase that
+  // opens the next unit, and its 8 store instructions (+ the statistics of those values) go out one per L phase over the next unit's first
+  // 8 runs -- issued back to back they drain at ~12 B/clk/CU (2 700 cycles per unit and wave half, with the other half's MFMAs waiting at
+  // the barrier: 13 % of the kernel).
+  const unsigned olane = (unsigned)((r16 * a.Cout + g * 8) * 2);
+  const unsigned orow = (unsigned)(a.W * a.Cout * 2);
+  u32x4 pk[VS][NS / 2];
+  long long pk_off = 0;                                  // element offset of the pending unit's first output voxel of this wave (wave-uniform)
+  auto finish_unit = [&](const int pc0, const int pc1) __attribute__((always_inline)) {
     Item it; it.c0 = pc0; it.c1 = pc1;
-    const int co0 = IT_CO0(it), q0d = IT_Q0D(it), q0h = IT_Q0H(it), q0w = IT_Q0W(it), ib = IT_B(it);
+    const int co0 = IT_CO0(it);
+    pk_off = ((((long long)IT_B(it) * a.D + (IT_Q0D(it) + wave)) * a.H + IT_Q0H(it)) * a.W + IT_Q0W(it)) * (long long)a.Cout + co0;
+    // per-channel constants from the LDS table (global loads here would put a `vmcnt` wait into this phase)
     f32x4 bia[NS], esc[NS], esh[NS];
+    if (a.bias) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      const int co = co0 + (i >> 1) * 32 + g * 8 + (i & 1) * 4;
-      bia[i] = (a.bias && co < a.Cout) ? *(const f32x4*)(a.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-      const bool okc = a.ep_scale && co < a.Cout;
-      esc[i] = okc ? *(const f32x4*)(a.ep_scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
-      esh[i] = okc ? *(const f32x4*)(a.ep_shift + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < NS; ++i) bia[i] = *(const f32x4*)(lds + KLDS_TAB + ((i >> 1) * 32 + g * 8 + (i & 1) * 4) * 4);
     }
-    const int od = q0d + wave;
+    if (EP && a.ep_scale) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        esc[i] = *(const f32x4*)(lds + KLDS_TAB + 256 + ((i >> 1) * 32 + g * 8 + (i & 1) * 4) * 4);
+        esh[i] = *(const f32x4*)(lds + KLDS_TAB + 512 + ((i >> 1) * 32 + g * 8 + (i & 1) * 4) * 4);
+      }
+    }
+    if (EP && a.ep_res) {                                  // the skip tensor's chunks land in pk and are replaced by the results
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)k3_uni_ptr(a.ep_res + pk_off), 0, 0x7fffff00, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < VS; ++j)
+#pragma unroll
+        for (int h = 0; h < NS / 2; ++h) pk[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rr, olane, j * orow + h * 64, 0);
+    }
 #pragma unroll
     for (int j = 0; j < VS; ++j) {
-      const int oh = q0h + j, ow = q0w + r16;
-      const bool inr = od < a.D && oh < a.H && ow < a.W;
-      const size_t ovox = ((size_t)(ib * a.D + od) * a.H + oh) * a.W + ow;
-      bf16_t* dstv = yg + ovox * a.Cout + co0 + g * 8;
 #pragma unroll
       for (int h = 0; h < NS / 2; ++h) {
-        f32x4 o0 = acc[2 * h][j] + bia[2 * h], o1 = acc[2 * h + 1][j] + bia[2 * h + 1];
-        bf16_t* dst = dstv + h * 32;
-        const bool wr = inr && co0 + h * 32 + g * 8 < a.Cout;
+        f32x4 o0 = acc[2 * h][j], o1 = acc[2 * h + 1][j];
+        if (a.bias) { o0 += bia[2 * h]; o1 += bia[2 * h + 1]; }
         if (fused) {
-          f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-          if (a.ep_res && wr) {
-            const f32x8 f = __builtin_convertvector(*(const bfx8*)(a.ep_res + (dst - yg)), f32x8);
-            r0 = f32x4{f[0], f[1], f[2], f[3]}; r1 = f32x4{f[4], f[5], f[6], f[7]};
-          }
           if (a.ep_scale) { o0 = o0 * esc[2 * h] + esh[2 * h]; o1 = o1 * esc[2 * h + 1] + esh[2 * h + 1]; }
-          o0 += r0; o1 += r1;
+          if (a.ep_res) {
+            const f32x8 f = __builtin_convertvector(__builtin_bit_cast(bfx8, pk[j][h]), f32x8);
+            o0 += f32x4{f[0], f[1], f[2], f[3]}; o1 += f32x4{f[4], f[5], f[6], f[7]};
+          }
           if (a.ep_act != AM_ACT_NONE) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -225,49 +274,90 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
           }
         }
         const bfx4 p0 = __builtin_convertvector(o0, bfx4), p1 = __builtin_convertvector(o1, bfx4);
-        const bfx8 pk = __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7);
+        pk[j][h] = __builtin_bit_cast(u32x4, __builtin_shufflevector(p0, p1, 0, 1, 2, 3, 4, 5, 6, 7));
+        acc[2 * h][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[2 * h + 1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  // chunk c = 2 j + h of the pending unit: one 16-byte store per lane (+ the statistics of the stored values)
+  auto store_chunk = [&](const int c, const bool tail) __attribute__((always_inline)) {
+    const int j = c >> 1, h = c & 1;
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)k3_uni_ptr(yg + pk_off), 0, 0x7fffff00, 0x00020000);
 #ifdef AM_ABLATE
-        if (!(a.dbg & 1))
+    if (!(a.dbg & 1))
 #endif
-        if (wr) { if (a.nt_store) __builtin_nontemporal_store(pk, (bfx8*)dst); else *(bfx8*)dst = pk; }
-        if (want_stats) {
-          const f32x8 s = __builtin_convertvector(pk, f32x8);        // the STORED values
+    {
+      if (a.nt_store) __builtin_amdgcn_raw_buffer_store_b128(pk[j][h], ry, olane, j * orow + h * 64, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(pk[j][h], ry, olane, j * orow + h * 64, 0);
+      // A 16-byte store's data registers must not be rewritten in the next cycles.  hipcc inserts the wait states only for stores whose
+      // soffset is an immediate; with the row offset in an SGPR (chunks 2..5) it emits none, and the TAIL flush -- convert, store, convert
+      // into the same registers -- stored corrupted values in ~7 % of those chunks (found by tools/k3_check.py: NaNs in the last unit of
+      // every workgroup, rows 1 and 2 of each plane, plain instantiation only: the others have statistics code between two stores).
+      // (the asm holds the data registers live across the wait states: nothing can be scheduled into them in between)
+      if (tail) asm volatile("s_nop 4" : "+v"(pk[j][h]) :: "memory");
+    }
+    if (want_stats) {
+      // the STORED values: words 0, 1 = channels 0..3 of tile 2h (rows r), words 2, 3 = those of tile 2h + 1.  A lane keeps the tile of its
+      // parity and gives the other one to its pair lane (quad_perm [1, 0, 3, 2]).  Bitwise selects on the packed words (v_bfi_b32): a
+      // `odd ? v[4 + r] : v[r]` on the unpacked vector becomes a dynamic element index -- an 8-way compare / select chain per value.
+      const u32x4 wv = pk[j][h];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v0 = wr ? s[r] : 0.f, v1 = wr ? s[4 + r] : 0.f;
-            st1[2 * h][r] += v0; st2[2 * h][r] += v0 * v0;
-            st1[2 * h + 1][r] += v1; st2[2 * h + 1][r] += v1 * v1;
-          }
+      for (int q = 0; q < 2; ++q) {
+        const unsigned kw = (wv[2 + q] & oddm) | (wv[q] & ~oddm), gw = (wv[q] & oddm) | (wv[2 + q] & ~oddm);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int r = 2 * q + e;
+          const float keep = __uint_as_float(e ? (kw & 0xffff0000u) : (kw << 16)), give = __uint_as_float(e ? (gw & 0xffff0000u) : (gw << 16));
+          f1[h][r] += keep; f2[h][r] += keep * keep;
+          f1[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+          const float g2 = give * give;
+          f2[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, g2), 0xB1, 0xF, 0xF, true));
         }
       }
     }
   };
 
   // ---- prologue: this wave's statistics row starts at zero; first weights run and first slab
-  if (want_stats) {
+  if (want_stats && a.ny > 1) {                          // (channels of the other tiles: this workgroup contributes nothing to them)
     float* part = a.partials + ((size_t)blockIdx.x * 8 + wave) * a.Cout * 2;
     for (int c = lane; c < a.Cout * 2; c += 64) part[c] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if (isX) {
-    issue_weights(cur, 0, 0);
-    issue_pieces(cur, 0, 0, 17);
+  if (tid < 64) {                                        // (the channel tile of a workgroup never changes: the grid is a multiple of ny)
+    const int c = IT_CO0(cur) + tid;
+    ((float*)(lds + KLDS_TAB))[tid] = a.bias ? a.bias[c] : 0.f;
+    ((float*)(lds + KLDS_TAB))[64 + tid] = a.ep_scale ? a.ep_scale[c] : 1.f;
+    ((float*)(lds + KLDS_TAB))[128 + tid] = a.ep_scale ? a.ep_shift[c] : 0.f;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (isX) { issue_weights(cur, 0, 0); issue_pieces(cur, 0, 0, 9); }
+  else issue_pieces(cur, 0, 0, 8);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (!isX) __builtin_amdgcn_s_barrier();               // Y runs one time slot behind X from here on
 
+#ifdef AM_ABLATE
+  // diagnostic stamps (AM_K3_DBG & 16): cycles this wave spends in its L phases, waiting at the barrier behind them, in its M phases and
+  // at the barrier behind those, summed over the walk; written as raw integers into the wave's statistics row
+  unsigned tL = 0, tWL = 0, tM = 0, tWM = 0, tE = 0, t_prev = 0;
+  unsigned long long rt0 = 0;
+  const bool stamps = (a.dbg & 16) != 0;
+#define K3_STAMP(ACC) if (stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ACC += (unsigned)t_ - t_prev; t_prev = (unsigned)t_; }
+  if (stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); t_prev = (unsigned)t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0) :: "memory"); }
+#else
+#define K3_STAMP(ACC)
+#endif
   int par = 0, sb = 0;                                   // weight slot of the current run, slab buffer of the current item
   int pc0 = 0, pc1 = 0; bool have_prev = false;         // the finished unit whose epilogue is due
+  bool spend = false;                                    // its 8 stores are pending: one per L phase of this slab's runs 0..7
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int j = 0; j < VS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   while (true) {
-    if (cur.k == 0) {
-      if (have_prev) {
-        epilogue(pc0, pc1);
-        if (want_stats && (pc1 >> 8) != (cur.c1 >> 8)) flush_stats((pc1 >> 8) * 64);
-      }
-#pragma unroll
-      for (int i = 0; i < NS; ++i)
-#pragma unroll
-        for (int j = 0; j < VS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    spend = false;
+    if (cur.k == 0 && have_prev) {
+      finish_unit(pc0, pc1);                             // (also zeroes the accumulators)
+      spend = true;
+      K3_STAMP(tE);
     }
     const bool has_next = nxt.u < a.nunit;
     int bxc[3];
@@ -285,25 +375,31 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       for (int th = 0; th < 3; ++th)
 #pragma unroll
         for (int i = 0; i < NS; ++i) af[th][i] = *(const u32x4*)(lds + wbase + th * (NT * 64) + i * 1024);
-      int npend = 0;                                     // brick pieces issued after the weights in this L phase (compile time)
+      // DMA issue.  X: W(run + 1) into the slot Y finished reading one slot ago (it has this phase and the M phase that follows to land),
+      // then its share of the next slab (9 pieces over runs 0..7), then a deferred store.  Y: a deferred store, then its share of the next
+      // slab (8 pieces over runs 0..6; retired at the end of M(7): X reads that slab two time slots later).
+      const int pk0 = run == 0 ? 0 : (run == 1 ? 1 : run + 1);          // first piece of this phase: 0 | 1 2 | 3 | 4 | ...
+      const int npx = run == 1 ? 2 : (run < 8 ? 1 : 0);                 // pieces X issues in this phase (9 in all, the last in run 7)
+      const int npy = run == 1 ? 2 : (run < 7 ? 1 : 0);                 // pieces Y issues (8 in all, the last in run 6)
       if (isX) {
         if (run < 8) issue_weights(cur, run + 1, par ^ 1);
         else if (has_next) issue_weights(nxt, 0, par ^ 1);
-        if (has_next) {
-          // 17 pieces per X wave over runs 1..7 (none in run 0: the previous brick's epilogue shares that phase; none in run 8:
-          // the slab must have landed when its last M phase ends)
-          if (run == 1) issue_pieces(nxt, sb ^ 1, 0, 3);
-          else if (run == 2) issue_pieces(nxt, sb ^ 1, 3, 6);
-          else if (run == 3) issue_pieces(nxt, sb ^ 1, 6, 9);
-          else if (run == 4) issue_pieces(nxt, sb ^ 1, 9, 11);
-          else if (run == 5) issue_pieces(nxt, sb ^ 1, 11, 13);
-          else if (run == 6) issue_pieces(nxt, sb ^ 1, 13, 15);
-          else if (run == 7) issue_pieces(nxt, sb ^ 1, 15, 17);
-        }
+        if (has_next && npx > 0) issue_pieces(nxt, sb ^ 1, pk0, pk0 + npx);
+        if (spend && run < 8) store_chunk(run, false);   // (behind the weights: the counted wait below leaves it in flight)
+      } else {
+        if (spend && run < 8) store_chunk(run, false);
+        if (has_next && npy > 0) issue_pieces(nxt, sb ^ 1, pk0, pk0 + npy);
       }
-      npend = run == 0 || run == 8 ? 0 : (run <= 3 ? 3 : 2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      // ONE barrier per run and wave.  Between two barriers X runs [L(n) M(n)] and Y runs [M(n - 1) L(n)]: X fetches while Y multiplies, then
+      // the other way round.  What the barrier orders: every X wave's weights of run n + 1 have landed (its counted `vmcnt` wait sits in front
+      // of it) before anyone reads them; Y's reads of the weight slot of run n -- and, at a slab's end, of the slab buffer -- are complete
+      // (its `lgkmcnt(0)` sits in front of it) before X's DMA refills them in the next interval.  X's own reads are consumed by its MFMAs.
+      K3_STAMP(tL);
+      if (!isX) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        K3_STAMP(tWL);
+      }
       // ---------------- M: 48 MFMAs
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -318,14 +414,25 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
           for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<bf16_t>(af[th][i], brow[j + th], acc[i][j]);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      // X: the weights of the next run (issued in this run's L phase) must have landed; Y: the next slab, before the barrier that ends M(7)
+      // X: the weights of the next run must have landed -- everything but what it issued behind them in this run's L phase (pieces, a
+      // deferred store); at the end of M(8) the whole next slab.  Y: at the end of M(7) its share of the next slab (a store issued in L(7) is
+      // the youngest operation and stays in flight).
       if (isX) {
-        // the weights of the next run (issued in this run's L phase, BEFORE its brick pieces) must have landed: all but the npend youngest
-        // (no next item: no pieces were issued, the weights are the youngest)
-        if (has_next && npend == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else if (has_next && npend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        const int nbehind = (has_next ? npx : 0) + ((spend && run < 8) ? 1 : 0);
+        if (nbehind == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nbehind == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (nbehind == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      } else if (run == 7) {
+        if (spend) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      __builtin_amdgcn_s_barrier();
+      K3_STAMP(tM);
+      if (isX) {
+        __builtin_amdgcn_s_barrier();
+        K3_STAMP(tWM);
+      }
       par ^= 1;
     }
     sb ^= 1;
@@ -333,9 +440,19 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
     if (!has_next) break;
     cur = nxt; advance(nxt);
   }
-  epilogue(pc0, pc1);
+  finish_unit(pc0, pc1);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) store_chunk(c, true);
   if (want_stats) flush_stats((pc1 >> 8) * 64);
-  if (isX) __builtin_amdgcn_s_barrier();                // (Y's extra barrier of the prologue)
+#ifdef AM_ABLATE
+  if (stamps && a.partials) {
+    K3_STAMP(tE);
+    unsigned long long rt1; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1) :: "memory");
+    unsigned* row = (unsigned*)(a.partials + ((size_t)blockIdx.x * 8 + wave) * a.Cout * 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) { row[0] = tL; row[1] = tWL; row[2] = tM; row[3] = tWM; row[4] = tE; row[5] = (unsigned)(rt1 - rt0); }
+  }
+#endif
 }
 
 }  // namespace
@@ -350,7 +467,9 @@ static int k3_grid(int B, int D, int H, int W, int Cout, int* units) {
   static int cached = 0;
   if (!cached) { hipDeviceProp_t p; int dev = 0; (void)hipGetDevice(&dev); if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cached = p.multiProcessorCount; else cached = 256; (void)hipGetLastError(); }
   cus = cached;
-  return *units < cus ? *units : cus;
+  // a multiple of the channel-tile count: a workgroup's units (u, u + G, ...) then all have the same channel tile
+  const int G = *units < cus ? *units : cus;
+  return G - G % ny > 0 ? G - G % ny : ny;
 }
 
 static bool k3_qualifies(int mode, int dtype, int ksize, int stride, int D, int H, int W, int Cin, int Cout, bool masks) {
@@ -389,9 +508,16 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
 #ifdef AM_ABLATE
   { const char* e = getenv("AM_K3_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
-  auto kern = conv_k3_kernel<4>;
+  const bool ep = a.ep_scale || a.ep_res || a.ep_act != AM_ACT_NONE;
+  if (ep && a.partials) return 0;                  // (no caller fuses a store epilogue AND asks for statistics: conv_igemm.hip serves it)
+  auto kern = ep ? conv_k3_kernel<4, true, false> : (a.partials ? conv_k3_kernel<4, false, true> : conv_k3_kernel<4, false, false>);
   static PerDeviceOnce lds_cap;
-  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  lds_cap.run([&](int) {
+    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+  });
   AM_LAUNCH(kern, dim3(G), dim3(512), KLDS, (hipStream_t)stream, a);
   AM_CHECK_LAUNCH();
   return 1;

@@ -331,6 +331,71 @@ def test_conv_fwd_dgrad_wgrad(ops, dtype, case, sparse):
     close(dw.cpu(), wr.grad, TOL[dtype], "conv wgrad")
 
 
+# ------------------------------------------------------------------ persistent LDS-DMA kernel (conv_k3.hip, round 4)
+# Dense k3 s1 forward / data gradient in bf16 with >= 512 units (8x4x16 bricks x 64-channel tiles) take the 8-wave persistent kernel:
+# P/decoder3D.py:20-22 (the decoder's conv3x3x3 pairs) at training sizes.  Cases cover one / two / three / four channel slabs, one / two /
+# three channel tiles (the grid is a multiple of the tile count: 255 workgroups for three), a unit count that is not a multiple of the grid,
+# volume borders on every face, bias, the statistics rows and the fused store epilogue.
+K3_CASES = [(64, 64, (64, 64, 64), 1), (32, 64, (32, 64, 128), 1), (128, 128, (32, 32, 64), 2), (64, 64, (64, 64, 80), 1), (96, 192, (40, 48, 48), 1)]
+
+
+@pytest.mark.parametrize("case", K3_CASES)
+def test_conv_k3_persistent_kernel_fwd_dgrad_stats(ops, case):
+    cin, cout, S, B = case
+    dtype = torch.bfloat16
+    x = q(rnd(B, cin, *S, seed=71), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=72, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    bias = rnd(cout, seed=73)
+    dy = q(rnd(B, cout, *S, seed=74), dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv3d(xr, w, bias, padding=1)
+    yr.backward(dy)
+    wd = w.to(DEV)
+    y, part = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), ops.pack_weight(wd, dtype, False, False), bias.to(DEV), S, 3, 1, want_partials=True)
+    units = B * (S[0] // 8) * (S[1] // 4) * (S[2] // 16) * (cout // 64)
+    ny = cout // 64
+    assert units >= 512 and part.rows == 8 * (256 - 256 % ny), "the launch must have taken conv_k3_kernel (8 rows per workgroup)"
+    close(from_cl(y), yr.detach(), TOL[dtype], "conv_k3 fwd")
+    # statistics rows == a separate pass over the stored output
+    st_a, st_b = ops.NormStats(cout, DEV), ops.NormStats(cout, DEV)
+    part.reduce(sums=st_a.sums)
+    ops.chan_stats(y, None, 0, st_b)
+    ref = st_b.sums.cpu().sum(0)
+    assert (st_a.sums.cpu()[0] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    # data gradient (the weight tap index is mirrored, the packed weight transposed)
+    dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), ops.pack_weight(wd, dtype, False, True), None, S, 3, 1)
+    close(from_cl(dx), xr.grad, TOL[dtype], "conv_k3 dgrad")
+
+
+def test_conv_k3_persistent_kernel_fused_epilogue(ops):
+    """act(conv * scale + shift + res) in the store of the persistent kernel (the teacher's decoder convs at 128^3 / 64^3)."""
+    dtype = torch.bfloat16
+    B, cin, cout, S = 1, 64, 64, (64, 64, 64)
+    x = q(rnd(B, cin, *S, seed=81), dtype)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=82, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    sc, sh = rnd(cout, seed=83).abs() + 0.5, rnd(cout, seed=84)
+    res = q(rnd(B, cout, *S, seed=85), dtype)
+    conv = F.conv3d(x, w, None, padding=1)
+    wp = ops.pack_weight(w.to(DEV), dtype, False, False)
+    bc = lambda t: t.view(1, -1, 1, 1, 1)
+    y1 = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, S, 3, 1, ep_scale=sc.to(DEV), ep_shift=sh.to(DEV), ep_act=ops.ACT_RELU6)
+    close(from_cl(y1), torch.clamp(conv * bc(sc) + bc(sh), 0, 6), TOL[dtype], "conv_k3 + bn + relu6")
+    y2 = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, S, 3, 1, ep_scale=sc.to(DEV), ep_shift=sh.to(DEV), ep_res=to_cl(res, dtype))
+    close(from_cl(y2), conv * bc(sc) + bc(sh) + res, TOL[dtype], "conv_k3 + bn + res")
+    y3 = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), wp, None, S, 3, 1, ep_res=to_cl(res, dtype), ep_act=ops.ACT_LRELU)
+    close(from_cl(y3), F.leaky_relu(conv + res, 0.01), TOL[dtype], "conv_k3 + res + lrelu")
+
+
+def test_conv_k3_persistent_kernel_is_deterministic(ops):
+    """Two launches on the same inputs give the same bits, output and statistics rows (fixed unit -> workgroup map, one adder per row)."""
+    dtype = torch.bfloat16
+    x = to_cl(q(rnd(1, 64, 64, 64, 64, seed=91), dtype), dtype)
+    wp = ops.pack_weight(q(rnd(64, 64, 3, 3, 3, seed=92, scale=0.03), dtype).to(DEV), dtype, False, False)
+    y1, p1 = ops.conv3d(ops.CONV_FWD, x, wp, None, (64, 64, 64), 3, 1, want_partials=True)
+    y2, p2 = ops.conv3d(ops.CONV_FWD, x, wp, None, (64, 64, 64), 3, 1, want_partials=True)
+    assert torch.equal(y1, y2) and torch.equal(p1.t[:p1.rows], p2.t[:p2.rows])
+
+
 # ------------------------------------------------------------------ kernel branches only STUNet-L / STUNet-H reach
 # (P/pretrain_AnatoMask_DDP.py:222-229: depth 2/3, dims 64..1024 / 96..1536, patches 160^3 / 192^3 -> 10^3 / 12^3 grids of
 # one-voxel patches at level 4, 20- / 24-wide decoder grids, 96-channel level 0).  Every case: forward, data gradient and weight

@@ -33,6 +33,8 @@ def timed(fn, name, flops):
 
 fl = 2.0 * B * S ** 3 * C * C * 27
 if what in ("fwd", "all"):
-    timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (S, S, S), 3, 1, out=y), "conv fwd 64->64 @128^3", fl)
+    # AM_CB_STATS=1: with the statistics epilogue (the launch the training step runs: the student's decoder conv feeds a BatchNorm)
+    st = bool(int(os.environ.get("AM_CB_STATS", "0")))
+    timed(lambda: ops.conv3d(ops.CONV_FWD, x, wp, None, (S, S, S), 3, 1, out=y, want_partials=st), "conv fwd 64->64 @128^3" + (" + statistics" if st else ""), fl)
 if what in ("wgrad", "all"):
     timed(lambda: ops.conv3d_wgrad(ops.CONV_FWD, x, dy, 3, 1), "conv wgrad 64x64 @128^3", fl)
