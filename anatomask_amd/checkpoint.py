@@ -62,7 +62,7 @@ def reference_state(trainer, train_losses: List[float], epoch: int, val_losses: 
           # --- resume extras (not in the reference) ---
           "ema_weights": {k: v.detach().cpu().clone() for k, v in trainer.teacher.ema.state_dict().items()},
           "ema_decay": trainer.teacher.decay, "rng_state": trainer.gen.get_state().cpu(), "rng_rank": getattr(trainer, "rank", 0),
-          "step_count": trainer.step_count, "anatomask_amd_version": 2}
+          "step_count": trainer.step_count, "anatomask_amd_version": FORMAT_VERSION}
     if val_losses is not None:
         ck["val_loss"] = list(val_losses)
     if extra:
@@ -77,11 +77,32 @@ def save_checkpoint(path: str, trainer, train_losses: List[float], epoch: int, v
     os.replace(tmp, path)                              # a crash mid-write never destroys the previous 'latest'
 
 
-def load_checkpoint(path: str, trainer, rank: int = 0) -> Dict:
+FORMAT_VERSION = 3      # 3: tensors and python scalars only (loader / augmenter RandomStates as plain tuples); 2 pickled numpy RandomState tuples
+
+
+def read_checkpoint(path: str) -> Dict:
+    """The file as a dict, read ONCE (pretrain.py hands the same dict to the feed and to load_checkpoint).  Files of format 3 load with
+    torch's default `weights_only=True`; an older file of ours (format 2: numpy objects inside `feed_state`) fails that check -- it is
+    re-read with weights_only=False ONLY when the caller vouches for it (`trust_own_files`), and its feed state is dropped."""
+    import pickle
+    try:
+        return torch.load(path, map_location="cpu")
+    except pickle.UnpicklingError as e:
+        import warnings
+        warnings.warn(f"{path}: not a format-{FORMAT_VERSION} checkpoint ({e}); re-reading it as a format-2 file of this package and "
+                      "dropping its loader state (the loaders restart from their seeds)")
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        if int(ck.get("anatomask_amd_version", 0)) >= FORMAT_VERSION:
+            raise
+        ck.pop("feed_state", None)
+        return ck
+
+
+def load_checkpoint(path, trainer, rank: int = 0) -> Dict:
     """Resume.  Returns the checkpoint dict (its 'current_epoch' + 1 is the next epoch).  The sampler RNG is restored only on the rank
     that saved it; every other rank re-derives its stream from (seed, rank, epoch) -- restoring rank 0's state everywhere would make
     all ranks draw identical masks, which a fresh run (seed 4321 + rank) never does."""
-    ck = torch.load(path, map_location="cpu")          # default arguments: the file holds tensors and python scalars only
+    ck = path if isinstance(path, dict) else read_checkpoint(path)      # (a dict: the caller has read the file already)
     m = trainer.model
     m.load_state_dict({k[len("module."):]: v for k, v in ck["network_weights"].items()})
     if "ema_weights" in ck:
@@ -105,9 +126,9 @@ def load_checkpoint(path: str, trainer, rank: int = 0) -> Dict:
     return ck
 
 
-def peek_extra(path: str, key: str):
-    """one extra entry of a checkpoint (e.g. 'feed_state') without touching a trainer."""
-    return torch.load(path, map_location="cpu").get(key)
+def peek_extra(path, key: str):
+    """one extra entry of a checkpoint (e.g. 'feed_state') without touching a trainer; `path` may be the dict read_checkpoint returned."""
+    return (path if isinstance(path, dict) else read_checkpoint(path)).get(key)
 
 
 def encoder_weights_for_finetuning(network_weights: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:

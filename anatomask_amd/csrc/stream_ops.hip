@@ -1729,6 +1729,9 @@ inline int rows_threads(const RowGeo& r) { return r.rpp * r.rowchunks; }
                                                         else AM_LAUNCH((KERN_<float, 256>), GRID_, dim3(256), 0, ST_, __VA_ARGS__); } while (0)
 #define DISPATCH_T(dtype, CALL_F32, CALL_BF16) do { if ((dtype) == AM_DT_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
 #define CHK_C(C) do { if ((C) % 8 || (C) > 2048 || (C) <= 0) return -1; } while (0)
+// entry points without a 512-thread instantiation (stem convs, projection head: Walk<T> kernels launched with 256 threads) refuse fp32 rows
+// wider than 1024 channels, as layer_ops.hip does -- with 256 threads such a row leaves every thread idle and the output untouched
+#define CHK_C_NARROW(C) do { CHK_C(C); if (dtype != AM_DT_BF16 && (C) > 1024) return -1; } while (0)
 
 extern "C" {
 
@@ -1942,7 +1945,7 @@ int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void*
 int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int C, int ksize, const uint8_t* mask, int bshift,
                      int fd, int fh, int fw, const float* w, const float* bias, void* y, float* partials,
                      const int32_t* active_list, int n_active, int* partial_rows_written, void* stream) {
-  CHK_C(C);
+  CHK_C_NARROW(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, false, B, D, H, W, C, mask, bshift, fd, fh, fw);
   const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
@@ -1978,7 +1981,7 @@ int am_stem_conv_fwd(int dtype, const float* x, int B, int D, int H, int W, int 
 int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, int H, int W, int C, int ksize,
                        const uint8_t* mask, int bshift, int fd, int fh, int fw, float* dw_accum, float* db_accum,
                        const int32_t* active_list, int n_active, float* det_workspace, long det_workspace_floats, void* stream) {
-  CHK_C(C);
+  CHK_C_NARROW(C);
   if (ksize != 1 && ksize != 3) return -2;
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
@@ -2024,7 +2027,7 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
 
 int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b, const float* pre_scale, const float* pre_shift,
                 float* rec, void* stream) {
-  CHK_C(C);
+  CHK_C_NARROW(C);
   if ((pre_scale == nullptr) != (pre_shift == nullptr)) return -1;
   hipStream_t st = (hipStream_t)stream;
   const int nb = (int)((nvox + 255) / 256);
@@ -2037,7 +2040,7 @@ int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, cons
 int am_proj_norm_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, const float* gamma, const float* beta,
                      const float* mean, const float* rstd, const float* scale, double* workspace, float* coef, void* dx,
                      float* dgamma_accum, float* dbeta_accum, float* dw_accum, float* db_accum, void* stream) {
-  CHK_C(C);
+  CHK_C_NARROW(C);
   if (!x || !drec || !w || !gamma || !beta || !mean || !rstd || !scale || !workspace || !coef || !dx || !dgamma_accum || !dbeta_accum ||
       !dw_accum || !db_accum || nvox <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
@@ -2055,7 +2058,7 @@ int am_proj_norm_bwd(int dtype, const void* x, const float* drec, long nvox, int
 
 int am_proj_bwd(int dtype, const void* x, const float* drec, long nvox, int C, const float* w, void* dx, float* dw_accum,
                 float* db_accum, float* det_workspace, long det_workspace_floats, void* stream) {
-  CHK_C(C);
+  CHK_C_NARROW(C);
   hipStream_t st = (hipStream_t)stream;
   const int vpw = pick_vpw(nvox, C, dtype, true);
   const int nb = nblk(nvox, vpw);

@@ -107,6 +107,8 @@ class PatchLoader3D:
         self.final = tuple(int(v) for v in (final_patch_size if final_patch_size is not None else patch_size))
         self.need_to_pad = [self.patch[d] - self.final[d] for d in range(3)]
         self.p_fg, self.rs, self.pin, self.pool = oversample_foreground_percent, np.random.RandomState(seed), pin_memory, pool
+        import threading
+        self.lock = threading.Lock()          # held while a batch draws from self.rs: rng_snapshot() sees the generator at a batch boundary
         self.keys = dataset.keys()
 
     def _force_fg(self, j: int) -> bool:                       # base_data_loader.py:47-51
@@ -136,7 +138,17 @@ class PatchLoader3D:
     def __iter__(self):
         return self
 
+    def rng_snapshot(self):
+        """np.random.RandomState.get_state() of this loader, never in the middle of a batch's draws (the prefetch thread that owns the
+        loader holds `lock` while it assembles a batch: key array and position are captured together)."""
+        with self.lock:
+            return self.rs.get_state()
+
     def __next__(self):
+        with self.lock:
+            return self._next_locked()
+
+    def _next_locked(self):
         data_all = seg_all = None
         held = None
         props, sel = [], [self.keys[i] for i in self.rs.choice(len(self.keys), self.B, replace=True)]
@@ -271,22 +283,70 @@ class DeviceAugmenter:
         return out
 
 
+def gpu_numa_cpus(device_index: int) -> Optional[List[int]]:
+    """CPUs of the NUMA node the GPU `device_index` hangs off (sysfs: /sys/bus/pci/devices/<bus id>/numa_node ->
+    /sys/devices/system/node/node<N>/cpulist), or None when the platform does not say (single-node hosts report -1).
+    One process per GPU: a rank's loader threads and its pinned host buffers belong next to ITS GPU's PCIe root -- on an 8-GPU node the
+    other socket's memory costs a hop over the inter-socket link for every H2D batch (P/pretrain_AnatoMask_DDP.py:260-295 runs its
+    workers wherever the scheduler puts them)."""
+    try:
+        import torch
+        bus = torch.cuda.get_device_properties(device_index).pci_bus_id if hasattr(torch.cuda.get_device_properties(device_index), "pci_bus_id") else None
+        cands = []
+        if isinstance(bus, str):
+            cands.append(bus.lower())
+        elif bus is not None:
+            pr = torch.cuda.get_device_properties(device_index)
+            cands.append(f"{getattr(pr, 'pci_domain_id', 0):04x}:{int(bus):02x}:{getattr(pr, 'pci_device_id', 0):02x}.0")
+        for c in cands:
+            f = f"/sys/bus/pci/devices/{c}/numa_node"
+            if os.path.exists(f):
+                node = int(open(f).read().strip())
+                if node < 0:
+                    return None
+                return parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read())
+    except Exception:
+        return None
+    return None
+
+
+def parse_cpulist(txt: str) -> List[int]:
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)."""
+    out: List[int] = []
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
 class PrefetchLoader:
     """Background producers around a batch iterator factory (the role of LimitedLenWrapper / NonDetMultiThreadedAugmenter with
     num_cached = 6, P/pretrain_AntoMask.py:343-345): `n_workers` threads each own a loader (their own RandomState: the reference's
     workers are unseeded and unordered too) and push batches into one bounded queue.  numpy crops / copies / np.load release the
     GIL, so threads scale; batches arrive in completion order."""
 
-    def __init__(self, make_loader, n_workers: int = 4, num_cached: int = 6):
+    def __init__(self, make_loader, n_workers: int = 4, num_cached: int = 6, cpus: Optional[List[int]] = None):
+        """cpus: CPU ids the worker threads are pinned to (gpu_numa_cpus of the rank's GPU), None = wherever the scheduler puts them."""
         import queue
         import threading
         self.q = queue.Queue(maxsize=num_cached)
         self._stop = threading.Event()
+        self.cpus = list(cpus) if cpus else None
         self.threads = [threading.Thread(target=self._run, args=(make_loader, w), daemon=True) for w in range(n_workers)]
         for t in self.threads:
             t.start()
 
     def _run(self, make_loader, w):
+        if self.cpus:
+            try:
+                os.sched_setaffinity(0, set(self.cpus))     # (pid 0 = the calling thread on Linux)
+            except OSError:
+                pass
         it = iter(make_loader(w))
         while not self._stop.is_set():
             try:

@@ -530,11 +530,19 @@ def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: M
 
 
 def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo,
-             tape: Tape, drec: torch.Tensor, after_group=None):
+             tape: Tape, drec: torch.Tensor, after_group=None, join_before_hook: bool = True):
     """Accumulates parameter gradients into G (fp32, torch layout).  `after_group(tag)` is called when every gradient of a group has
     been ENQUEUED (main stream, or the side stream for the weight gradients): tags 'proj', 'dec3' .. 'dec0', 'densify',
-    'stage4.<b>' .. 'stage0.0' in that order (DDP overlap hook).  The hook must order its work behind BOTH streams (the trainer
-    issues its collectives from the side stream behind a main-stream event); the main stream is not joined before the hook."""
+    'stage4.<b>' .. 'stage0.0' in that order (DDP overlap hook).
+    join_before_hook=True (default, what SparK._after_group hooks get): the main stream waits for the side stream's weight gradients
+    before every hook call, so a hook may read G on the current stream.  False (the trainer): no join -- the hook itself must order
+    its work behind BOTH streams (the trainer issues its collectives from the side stream behind a main-stream event)."""
+    if after_group is not None and join_before_hook:
+        user_hook = after_group
+
+        def after_group(tag, _h=user_hook, _dev=inp.device):
+            _join_side(_dev)
+            _h(tag)
     dproj = decoder_backward(spec, W, G, pk, tape, drec, after_group)
     dfeat = densify_backward(spec, W, G, pk, mask, tape, dproj)
     if after_group:

@@ -49,7 +49,7 @@ def rng_state_to_plain(rs) -> dict:
     """numpy RandomState (MT19937) state as torch tensors / python scalars only: the checkpoint must stay loadable by the
     reference's hand-off, a plain `torch.load(fname)` (nnunetv2/run/load_pretrained_weights.py), which is weights_only=True
     from torch 2.6 on and rejects numpy objects anywhere in the file."""
-    name, keys, pos, has_gauss, cached = rs.get_state()
+    name, keys, pos, has_gauss, cached = rs if isinstance(rs, tuple) else rs.get_state()      # (a tuple: a snapshot taken under the loader's lock)
     return {"name": str(name), "keys": torch.from_numpy(keys.astype("int64")), "pos": int(pos), "has_gauss": int(has_gauss),
             "cached_gaussian": float(cached)}
 
@@ -77,14 +77,18 @@ class Feed:
                                                     p_rot=0.2 if augment else 0.0, p_scale=0.2 if augment else 0.0,
                                                     mirror_axes=(0, 1, 2) if augment else ()))
         self.load_state(state)
-        self.pf = PrefetchLoader(lambda w: self.loaders[w], n_workers=workers, num_cached=6)
+        # loader threads next to this rank's GPU (its NUMA node's CPUs), when the platform says which those are
+        from .data import gpu_numa_cpus
+        cpus = gpu_numa_cpus(dev.index if getattr(dev, "index", None) is not None else 0) if getattr(dev, "type", "cpu") == "cuda" else None
+        self.pf = PrefetchLoader(lambda w: self.loaders[w], n_workers=workers, num_cached=6, cpus=cpus)
         self.feed = DeviceFeed(self.pf, dev)
 
     def __next__(self):
         return self.aug(next(self.feed))
 
     def state(self):
-        return {"loader_rng": {int(w): rng_state_to_plain(ld.rs) for w, ld in self.loaders.items()}, "aug_rng": rng_state_to_plain(self.aug.aug.rs)}
+        # (each loader's generator is sampled under that loader's lock, i.e. between two batches of its prefetch thread)
+        return {"loader_rng": {int(w): rng_state_to_plain(ld.rng_snapshot()) for w, ld in self.loaders.items()}, "aug_rng": rng_state_to_plain(self.aug.aug.rs)}
 
     def load_state(self, st):
         for w, s_ in (st or {}).get("loader_rng", {}).items():
@@ -173,7 +177,8 @@ def main(argv=None):
         tr_keys, val_keys = split_cases(PreprocessedDataset(a.data).keys()) if a.plain_spark else (PreprocessedDataset(a.data).keys(), [])
         resumed = None
         if a.resume:                                   # the loaders' generators are restored before their threads start
-            resumed = (checkpoint.peek_extra(a.resume, "feed_state") or {}).get(rank)
+            ck_resume = checkpoint.read_checkpoint(a.resume)       # the file is read ONCE per rank (weights, EMA and Adam state ride in it)
+            resumed = (checkpoint.peek_extra(ck_resume, "feed_state") or {}).get(rank)
         feed = Feed(a.data, tr_keys, a.batch_size, a.input_size, dev, rank, workers, not a.no_augment, seed=1000, state=resumed)
         if a.plain_spark and val_keys:
             val_feed = Feed(a.data, val_keys, a.batch_size, a.input_size, dev, rank, max(1, workers // 4), False, seed=5000)
@@ -182,8 +187,10 @@ def main(argv=None):
         feed = type("Syn", (), {"__next__": lambda s: next(gen)["data"].to(dev, non_blocking=True), "state": lambda s: {}, "load_state": lambda s, st: None,
                                 "close": lambda s: None})()
     start, epoch_loss, val_loss, ema_loss, best_val = 0, [], [], None, 1e9
+    ck_resume = locals().get("ck_resume")
     if a.resume:
-        ck = checkpoint.load_checkpoint(a.resume, trainer, rank)
+        ck = checkpoint.load_checkpoint(ck_resume if ck_resume is not None else a.resume, trainer, rank)
+        ck_resume = None
         start = int(ck["current_epoch"]) + 1
         epoch_loss, val_loss, ema_loss = list(ck.get("train_loss", [])), list(ck.get("val_loss", [])), ck.get("ema_loss")
         best_val = ck.get("best_val_loss", best_val)

@@ -192,7 +192,7 @@ class AnatoMaskTrainer:
         # 5. backward (:435) with overlapped gradient exchange
         m._gflat.zero_()
         self.exchange_log.clear()
-        engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group if self.distributed else None)
+        engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group if self.distributed else None, join_before_hook=False)
         del tape
         self._finish_exchange()
         # 6. clip + AdamW + EMA (:437-440), one pass over the live parameters

@@ -221,6 +221,24 @@ def exchange_report(tr, grad_elems, world, dt, dtn, steps, backend):
             "ms_per_step_without_exchange": round(dtn / steps * 1e3, 3), "exposed_ms": round((dt - dtn) / steps * 1e3, 3)}
 
 
+def ranks_report(world, rank, dist, dev, per_ms, dt_local):
+    """N > 1: what makes the line self-proving -- every rank's device identity (uuid / PCI bus id), its own wall time of the timed window and
+    the median of its per-step HIP-event times, gathered on rank 0.  `ranks_seen` must equal N and the devices must be N DIFFERENT ones."""
+    if dev is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(pr, "uuid", "")) or f"{pr.name}:{getattr(pr, 'pci_bus_id', dev.index)}"
+        ident = f"{ident}|pci{getattr(pr, 'pci_bus_id', '?')}|local{dev.index}"
+    else:
+        ident = f"host-pid{os.getpid()}"
+    mine = {"rank": rank, "device": ident, "window_s": round(dt_local, 4), "step_ms_median": round(sorted(per_ms)[len(per_ms) // 2], 3),
+            "step_ms_min": round(min(per_ms), 3), "step_ms_max": round(max(per_ms), 3)}
+    if world == 1:
+        return [mine]
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return got
+
+
 def timed_window(step, steps, world, dist, dev):
     """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (wall clock, MAX over ranks), with a HIP event
     after every step for the per-step distribution.  dev None: host-only ranks (the gloo dry run), no device calls."""
@@ -244,6 +262,7 @@ def timed_window(step, steps, world, dist, dev):
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)) if gpu else [dt / steps * 1e3] * steps
+    timed_window.local_s = dt                               # this rank's own clock (ranks_report)
     if world > 1:
         tt = torch.tensor([dt], device=dev if gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -290,7 +309,8 @@ def dry_run_launch(a):
         return m._gflat[:1] * tr.grad_scale
     for _ in range(a.warmup):
         step()
-    dt, _, out = timed_window(step, a.steps, world, dist, None)
+    dt, per0, out = timed_window(step, a.steps, world, dist, None)
+    rr = ranks_report(world, rank, dist, None, per0, timed_window.local_s)
     ok = abs(float(out) - sum(range(1, world + 1)) / world) < 1e-6
     tr.distributed = False
     dtn, _, _ = timed_window(step, a.steps, world, dist, None)
@@ -300,6 +320,7 @@ def dry_run_launch(a):
     dist.all_reduce(t)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": a.gpus, "world": world, "rank_sum": t.item(), "backend": "gloo", "mean_gradient_ok": ok,
+                          "ranks_seen": len({r["device"] for r in rr}), "ranks": rr,
                           "exchange": exchange_report(tr, m._live_end, world, dt, dtn, a.steps, "gloo")}), flush=True)
     dist.destroy_process_group()
 
@@ -362,6 +383,7 @@ def main():
     w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     w0.record(); w1.record(); w1.synchronize(); w0.elapsed_time(w1)
     dt, per, out = timed_window(lambda: tr.step(x, epoch=500), a.steps, world, dist, dev)
+    rr = ranks_report(world, rank, dist, dev, per, timed_window.local_s)
     loss = out["loss"].item()
     assert loss == loss and abs(loss) < 1e6, f"non-finite loss {loss}"   # the reference's finite-loss guard (:443-446)
 
@@ -373,7 +395,12 @@ def main():
                "config": {"workload": f"STUNet-{a.size} AnatoMask step, {a.patch}^3 patch, mask_ratio {a.mask_ratio}, {a.dtype} storage/MFMA + fp32 master",
                           "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                           "step": "teacher fwd + sampler + student fwd + loss + bwd + clip + AdamW + EMA"},
-               "final_loss": round(loss, 5), "step_ms_median": round(per[len(per) // 2], 3), "step_ms_min": round(per[0], 3)}
+               "final_loss": round(loss, 5), "step_ms_median": round(per[len(per) // 2], 3), "step_ms_min": round(per[0], 3),
+               # N > 1: the devices that took part (must be N distinct ones), every rank's own clock, and the per-GPU rate to hold against the N = 1 line
+               "ranks_seen": len({r["device"] for r in rr}), "ranks": rr,
+               "value_per_gpu": round(a.batch * a.steps / dt, 4),
+               "rank_step_ms": {"min": min(r["step_ms_median"] for r in rr), "median": sorted(r["step_ms_median"] for r in rr)[len(rr) // 2],
+                                "max": max(r["step_ms_median"] for r in rr)}}
 
     # ---- the same steps fed from pinned host memory through the copy stream (reported beside `value`, never as `value`)
     if not a.no_h2d:

@@ -130,3 +130,26 @@ def test_unpack_dataset_once_and_same_batches(tmp_path):
     assert isinstance(data, np.memmap) and data.shape == (1, 20, 70, 33)
     after = [next(PatchLoader3D(ds, 2, (16, 24, 16), seed=5))["data"] for _ in range(1)]
     assert all(torch.equal(a, b) for a, b in zip(before, after))
+
+
+def test_cpulist_parsing_and_pinned_prefetch_threads():
+    """loader threads pinned to a CPU set (the rank's GPU NUMA node on the GPU box): the kernel's cpulist format, and the affinity the
+    worker threads actually run with."""
+    import os
+    from anatomask_amd.data import PrefetchLoader, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("5") == [5] and parse_cpulist("") == []
+    allowed = sorted(os.sched_getaffinity(0))
+    want = allowed[:1]
+    seen = []
+
+    def make(w):
+        def gen():
+            for i in range(3):
+                seen.append(sorted(os.sched_getaffinity(0)))
+                yield {"data": i}
+        return gen()
+    pf = PrefetchLoader(make, n_workers=2, num_cached=2, cpus=want)
+    got = [next(pf)["data"] for _ in range(4)]
+    pf.close()
+    assert len(got) == 4 and all(s == want for s in seen)
+    assert sorted(os.sched_getaffinity(0)) == allowed          # the calling thread keeps its own mask

@@ -21,11 +21,29 @@ def test_bench_self_launch_two_ranks_gloo():
     assert len(lines) == 1, r.stdout                       # ONE line, from rank 0
     out = json.loads(lines[0])
     ex = out.pop("exchange")
-    assert out == {"dry_run": True, "n_gpus": 2, "world": 2, "rank_sum": 1.0, "backend": "gloo", "mean_gradient_ok": True}
+    ranks = out.pop("ranks")
+    assert out == {"dry_run": True, "n_gpus": 2, "world": 2, "rank_sum": 1.0, "backend": "gloo", "mean_gradient_ok": True, "ranks_seen": 2}
+    assert sorted(r["rank"] for r in ranks) == [0, 1] and len({r["device"] for r in ranks}) == 2 and all(r["window_s"] > 0 for r in ranks)
     # the rank body's N > 1 branches ran for real (gloo): timed window, exchange-off window, the `exchange` record of the JSON line
     assert ex["ranks"] == 2 and ex["backend"] == "gloo" and ex["gradient_bytes_per_step"] > 50e6          # STUNet-S: 13.3 M parameters
     assert ex["collectives_per_step"] >= 4 and ex["largest_collective_bytes"] <= 8 << 20
     assert ex["first_collective_after_tag"].startswith("dec") and ex["ms_per_step_without_exchange"] >= 0
+
+
+@pytest.mark.timeout(400)
+def test_bench_self_launch_eight_ranks_gloo():
+    """The shape of the driver's 8-GPU run, on CPU: 8 ranks, every one seen, the mean of 8 different gradients, one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-launch", "--steps", "2", "--warmup", "1"], capture_output=True,
+                       text=True, timeout=380, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["world"] == 8 and out["ranks_seen"] == 8 and out["rank_sum"] == 28.0 and out["mean_gradient_ok"]
+    assert sorted(r_["rank"] for r_ in out["ranks"]) == list(range(8))
+    assert out["exchange"]["ranks"] == 8 and out["exchange"]["collectives_per_step"] >= 4
 
 
 def test_launch_command_and_noop_under_a_launcher(monkeypatch):

@@ -60,8 +60,8 @@ for (S, C, B) in [(128, 32, 4), (64, 64, 4)]:
     line("layer scale + residual fwd", timed(lambda: L.scale_residual(1, 0, x.data_ptr(), dy.data_ptr(), ga.data_ptr(), y.data_ptr(), None, B, S, S, S, C, mp, bs, *al, st)), 3 * tb)
     yo = torch.empty(B, S // 2, S // 2, S // 2, C, device=dev, dtype=dt)
     idx = torch.empty(B, S // 2, S // 2, S // 2, C, device=dev, dtype=torch.int32)
-    line("max pool k2 s2 fwd (+argmax)", timed(lambda: L.pool3d_fwd(1, 0, x.data_ptr(), yo.data_ptr(), idx.data_ptr(), B, S, S, S, C, 2, 2, 0, 1, S // 2, S // 2, S // 2, mp, bs, bs - 1, fd, fh, fw, *al, st)), tb + tb // 8 * 3)
-    line("max pool k2 s2 bwd", timed(lambda: L.pool3d_bwd(1, 0, yo.data_ptr(), idx.data_ptr(), y.data_ptr(), B, S, S, S, C, 2, 2, 0, 1, S // 2, S // 2, S // 2, mp, bs, bs - 1, fd, fh, fw, *al, st)), tb + tb // 8 * 3)
+    line("max pool k2 s2 fwd (+argmax)", timed(lambda: L.pool3d_fwd(1, 0, x.data_ptr(), yo.data_ptr(), idx.data_ptr(), B, S, S, S, C, 2, 2, 0, 1, 1, S // 2, S // 2, S // 2, mp, bs, bs - 1, fd, fh, fw, *al, st)), tb + tb // 8 * 3)
+    line("max pool k2 s2 bwd", timed(lambda: L.pool3d_bwd(1, 0, yo.data_ptr(), idx.data_ptr(), y.data_ptr(), B, S, S, S, C, 2, 2, 0, 1, 1, S // 2, S // 2, S // 2, mp, bs, bs - 1, fd, fh, fw, *al, st)), tb + tb // 8 * 3)
     for k in (3, 7):
         w = torch.randn(C, k ** 3, device=dev) * 0.05
         bias = torch.randn(C, device=dev)
