@@ -386,11 +386,46 @@ def _wgrad_into(G, name, mode, x, dy, k, stride, transposed=False, **masks):
     _on_side(x.device, (x, dy), run)
 
 
+def _dec_block_backward(W, G, pk: PackCache, t: dict, g: Optional[torch.Tensor], drec: Optional[torch.Tensor], bias_sum_into: Optional[torch.Tensor]):
+    """backward of ONE UNetBlock (`_dec_block`'s record t): g = gradient wrt the block output (None for a fused-head record: the gradient
+    arrives as drec, through the projection); accumulates the block's parameter gradients into G; returns the gradient wrt the block INPUT.
+    bias_sum_into: densify_projs[i].bias gradient (= per-channel sum of the returned tensor), or None."""
+    q = t["q"]
+    if t.get("head"):
+        dc2 = ops.proj_norm_bwd(t["c2"], t["st2"], drec, W["dense_decoder.proj.weight"].view(-1), W[f"{q}.conv.4.weight"],
+                                W[f"{q}.conv.4.bias"], G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"],
+                                G["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.bias"])
+    else:
+        dc2 = ops.norm_backward(g, None, t["c2"], t["st2"], W[f"{q}.conv.4.weight"], ACT_NONE, None, 0,
+                                G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"])
+    so = tuple(t["r"].shape[1:4])
+    # (bf16) the reduce pass of the BatchNorm backward rides in this dgrad's epilogue: dr and c1 are not re-read for it.  Only where
+    # the dgrad contracts >= 128 channels: the epilogue's work per output tile is fixed (64 activation derivatives per lane), and
+    # on the 32- / 64-channel levels it costs as much as the pass it replaces (32->64 @128^3: 4.15 -> 5.61 ms for a 1.7 ms pass)
+    fuse = ops.FUSED_NORM_BWD_REDUCE and dc2.dtype == torch.bfloat16 and t["st1"].sync_world <= 1 and dc2.shape[-1] >= 128
+    dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1,
+                    norm_bwd=(t["c1"], t["st1"], ACT_RELU6) if fuse else None)
+    dr, red1 = dr if fuse else (dr, None)
+    _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
+    dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
+                            G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"], reduced=red1)
+    du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
+    ptu.finalize(None, sum_accum=G[f"{q}.up_sample.bias"])  # ConvT bias gradient = per-channel sum of du
+    _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
+    si = tuple(t["xin"].shape[1:4])
+    gin = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2, want_partials=bias_sum_into is not None)
+    if bias_sum_into is not None:
+        gin, ptg = gin
+        ptg.finalize(None, sum_accum=bias_sum_into)
+    _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
+    return gin
+
+
 def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Tensor, after_group=None) -> List[Optional[torch.Tensor]]:
     """backward of decoder_forward: accumulates the decoder's parameter gradients into G, returns dproj[i] = gradient wrt
     to_dec[i].  (densify_projs[i].bias for i >= 1 -- the per-channel sum of dproj[i] -- is folded into the ConvT-dgrad epilogue.)"""
     n_dec = len(spec.dec_chs) - 1
-    # ---- projection (fused-head tapes differentiate it together with the last BatchNorm, below)
+    # ---- projection (fused-head tapes differentiate it together with the last BatchNorm, in the block's backward)
     fused_head = bool(tape.dec[n_dec - 1].get("head"))
     g = None
     if not fused_head:
@@ -405,39 +440,12 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
         if tape.recompute:                        # P/GC.py:68: re-run the block forward from its saved input
             _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False, sync=spec.sync_bn, head=bool(t.get("head")))
             tape.dec[i] = None
-        q = t["q"]
         if i + 1 < n_dec:
             dproj[i + 1] = g
-        if t.get("head"):
-            dc2 = ops.proj_norm_bwd(t["c2"], t["st2"], drec, W["dense_decoder.proj.weight"].view(-1), W[f"{q}.conv.4.weight"],
-                                    W[f"{q}.conv.4.bias"], G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"],
-                                    G["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.bias"])
-            if after_group:
-                after_group("proj")
-        else:
-            dc2 = ops.norm_backward(g, None, t["c2"], t["st2"], W[f"{q}.conv.4.weight"], ACT_NONE, None, 0,
-                                    G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"])
-        so = tuple(t["r"].shape[1:4])
-        # (bf16) the reduce pass of the BatchNorm backward rides in this dgrad's epilogue: dr and c1 are not re-read for it.  Only where
-        # the dgrad contracts >= 128 channels: the epilogue's work per output tile is fixed (64 activation derivatives per lane), and
-        # on the 32- / 64-channel levels it costs as much as the pass it replaces (32->64 @128^3: 4.15 -> 5.61 ms for a 1.7 ms pass)
-        fuse = ops.FUSED_NORM_BWD_REDUCE and dc2.dtype == torch.bfloat16 and t["st1"].sync_world <= 1 and dc2.shape[-1] >= 128
-        dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1,
-                        norm_bwd=(t["c1"], t["st1"], ACT_RELU6) if fuse else None)
-        dr, red1 = dr if fuse else (dr, None)
-        _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
-        dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
-                                G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"], reduced=red1)
-        du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
-        ptu.finalize(None, sum_accum=G[f"{q}.up_sample.bias"])  # ConvT bias gradient = per-channel sum of du
-        _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
-        si = tuple(t["xin"].shape[1:4])
-        need_sum = i > 0 and f"densify_projs.{i}.bias" in G        # densify_projs[i].bias gradient = sum of this tensor
-        g = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2, want_partials=bool(need_sum))
-        if need_sum:
-            g, ptg = g
-            ptg.finalize(None, sum_accum=G[f"densify_projs.{i}.bias"])
-        _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
+        need_sum = i > 0 and f"densify_projs.{i}.bias" in G        # densify_projs[i].bias gradient = sum of the block-input gradient
+        g = _dec_block_backward(W, G, pk, t, g, drec, G[f"densify_projs.{i}.bias"] if need_sum else None)
+        if t.get("head") and after_group:
+            after_group("proj")
         if after_group:
             after_group(f"dec{i}")
     dproj[0] = g
@@ -465,6 +473,50 @@ def densify_backward(spec: Spec, W, G, pk: PackCache, mask: MaskInfo, tape: Tape
     return dfeat
 
 
+def _enc_block_backward(W, G, pk: PackCache, inp: torch.Tensor, mask: MaskInfo, t: dict, gout: torch.Tensor, base: Optional[torch.Tensor],
+                        free_saved: bool = False) -> Optional[torch.Tensor]:
+    """backward of ONE BasicResBlock (`_enc_block`'s record t): gout = gradient wrt the block output (active voxels only); accumulates
+    the block's parameter gradients into G; returns the gradient wrt the block INPUT (None for the Cin = 1 stem block).
+    base: first block of a stage -- the gradient the block input already has from its densify branch (accumulated into, and returned), or None."""
+    p, s = t["p"], t["s"]
+    bs = 4 - s
+    y2, a1, y1, out, x = t["y2"], t["a1"], t["y1"], t["out"], t["x"]
+    dpre = torch.empty_like(y2)                      # gradient of the shortcut branch
+    # conv2.bias gradient = sum of dy2 (folded into the apply pass); conv3.bias gradient = sum of dpre = norm2's dbeta
+    dy2 = ops.norm_backward(gout, out, y2, t["st2"], W[f"{p}.norm2.weight"], ACT_LRELU, mask, bs,
+                            G[f"{p}.norm2.weight"], G[f"{p}.norm2.bias"], dres=dpre,
+                            dbeta2=G.get(f"{p}.conv3.bias"), dxsum=G[f"{p}.conv2.bias"])
+    sp = tuple(y2.shape[1:4])
+    da1 = ops.conv3d(CONV_DGRAD, dy2, pk.get(W, f"{p}.conv2.weight", False, True), None, sp, 3, 1,
+                     in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
+    red1 = None           # (the fused norm-backward reduce, ops.conv3d(norm_bwd=...), does not pay on block-sparse tensors: 64->64 @64^3 +0.12 ms for a 0.05 ms pass)
+    _wgrad_into(G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
+    dy1 = ops.norm_backward(da1, None, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
+                            G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"], reduced=red1)
+    stride = t["stride"]
+    if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only
+        ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None)
+        ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), None)
+        return None
+    bsx = bs + (1 if stride == 2 else 0)
+    spx = tuple(x.shape[1:4])
+    _wgrad_into(G, f"{p}.conv1.weight", CONV_FWD, x, dy1, 3, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
+    if free_saved:
+        t["y1"] = t["a1"] = t["y2"] = t["out"] = None      # free as we go
+    if t["first"]:
+        # block input = output map of stage s-1: add onto its densify gradient if it has one
+        gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, stride,
+                        in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=base, accumulate=base is not None)
+        _wgrad_into(G, f"{p}.conv3.weight", CONV_FWD, x, dpre, 1, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
+        ops.conv3d(CONV_DGRAD, dpre, pk.get(W, f"{p}.conv3.weight", False, True), None, spx, 1, stride,
+                   in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=gx, accumulate=True)
+        return gx
+    # identity shortcut
+    gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, 1,
+                    in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
+    return ops.add(gx, dpre, out=gx)
+
+
 def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: MaskInfo, tape: Tape, dfeat, after_group=None):
     """backward of encoder_forward, deep -> shallow.  dfeat[s] = gradient wrt the stage-s output map (active voxels only), or
     None (the stage-0 map feeds only stage 1 on the SparK path: its densify branch is dead)."""
@@ -474,7 +526,6 @@ def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: M
     for t in tape.enc:
         by_stage.setdefault(t["s"], []).append(t)
     for s in reversed(range(spec.n_stage)):
-        bs = 4 - s
         if tape.recompute:                        # P/GC.py:324: re-run the stage forward from its saved input
             xs, recs = tape.enc_in[s], []
             for b in range(spec.depth[s]):
@@ -485,47 +536,15 @@ def encoder_backward(spec: Spec, W, G, pk: PackCache, inp: torch.Tensor, mask: M
         if gout is None:                          # (stand-alone SparseEncoder.forward: the caller used only some of the maps)
             gout = torch.zeros_like(by_stage[s][-1]["out"])
         for t in reversed(by_stage[s]):
-            p = t["p"]
-            y2, a1, y1, out, x = t["y2"], t["a1"], t["y1"], t["out"], t["x"]
-            dpre = torch.empty_like(y2)                      # gradient of the shortcut branch
-            # conv2.bias gradient = sum of dy2 (folded into the apply pass); conv3.bias gradient = sum of dpre = norm2's dbeta
-            dy2 = ops.norm_backward(gout, out, y2, t["st2"], W[f"{p}.norm2.weight"], ACT_LRELU, mask, bs,
-                                    G[f"{p}.norm2.weight"], G[f"{p}.norm2.bias"], dres=dpre,
-                                    dbeta2=G.get(f"{p}.conv3.bias"), dxsum=G[f"{p}.conv2.bias"])
-            sp = tuple(y2.shape[1:4])
-            da1 = ops.conv3d(CONV_DGRAD, dy2, pk.get(W, f"{p}.conv2.weight", False, True), None, sp, 3, 1,
-                             in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
-            red1 = None           # (the fused norm-backward reduce, ops.conv3d(norm_bwd=...), does not pay on block-sparse tensors: 64->64 @64^3 +0.12 ms for a 0.05 ms pass)
-            _wgrad_into(G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
-            dy1 = ops.norm_backward(da1, None, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
-                                    G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"], reduced=red1)
-            stride = t["stride"]
-            if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only
-                ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None)
-                ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), None)
-                if after_group:
-                    after_group(f"stage{s}.{t['b']}")
-                break
-            bsx = bs + (1 if stride == 2 else 0)
-            spx = tuple(x.shape[1:4])
-            _wgrad_into(G, f"{p}.conv1.weight", CONV_FWD, x, dy1, 3, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
-            if tape.recompute:
-                t["y1"] = t["a1"] = t["y2"] = t["out"] = None      # free as we go
-            if t["first"]:
-                # block input = output map of stage s-1: add onto its densify gradient if it has one
-                base = gstage[s - 1]
-                gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, stride,
-                                in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=base, accumulate=base is not None)
-                _wgrad_into(G, f"{p}.conv3.weight", CONV_FWD, x, dpre, 1, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
-                ops.conv3d(CONV_DGRAD, dpre, pk.get(W, f"{p}.conv3.weight", False, True), None, spx, 1, stride,
-                           in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=gx, accumulate=True)
+            gx = _enc_block_backward(W, G, pk, inp, mask, t, gout, gstage[s - 1] if (t["first"] and s > 0) else None, tape.recompute)
+            if t["first"] and s > 0:
                 gstage[s - 1] = gx
-            else:                                            # identity shortcut
-                gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, 1,
-                                in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
-                gout = ops.add(gx, dpre, out=gx)
+            elif gx is not None:
+                gout = gx
             if after_group:
                 after_group(f"stage{s}.{t['b']}")
+            if gx is None:
+                break
     _join_side(inp.device)
 
 

@@ -53,17 +53,21 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def dominant_kernel_roofline(B, dev, tr, x, C=64, S=128, size="B"):
-    """The dominant kernel of the step (profiles/: conv_igemm bf16, 4x4x16 brick, 64 output channels per workgroup) on its largest
-    instance: the first conv of the last decoder block, C -> C at S^3 (P/decoder3D.py:20; C = width / 8: 64 for STUNet-B, 128 for L,
-    192 for H).  Bound: MFMA (AI ~ 1700 flop/B at C = 64).
+    """The dominant kernel of the step (profiles/r04_*_step_kernel_stats_b16.csv: conv_k3_kernel, the persistent 8-wave LDS-DMA kernel of
+    the dense k3 s1 convolutions) on its largest instance: the first conv of the last decoder block, C -> C at S^3 (P/decoder3D.py:20;
+    C = width / 8: 64 for STUNet-B, 128 for L, 192 for H), launched as the training step launches it: WITH the statistics epilogue
+    (`want_partials=True`: the student's BatchNorm reads its sums from the conv).  Bound: MFMA (AI ~ 1700 flop/B at C = 64).
     `launch_ms`: the launch alone (20 back-to-back launches, HIP events on the launch stream); `launch_ms_in_step`: the SAME launch
-    timed by HIP events where it sits inside the training step (student decoder, last block, first conv), median over 3 steps."""
+    timed by HIP events where it sits inside the training step (student decoder, last block, first conv), median over 3 steps;
+    `launch_ms_no_statistics`: the variant without the epilogue sums (the teacher's / the data gradient's launch)."""
     from anatomask_amd import ops
     xx = torch.randn(B, S, S, S, C, device=dev).to(torch.bfloat16)
     w = (torch.randn(C, C, 3, 3, 3, device=dev) * 0.02)
     wp = ops.pack_weight(w, torch.bfloat16, False, False)
     y = torch.empty_like(xx)
-    t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, xx, wp, None, (S, S, S), 3, 1, out=y), iters=20 if size == "B" else 8)
+    it = 20 if size == "B" else 8
+    t = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, xx, wp, None, (S, S, S), 3, 1, out=y, want_partials=True), iters=it)
+    t_plain = time_kernel(lambda: ops.conv3d(ops.CONV_FWD, xx, wp, None, (S, S, S), 3, 1, out=y), iters=it)
     del xx, y
     flops = 2.0 * B * S ** 3 * C * C * 27
     # the same launch inside the step: wrap ops.conv3d for three steps (events only, no synchronisation inside the step)
@@ -94,14 +98,21 @@ def dominant_kernel_roofline(B, dev, tr, x, C=64, S=128, size="B"):
             in_step = ds[len(ds) // 2]
     achieved = flops / t / 1e12
     algo = (2 * S ** 3 * C * 2 * B) + 27 * C * C * 2
-    # HBM bytes per launch from the PMC counters of the SAME launch shape (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    # passes, FETCH_SIZE doubled per the gfx950 correction, counters in KB = 1024 B): profiles/r03_p_pmc_conv_bench_b16.md, measured
-    # at B=16 for 64 -> 64 @128^3 (4 807.8 MB fetched + 4 295.0 MB written) and linear in B; no counter pass exists for the other shapes -> null
-    traffic = (4807.8e6 + 4295.0e6) * B / 16 if (C, S) == (64, 128) else None
-    return {"bound": "mfma", "kernel": f"conv_igemm_kernel<bf16,4,4,16,4,11,3,true> (decoder conv3 {C}->{C} @{S}^3)", "achieved": round(achieved, 2),
+    # HBM bytes per launch: the PMC counters of the SAME launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
+    # doubled per the gfx950 correction, counters in KB = 1024 B), as tools/pmc_k3.sh left them in profiles/r04_pmc_k3.json: measured at
+    # B = 16 for 64 -> 64 @128^3 and linear in B.  No counter pass exists for the other shapes -> null; a missing file is an error, not a constant.
+    traffic = src = None
+    if (C, S) == (64, 128):
+        pj = os.path.join(ROOT, "profiles", "r04_pmc_k3.json")
+        rec = json.load(open(pj))["conv_k3_kernel"]            # (raises if the profile was not committed)
+        traffic = (rec["fetch_bytes"] + rec["write_bytes"]) * B / rec["batch"]
+        src = (f"profiles/r04_pmc_k3.json (tools/pmc_k3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this launch at B={rec['batch']}: "
+               f"{(rec['fetch_bytes'] + rec['write_bytes']) / rec['algorithmic_bytes']:.2f} x algorithmic, {rec['launch_us']:.0f} us under the profiler; scaled to the bench batch)")
+    return {"bound": "mfma", "kernel": f"conv_k3_kernel<4,false,true> (decoder conv3 {C}->{C} @{S}^3, statistics epilogue on)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
-            "traffic": traffic, "traffic_source": "profiles/r03_p_pmc_conv_bench_b16.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this launch at B=16: 1.06 x algorithmic; scaled to the bench batch)" if traffic else None,
+            "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes": algo, "launch_ms": round(t * 1e3, 4), "flop_per_launch": flops,
+            "launch_ms_no_statistics": round(t_plain * 1e3, 4), "frac_no_statistics": round(flops / t_plain / MFMA_BF16_PEAK, 4),
             "launch_ms_in_step": None if in_step is None else round(in_step, 4),
             "frac_in_step": None if in_step is None else round(flops / (in_step * 1e-3) / MFMA_BF16_PEAK, 4)}
 
