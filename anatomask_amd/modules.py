@@ -402,8 +402,12 @@ class SparK(nn.Module):
         self.sparse_encoder, self.dense_decoder, self.sbn = sparse_encoder, dense_decoder, sbn
         self.hierarchy = len(sparse_encoder.enc_feat_map_chs)
         self.densify_norm_str = densify_norm.lower()
-        if self.densify_norm_str != "in":
-            raise NotImplementedError("AnatoMask uses densify_norm='in' (P/pretrain_AntoMask.py:214-217)")
+        # densify_norm other than 'in' (P/AnatoMask.py:44-56: 'bn' / 'ln' / 'gn' / anything else = identity) runs through the sparse layer zoo
+        # in the GENERIC composition (zoo-converted encoders); the fused STUNet engine / trainer are built for the drivers' 'in'
+        # (P/pretrain_AntoMask.py:214-217)
+        if self.densify_norm_str != "in" and isinstance(sparse_encoder.sp_cnn, STUNet):
+            raise NotImplementedError("the fused STUNet path implements densify_norm='in' (what every driver uses); other densify norms run "
+                                      "with zoo-converted encoders (SparseEncoder(<dense backbone>))")
         self.densify_norms, self.densify_projs, self.mask_tokens = nn.ModuleList(), nn.ModuleList(), nn.ParameterList()
         e_widths, d_width = list(sparse_encoder.enc_feat_map_chs), dense_decoder.width
         for i in range(self.hierarchy):
@@ -411,7 +415,18 @@ class SparK(nn.Module):
             p = nn.Parameter(torch.zeros(1, e_width, 1, 1, 1))
             _trunc_normal_(p, std=.02, a=-.02, b=.02)
             self.mask_tokens.append(p)
-            self.densify_norms.append(SparseInstanceNorm(e_width, sparse=True))
+            if self.densify_norm_str == "in":
+                self.densify_norms.append(SparseInstanceNorm(e_width, sparse=True))
+            else:
+                from . import sparse_layers as SL
+                if self.densify_norm_str == "bn":
+                    self.densify_norms.append((SL.SparseSyncBatchNorm3d if self.sbn else SL.SparseBatchNorm3d)(e_width))
+                elif self.densify_norm_str == "ln":
+                    self.densify_norms.append(SL.SparseConvNeXtLayerNorm(e_width, data_format="channels_first", sparse=True))
+                elif self.densify_norm_str == "gn":
+                    self.densify_norms.append(SL.SparseGroupNorm(e_width, e_width, sparse=True))
+                else:
+                    self.densify_norms.append(nn.Identity())
             if i == 0 and e_width == d_width:
                 proj = nn.Identity()
             else:
@@ -514,8 +529,13 @@ class SparK(nn.Module):
         for i, f in enumerate(fea):
             if f is not None and i < len(self.dense_decoder.dec):    # (levels past the decoder's blocks are never read, :170 + decoder3D.py:56-60)
                 n_ = self.densify_norms[i]
-                # pooled sparse InstanceNorm + mask-token fill in one HIP apply pass (and one backward pair), as the fused engine does
-                f = SL._nc(SL._DensifyFn.apply(SL._cl(f), n_.weight, n_.bias, self.mask_tokens[i], n_.eps))
+                if self.densify_norm_str == "in":
+                    # pooled sparse InstanceNorm + mask-token fill in one HIP apply pass (and one backward pair), as the fused engine does
+                    f = SL._nc(SL._DensifyFn.apply(SL._cl(f), n_.weight, n_.bias, self.mask_tokens[i], n_.eps))
+                else:
+                    # P/AnatoMask.py:158-163: the zoo norm (zeros at inactive positions), then the mask token at the inactive positions of
+                    # THIS level's map (the activity mask up-sampled to the map: SL.fill_tokens, one HIP pass forward, one backward)
+                    f = SL.fill_tokens(n_(f), self.mask_tokens[i])
                 pr = self.densify_projs[i]
                 if not isinstance(pr, nn.Identity):
                     f = SL.dense_conv(f, pr.weight, pr.bias, pr.kernel_size[0])
@@ -537,14 +557,31 @@ class SparK(nn.Module):
     @torch.no_grad()
     def generate_mask(self, loss_pred, guide=True, epoch=0, total_epoch=200, generator=None, original_mask=None, keys=None):
         """P/AnatoMask.py:81-135, on device in one kernel (no .cpu().numpy() round trips).  Returns
-        (mask, easy_mask); easy_mask is not consumed by any caller of the reference and is returned as None.
+        (mask, easy_mask); easy_mask (not consumed by any caller of the reference) is what P/AnatoMask.py:116-134 describes, see _easy_mask.
         `keys` (B,L) teacher-forces the random permutation (keys[id] = position); default: device rand."""
         B, L = loss_pred.shape
         ll = self.len_loss_for(L, self.len_keep, epoch, total_epoch, guide)
         if keys is None:
             keys = torch.rand(B, L, device=loss_pred.device, generator=generator)
         m = ops.mask_sampler(loss_pred.float().contiguous(), keys.float().contiguous().to(loss_pred.device), self.len_keep, ll)
-        return m.bool().view(B, 1, self.fmap_h, self.fmap_w, self.fmap_d), None
+        mask = m.bool().view(B, 1, self.fmap_h, self.fmap_w, self.fmap_d)
+        return mask, self._easy_mask(loss_pred, mask, ll)
+
+    def _easy_mask(self, loss_pred, mask, len_loss):
+        """The second output of P/AnatoMask.py:116-134.  What its construction states: the `easy_len = L - len_keep - len_loss` patches
+        whose teacher loss ranks just BELOW the hard band (ascending ranks [len_keep + ... ) i.e. [L - len_loss - easy_len, L - len_loss))
+        are hidden, the other len_keep + len_loss patches are visible; in the random regime (len_loss == 0) it is the mask itself.
+        No driver reads it.  The reference's code for it is not reproducible bit for bit and is not reproduced: it
+        re-creates `ids_shuffle2` inside the per-sample loop (only the LAST sample's row survives), its second slice assignment overwrites
+        part of the first, and it shuffles with the unseeded global numpy generator -- this is the per-sample result those lines describe,
+        which involves no random draw (every patch outside the band is visible).  Host-side bookkeeping on (B, L) booleans."""
+        B, L = loss_pred.shape
+        if len_loss <= 0:
+            return mask.clone()
+        easy_len = (L - self.len_keep) - len_loss
+        ranks = torch.argsort(torch.argsort(loss_pred.float(), dim=1, stable=True), dim=1, stable=True)     # ascending loss rank of every patch
+        hidden = (ranks >= L - len_loss - easy_len) & (ranks < L - len_loss)
+        return (~hidden).view(B, 1, self.fmap_h, self.fmap_w, self.fmap_d)
 
     # ---------------------------------------------------------------- forward
     def reconstruct(self, inp_bchwd: torch.Tensor, active_b1ff: torch.Tensor) -> torch.Tensor:

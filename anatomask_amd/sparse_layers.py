@@ -349,6 +349,38 @@ class _DensifyFn(torch.autograd.Function):
         return dx, dg, db, dt.view(tshape).to(tdtype), None
 
 
+class _FillTokensFn(torch.autograd.Function):
+    """`torch.where(active, x, mask_token)` of P/AnatoMask.py:161-163 for densify norms other than the pooled InstanceNorm (which has its
+    own fused pair, _DensifyFn): one am_norm_apply pass with unit scale / zero shift and the token as fill; backward: the gradient passes
+    through at the active voxels (inactive ones are don't-care for every sparse consumer), the token gradient is the per-channel sum of
+    dy over the INACTIVE voxels = (sum over all) - (sum over the active ones), two am_chan_sum passes."""
+
+    @staticmethod
+    def forward(ctx, x_cl, token):
+        mi = current_mask(x_cl.device)
+        B, D, H, W, C = x_cl.shape
+        bs = _bshift(mi, D)
+        st = ops.NormStats(C, x_cl.device)
+        st.scale.fill_(1.0); st.shift.zero_(); st.mean.zero_(); st.rstd.fill_(1.0)
+        y = ops.norm_apply(x_cl, st, ops.ACT_NONE, mi, bs, fill=token.float().contiguous().view(-1))
+        ctx.cfg = (mi, bs, token.shape, token.dtype, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        mi, bs, tshape, tdtype, C = ctx.cfg
+        dy = dy.contiguous()
+        tot, act = torch.zeros(C, device=dy.device, dtype=torch.float32), torch.zeros(C, device=dy.device, dtype=torch.float32)
+        ops.chan_sum(dy, None, 0, tot)
+        ops.chan_sum(dy, mi, bs, act)
+        return dy, (tot - act).view(tshape).to(tdtype)
+
+
+def fill_tokens(x: torch.Tensor, token: torch.Tensor) -> torch.Tensor:
+    """NCDHW map with zeros at the inactive voxels -> the same map with `token` (1, C, 1, 1, 1) there (the current mask: modules._cur_active)."""
+    return _nc(_FillTokensFn.apply(_cl(x), token))
+
+
 class SparseBatchNorm3d(nn.BatchNorm1d):
     """encoder3D.py:39-40 (sp_bn_forward :17-25): BatchNorm1d over the (N_active, C) matrix -- batch statistics over all active voxels
     of the (local) batch, running statistics with the unbiased variance, eval mode on the running statistics."""

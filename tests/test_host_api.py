@@ -63,3 +63,22 @@ def test_feed_rng_state_is_weights_only_safe_and_round_trips(tmp_path):
     rng_state_from_plain(rs2, ck["feed_state"][0]["loader_rng"][0])
     assert np.array_equal(rs2.uniform(size=5), want[0]) and np.array_equal(rs2.standard_normal(3), want[1])
     assert 1 <= default_workers(8) <= 8 and default_workers(1) >= default_workers(8)
+
+
+def test_easy_mask_is_the_band_below_the_hard_patches():
+    """generate_mask's second output (P/AnatoMask.py:116-134): the `L - len_keep - len_loss` patches ranked just below the hard band are
+    hidden, the other len_keep + len_loss are visible; in the random regime it is the mask itself.  (Host-side: SparK._easy_mask.)"""
+    m = build()
+    L = m.fmap_h * m.fmap_w * m.fmap_d
+    g = torch.Generator().manual_seed(3)
+    loss = torch.rand(2, L, generator=g)
+    ll = m.len_loss_for(L, m.len_keep, 120, 200)
+    assert 0 < ll < L - m.len_keep
+    mask = torch.zeros(2, 1, m.fmap_h, m.fmap_w, m.fmap_d, dtype=torch.bool)
+    easy = m._easy_mask(loss, mask, ll).view(2, L)
+    assert (easy.sum(1) == m.len_keep + ll).all()
+    order = loss.argsort(1)
+    for b in range(2):
+        hidden = set(order[b, m.len_keep:L - ll].tolist())             # ascending ranks [L - ll - easy_len, L - ll), easy_len = L - len_keep - ll
+        assert hidden == set((~easy[b]).nonzero().flatten().tolist())
+    assert torch.equal(m._easy_mask(loss, mask, 0), mask)                # random regime

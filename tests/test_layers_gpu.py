@@ -380,6 +380,48 @@ def test_spark_around_a_mednext_encoder_matches_the_reference(SL, dtype, tol):
             assert np.abs(got - F_[k]).max() <= 2 * tol * max(1.0, np.abs(F_[k]).max()), k
 
 
+@pytest.mark.parametrize("dn", ["bn", "ln", "gn", "none"])
+def test_spark_densify_norm_variants_match_the_reference(SL, dn):
+    """P/AnatoMask.py:44-56: densify_norm 'bn' / 'ln' / 'gn' / anything else (identity) -- the zoo's sparse norms + the mask-token fill
+    (SL.fill_tokens) in the generic composition, against the reference's own SparK run in float64 (tests/golden/spark_mednext_densify.npz,
+    made by tests/golden/make_spark_densify_fixture.py): loss, per-patch l2, and the gradient of every densify-stage parameter (mask
+    tokens, norm affines, projections) within 3x the reference's own fp32-vs-fp64 distance + the fp32 tolerance."""
+    from anatomask_amd import modules as M
+    from tests.helpers import seeded_params, tiny_mednext
+    F_ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spark_mednext_densify.npz"))
+    tol = 5e-4
+    dense = tiny_mednext()
+    dense.get_downsample_ratio = lambda: 16
+    dense.get_feature_map_channels = lambda: [8, 16, 32, 64, 128]
+    enc = M.SparseEncoder(dense, input_size=(64, 64, 64))
+    dec = M.LightDecoder(enc.downsample_ratio, sbn=False, width=128, out_channel=1)
+    model = M.SparK(sparse_encoder=enc, dense_decoder=dec, mask_ratio=0.5, densify_norm=dn, compute_dtype=torch.float32).train()
+    seeded_params(model)
+    model = model.to(DEV)
+    active = torch.from_numpy(F_["active"]).to(DEV)
+    x = torch.from_numpy(np.random.RandomState(11).standard_normal((2, 1, 64, 64, 64)).astype(np.float32)).to(DEV)
+    inp, rec = model(x, active_b1ff=active)
+    loss, l2 = model.forward_loss(inp, rec, active)
+    want = float(F_[f"{dn}.loss"])
+    assert abs(loss.item() - want) <= tol * abs(want), (dn, loss.item(), want)
+    assert np.abs(l2.detach().cpu().numpy() - F_[f"{dn}.l2"]).max() <= 2 * tol * np.abs(F_[f"{dn}.l2"]).max()
+    loss.backward()
+    gtot, seen = float(F_[f"{dn}.gtot"]), 0
+    for n, p in model.named_parameters():
+        key = f"{dn}.gn.{n}"
+        if key not in F_.files:
+            continue
+        seen += 1
+        g = p.grad.reshape(-1).float().cpu()
+        idx = np.linspace(0, g.numel() - 1, min(64, g.numel())).astype(np.int64)
+        want_n, want_s, floor = float(F_[key]), F_[f"{dn}.gs.{n}"], float(F_[f"{dn}.floor.{n}"])
+        bound = 3 * floor + 4 * tol
+        assert abs(float(g.norm()) - want_n) <= bound * max(want_n, 1e-3 * gtot), (dn, n, float(g.norm()), want_n, floor)
+        scale = max(float(np.abs(want_s).max()), 1e-3 * gtot / np.sqrt(g.numel()))
+        assert float(np.abs(g[torch.from_numpy(idx)].numpy() - want_s).max()) <= 2 * bound * scale + 1e-7, (dn, n, floor)
+    assert seen == sum(1 for k in F_.files if k.startswith(f"{dn}.gn."))
+
+
 @pytest.mark.parametrize("name", ["maxpool_k3s2p1", "avgpool_k3s2p1_nopad", "bn_train", "gn_g2", "ln_cf", "ln_cl", "grn", "adaptive_avg", "dwconv7",
                                   "dwconv3s2", "conv3s2", "convnext"])
 def test_layers_in_bf16_storage(SL, name):
