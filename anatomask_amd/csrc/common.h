@@ -13,6 +13,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define AM_DT_F32 0
 #define AM_DT_BF16 1
+#define AM_DT_F32S 2   // fp32 storage, matrix-core products from bf16 hi / lo splits of both operands (see f32s_t)
+
+// fp32 storage with SPLIT products (AM_DT_F32S): tensors are fp32 in memory, exactly as AM_DT_F32; the channel contraction runs on the bf16
+// matrix cores on x = hi + lo (hi = bf16(x), lo = bf16(x - hi): 16 significant bits, |x - hi - lo| <= 2^-17 |x|) with all four partial
+// products (hi hi + hi lo + lo hi + lo lo) accumulated in fp32.  The exact mode's v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate;
+// this one at 1/4 (two 16x16x32 bf16 instructions per 16 fp32 channels).  Same size and layout in memory as float.
+struct f32s_t { float v; };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -28,6 +35,11 @@ template <> struct TT<float> {
   static constexpr int EPC = 4;  // elements per 16-byte chunk
   static __device__ __forceinline__ float ld(const float* p) { return *p; }
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct TT<f32s_t> {
+  static constexpr int EPC = 4;
+  static __device__ __forceinline__ float ld(const f32s_t* p) { return p->v; }
+  static __device__ __forceinline__ void st(f32s_t* p, float v) { p->v = v; }
 };
 template <> struct TT<bf16_t> {
   static constexpr int EPC = 8;
@@ -73,6 +85,28 @@ template <> __device__ __forceinline__ f32x4 mma_chunk<float>(const u32x4& a, co
   for (int s = 0; s < 4; ++s)
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[s]), __uint_as_float(b[s]), acc, 0, 0, 0);
   return acc;
+}
+
+// f32s_t: four floats -> their bf16 hi parts (2 dwords) and lo parts (2 dwords); v_cvt_pk_bf16_f32 (round to nearest even)
+__device__ __forceinline__ void split4_bf16(const u32x4& c, unsigned (&hi)[2], unsigned (&lo)[2]) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bfx2_;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float x0 = __uint_as_float(c[2 * i]), x1 = __uint_as_float(c[2 * i + 1]);
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{x0, x1}), bfx2_));
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    hi[i] = h;
+    lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{r0, r1}), bfx2_));
+  }
+}
+// One chunk MMA of the split mode: the 64-byte LDS row of 16 fp32 channels is [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] (bf16); lane group g
+// supplies chunk g of the A row, chunk (g & 1) of the B row for b1 (hi) and chunk 2 + (g & 1) for b2 (lo):
+//   sum_g A_g . B1_g = (hiA + loA) . hiB,   sum_g A_g . B2_g = (hiA + loA) . loB
+__device__ __forceinline__ f32x4 mma_split(const u32x4& a, const u32x4& b1, const u32x4& b2, f32x4 acc) {
+  typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b1), acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b2), acc, 0, 0, 0);
 }
 
 // sum over the 16 lanes of a DPP row (lanes 16k..16k+15), result in every lane of the row: 4 v_add_f32 with DPP operands

@@ -46,6 +46,10 @@ namespace {
 template <typename T, int BD, int BH, int BW, int NS, int NIT, int TGS = 3, bool HR = false, bool NB = false, bool HT = false>
 __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) void conv_igemm_kernel(ConvArgs a) {
   constexpr int EPC = TT<T>::EPC;
+  // SPL (T = f32s_t, AM_DT_F32S): fp32 in memory, but the staged LDS row of a voxel's 16 channels is [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15]
+  // in bf16 (the split happens once per staged element, here; the weights arrive pre-split from am_pack_weight) and a chunk MMA is two
+  // bf16 matrix instructions on two B fragments (common.h mma_split) -- 4x the rate of the exact fp32 mode
+  constexpr bool SPL = std::is_same<T, f32s_t>::value;
   constexpr int KC = (ROWB / 16) * EPC;                 // channels per slab
   constexpr int MV = BD * BH * BW;
   constexpr int VS = MV / 64;                           // 16-voxel subtiles per wave
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.w_bytes, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   const int cchunk = (tid & 3) * EPC;                    // this thread's channel offset inside the slab
-  const int sdst = (tid >> 2) * LROWB + (tid & 3) * 16;  // LDS byte offset of iteration 0; iteration it adds it*64*LROWB (immediate)
+  const int sdst = (tid >> 2) * LROWB + (tid & 3) * (SPL ? 8 : 16);  // LDS byte offset of iteration 0; iteration it adds it*64*LROWB (immediate)
   const int wtapB = a.Coutp * a.Cinp * (int)sizeof(T);   // bytes per weight tap slice
 
   // ---- per-thread staging plan for the weight groups: chunk idx -> (tap in group [wave-uniform], cout row, chunk) ----
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
 #pragma unroll
     for (int j = 0; j < VS; ++j) {
       const int v = wave * (MV / 4) + j * 16 + r16;
-      bb[j] = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * LROWB + g * 16;
+      bb[j] = (((v / (BW * BH)) * EH + (v / BW) % BH) * EW + v % BW) * LROWB + (SPL ? (g & 1) : g) * 16;
     }
 
     // Software pipeline over the channel slabs: the source brick of slab k+1 and the first weight group of slab k+1 are
@@ -263,7 +267,17 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
       }
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
-        if (((tid + it * 256) >> 2) < nvox) *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
+        if (((tid + it * 256) >> 2) < nvox) {
+          if constexpr (SPL) {                           // this thread's 4 channels: hi pair at +8 c, lo pair at +32 + 8 c of the row
+            typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
+            unsigned h2[2], l2[2];
+            split4_bf16(stg[it], h2, l2);
+            *(u32x2_*)(lds + sdst + it * 64 * LROWB) = u32x2_{h2[0], h2[1]};
+            *(u32x2_*)(lds + sdst + it * 64 * LROWB + 32) = u32x2_{l2[0], l2[1]};
+          } else {
+            *(u32x4*)(lds + sdst + it * 64 * LROWB) = stg[it];
+          }
+        }
       __syncthreads();
       const bool more_slabs = kc + KC < a.Cinp;
       // One weight group = TG taps: straight-line (padding taps multiply zero weights), no per-tap branch, so the fragment reads of
@@ -280,9 +294,12 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
 #pragma unroll
           for (int tr = 0; tr < NTP / 3; ++tr) {
             const int tob = AM_TAP(gi * TG + tr * 3) & 0xFFFFF;
-            u32x4 brow[VS + 2];
+            u32x4 brow[VS + 2], brow2[SPL ? VS + 2 : 1];
 #pragma unroll
-            for (int r = 0; r < VS + 2; ++r) brow[r] = *(const u32x4*)(lds + bb[0] + tob + r * ewb);
+            for (int r = 0; r < VS + 2; ++r) {
+              brow[r] = *(const u32x4*)(lds + bb[0] + tob + r * ewb);
+              if constexpr (SPL) brow2[r] = *(const u32x4*)(lds + bb[0] + tob + r * ewb + 32);
+            }
 #pragma unroll
             for (int th = 0; th < 3; ++th) {
               u32x4 af[NS];
@@ -291,7 +308,10 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
 #pragma unroll
               for (int j = 0; j < VS; ++j)
 #pragma unroll
-                for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], brow[j + th], acc[i][j]);
+                for (int i = 0; i < NS; ++i) {
+                  if constexpr (SPL) acc[i][j] = mma_split(af[i], brow[j + th], brow2[j + th], acc[i][j]);
+                  else acc[i][j] = mma_chunk<T>(af[i], brow[j + th], acc[i][j]);
+                }
             }
           }
         } else {
@@ -305,9 +325,16 @@ __global__ __launch_bounds__(256, (TGS == 2 && BD * BH * BW <= 256) ? 3 : 2) voi
 #pragma unroll
             for (int j = 0; j < VS; ++j) {
               // (16-wide bricks with one d-plane per wave: subtile j is h-row j, so its offset is bb[0] + j rows -- no register per subtile)
-              const u32x4 bf = *(const u32x4*)(lds + ((BW == 16 && MV / 4 == BH * BW) ? bb[0] + j * (EW * LROWB) : bb[j]) + tob);
+              const int bo_ = ((BW == 16 && MV / 4 == BH * BW) ? bb[0] + j * (EW * LROWB) : bb[j]) + tob;
+              const u32x4 bf = *(const u32x4*)(lds + bo_);
+              if constexpr (SPL) {
+                const u32x4 bf2 = *(const u32x4*)(lds + bo_ + 32);
 #pragma unroll
-              for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+                for (int i = 0; i < NS; ++i) acc[i][j] = mma_split(af[i], bf, bf2, acc[i][j]);
+              } else {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) acc[i][j] = mma_chunk<T>(af[i], bf, acc[i][j]);
+              }
             }
           }
         }
@@ -771,7 +798,7 @@ generic:
   a.nt_store = ((size_t)B * Do * Ho * Wo * Cout * 2 >= ((size_t)384 << 20) && !accumulate) || AM_DBG(a, 8);
   hipStream_t st = (hipStream_t)stream;
   if (partial_rows_written) *partial_rows_written = (a.plist ? a.nlive : a.B * a.nbd * a.nbh * a.nbw) * a.nclass;
-  return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, shape, st) : dispatch<float>(P, shape, st);
+  return dtype == AM_DT_BF16 ? dispatch<bf16_t>(P, shape, st) : dtype == AM_DT_F32S ? dispatch<f32s_t>(P, shape, st) : dispatch<float>(P, shape, st);
 }
 
 extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed,

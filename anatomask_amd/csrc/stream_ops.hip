@@ -4,6 +4,7 @@
 // Every kernel walks channels-last rows with one 16-byte chunk per lane (coalesced: consecutive
 // lanes take consecutive chunks of consecutive voxels) and touches only voxels of active patches.
 #include <mutex>
+#include <type_traits>
 #include "common.h"
 #include "../../include/anatomask_hip.h"
 
@@ -1438,11 +1439,37 @@ __global__ __launch_bounds__(256) void rows_fold_kernel(const float* __restrict_
   if (i < n0) dst0[i] += s; else if (dst1) dst1[i - n0] += s;
 }
 
+// ------------------------------------------------------------------ fp32 -> (hi, lo) bf16 planes (AM_DT_F32S weight gradients)
+// x = hi + lo + r, hi = bf16(x), lo = bf16(x - hi), |r| <= 2^-17 |x|: the weight gradient of the split mode is three bf16 contractions
+// (hi hi + hi lo + lo hi) of these planes accumulated into the fp32 gradient (ops.conv3d_wgrad); one streaming pass, 16 bytes per lane in
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long n4) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const u32x4 c = *(const u32x4*)(x + 4 * i);
+    unsigned h2[2], l2[2];
+    split4_bf16(c, h2, l2);
+    *(u32x2_*)(hi + 4 * i) = u32x2_{h2[0], h2[1]};
+    *(u32x2_*)(lo + 4 * i) = u32x2_{l2[0], l2[1]};
+  }
+}
+
 // ------------------------------------------------------------------ weight (un)packing
 // dst[t][r][k] = src[r*sr + k*sk + t] for r < R, k < K, zero in the padding (dst is [taps][Rp][Kp])
 // (fp32 master -> compute dtype, MFMA row-fragment layout, whole tiles so the conv inner loop needs no bounds).
 // One workgroup per (row r, 64 consecutive k): when taps are innermost in the source (sk == taps, the forward
 // pack) the 64*taps source floats are one contiguous run -> coalesced read, LDS transpose, coalesced 128-byte row writes.
+// packed element (row base `rowp`, k): plain for float / bf16; AM_DT_F32S: every 16-channel group of a row is 64 bytes
+// [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] in bf16 (hi = bf16(w), lo = bf16(w - hi)) -- the LDS image conv_igemm's split mode contracts
+template <typename T> __device__ __forceinline__ void pack_store(T* rowp, int k, float v) {
+  if constexpr (std::is_same<T, f32s_t>::value) {
+    bf16_t* g = (bf16_t*)rowp + (k >> 4) * 32 + (k & 15);
+    const bf16_t h = f2bf(v);
+    g[0] = h; g[16] = f2bf(v - bf2f(h));
+  } else {
+    TT<T>::st(rowp + k, v);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int K, int taps,
                                                           long sr, long sk, int Rp, int Kp) {
@@ -1466,7 +1493,7 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 256) {
     const int kk = i % 64, tp = i / 64;
-    if (k0 + kk < Kp) TT<T>::st(dst + ((size_t)tp * Rp + r) * Kp + k0 + kk, tile[kk * taps + tp]);
+    if (k0 + kk < Kp) pack_store<T>(dst + ((size_t)tp * Rp + r) * Kp, k0 + kk, tile[kk * taps + tp]);
   }
 }
 // the same repack for a table of weights: block -> (descriptor by binary search on first_block, row, 64-wide k block)
@@ -1498,7 +1525,7 @@ __global__ __launch_bounds__(256) void pack_weights_batched_kernel(const am_pack
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += 256) {
     const int kk = i % 64, tp = i / 64;
-    if (k0 + kk < d.Kp) TT<T>::st(dst + ((size_t)tp * d.Rp + r) * d.Kp + k0 + kk, tile[kk * taps + tp]);
+    if (k0 + kk < d.Kp) pack_store<T>(dst + ((size_t)tp * d.Rp + r) * d.Kp, k0 + kk, tile[kk * taps + tp]);
   }
 }
 // dst[r*sr + k*sk + t] (+)= src[t][r][k]
@@ -2132,6 +2159,10 @@ int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int tap
   if (Rp < R || Kp < K) return -1;
   dim3 grid(Rp, (Kp + 63) / 64);
   const size_t sm = sizeof(float) * 64 * taps;
+  if (dtype == AM_DT_F32S) {
+    if (Kp % 16) return -1;
+    AM_LAUNCH(pack_weight_kernel<f32s_t>, grid, dim3(256), sm, st, src, (f32s_t*)dst, R, K, taps, stride_r, stride_k, Rp, Kp);
+  } else
   DISPATCH_T(dtype, AM_LAUNCH(pack_weight_kernel<float>, grid, dim3(256), sm, st, src, (float*)dst, R, K, taps, stride_r, stride_k, Rp, Kp),
              AM_LAUNCH(pack_weight_kernel<bf16_t>, grid, dim3(256), sm, st, src, (bf16_t*)dst, R, K, taps, stride_r, stride_k, Rp, Kp));
   AM_CHECK_LAUNCH();
@@ -2141,8 +2172,18 @@ int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int tap
 int am_pack_weights_batched(int dtype, const am_pack_desc* descs, int ndesc, int total_blocks, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (ndesc <= 0 || total_blocks <= 0) return 0;
+  if (dtype == AM_DT_F32S) AM_LAUNCH(pack_weights_batched_kernel<f32s_t>, dim3(total_blocks), dim3(256), 0, st, descs, ndesc);
+  else
   DISPATCH_T(dtype, AM_LAUNCH(pack_weights_batched_kernel<float>, dim3(total_blocks), dim3(256), 0, st, descs, ndesc),
              AM_LAUNCH(pack_weights_batched_kernel<bf16_t>, dim3(total_blocks), dim3(256), 0, st, descs, ndesc));
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_split_bf16(const float* x, void* hi, void* lo, long n, void* stream) {
+  if (n % 4) return -1;
+  long nb = (n / 4 + 255) / 256; if (nb > 16384) nb = 16384;
+  AM_LAUNCH(split_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)hi, (bf16_t*)lo, n / 4);
   AM_CHECK_LAUNCH();
   return 0;
 }

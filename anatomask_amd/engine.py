@@ -171,6 +171,9 @@ class PackCache:
     def get(self, W, name: str, transposed: bool, dgrad: bool) -> torch.Tensor:
         key = (name, dgrad)
         t = self.store.get(key)
+        if t is not None and getattr(t, "split", False) != bool(self.dtype == torch.float32 and ops.F32_SPLIT):
+            self.store.clear(); self.src.clear(); self.table = None; self.dirty = False      # (the fp32 product mode changed: other layout)
+            t = None
         if t is not None and self.src[key].data_ptr() != W[name].data_ptr():    # the master moved (new flat buffer): start over
             self.store.clear(); self.src.clear(); self.table = None; self.dirty = False
             t = None

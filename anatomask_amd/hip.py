@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libanatomask_hip.so")      # the in-tree build; no environment variable redirects the product loader
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "anatomask_hip.h")
 
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F32S = 0, 1, 2
 CONV_FWD, CONV_DGRAD, CONVT_FWD, CONVT_DGRAD = 0, 1, 2, 3
 ACT_NONE, ACT_LRELU, ACT_RELU6 = 0, 1, 2
 

@@ -19,6 +19,18 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+# fp32-storage models: False = exact fp32 products (v_mfma_f32_16x16x4_f32, the parity mode: 1/16 of the bf16 matrix rate);
+# True = AM_DT_F32S: products from bf16 hi / lo splits of both operands with fp32 accumulation (16 significant bits per operand, 1/4 of
+# the bf16 rate in the convolutions, three bf16 passes in the weight gradients).  Set by SparK / AnatoMaskTrainer(f32_split=True) BEFORE the
+# first forward (packed weight copies are made for one of the two); the reference computes in fp32 (AMP = False, P/pretrain_AntoMask.py:239).
+F32_SPLIT = False
+
+
+def _dtc(t: torch.Tensor) -> int:
+    """dtype code of a CONVOLUTION operand (am_conv3d / am_pack_weight / am_packed_dims / am_conv3d_partials_rows)."""
+    return hip.DT_F32S if (t.dtype == torch.float32 and F32_SPLIT) else _dt(t)
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -150,8 +162,9 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_
         R, K, sr, sk = cin, cout, s_in, s_out
     Rp, Kp = packed_dims(dtype, R, K)
     out = torch.empty(taps, Rp, Kp, device=w.device, dtype=dtype)
-    hip.lib().pack_weight(_dt(out), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, Rp, Kp, _stream())
+    hip.lib().pack_weight(_dtc(out), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, Rp, Kp, _stream())
     out.logical = (R, K)
+    out.split = bool(out.dtype == torch.float32 and F32_SPLIT)      # (what the copy was made for: PackCache re-makes it when the mode changes)
     out.pack_args = (R, K, taps, sr, sk, Rp, Kp)
     return out
 
@@ -175,7 +188,8 @@ class PackTable:
         return len(pairs) == self.n and all(p == (w.data_ptr(), o.data_ptr()) for p, (w, o) in zip(self.ptrs, pairs))
 
     def repack(self):
-        hip.lib().pack_weights_batched(hip.DT_BF16 if self.dtype == torch.bfloat16 else hip.DT_F32, self.dev.data_ptr(), self.n, self.blocks, _stream())
+        code = hip.DT_BF16 if self.dtype == torch.bfloat16 else (hip.DT_F32S if F32_SPLIT else hip.DT_F32)
+        hip.lib().pack_weights_batched(code, self.dev.data_ptr(), self.n, self.blocks, _stream())
 
 
 def unpack_grad(dw_packed: torch.Tensor, grad_out: torch.Tensor, transposed_conv: bool, accumulate: bool):
@@ -222,11 +236,12 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
                                part.t.data_ptr(), xp.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), int(nact), _ROWS_ADDR, _stream())
         part.rows = _ROWS_OUT.value
         return out, part
-    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift, _dt(x), Cin, aln) if want_partials else None
+    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift, _dtc(x), Cin, aln) if want_partials else None
     if out is None:
         out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
     rows = _ROWS_OUT
-    hip.lib().conv3d(mode, _dt(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
+    assert getattr(w_packed, "split", False) == bool(x.dtype == torch.float32 and F32_SPLIT), "packed weight copy made for the other fp32 product mode"
+    hip.lib().conv3d(mode, _dtc(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
                      B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
                      in_mask.t.data_ptr() if in_mask else None, in_bshift,
                      out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate),
@@ -263,12 +278,31 @@ def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, strid
     mk = x_mask or y_mask
     mp, fd, fh, fw = _mk(mk)
     ws = _det_workspace(x.device, taps * Cy * Cx) if DETERMINISTIC_WGRAD else None
-    hip.lib().conv3d_wgrad(mode, _dt(x), ksize, stride, x.data_ptr(), dy.data_ptr(), dw.data_ptr(),
-                           B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy,
-                           x_mask.t.data_ptr() if x_mask else None, x_bshift,
-                           y_mask.t.data_ptr() if y_mask else None, y_bshift, fd, fh, fw,
-                           ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream())
+
+    def launch(xx, yy):
+        hip.lib().conv3d_wgrad(mode, _dt(xx), ksize, stride, xx.data_ptr(), yy.data_ptr(), dw.data_ptr(),
+                               B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy,
+                               x_mask.t.data_ptr() if x_mask else None, x_bshift,
+                               y_mask.t.data_ptr() if y_mask else None, y_bshift, fd, fh, fw,
+                               ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream())
+    if x.dtype == torch.float32 and F32_SPLIT:
+        # AM_DT_F32S: dW = X^T dY with X = Xh + Xl, dY = Yh + Yl (bf16 planes, am_split_bf16): three bf16 matrix-core contractions
+        # accumulate into the ONE fp32 gradient (atomics, or the deterministic fold: both add into dw); the lo lo term (2^-16 of the
+        # result) is dropped.  The planes are transient (2 x 2 bytes per element = the size of the fp32 tensor).
+        xh, xl = split_bf16(x)
+        yh, yl = split_bf16(dy)
+        launch(xh, yh); launch(xl, yh); launch(xh, yl)
+        return dw
+    launch(x, dy)
     return dw
+
+
+def split_bf16(x: torch.Tensor):
+    """fp32 tensor -> (hi, lo) bf16 tensors of the same shape: hi = bf16(x), lo = bf16(x - hi) (am_split_bf16)."""
+    x = x.contiguous()
+    hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+    hip.lib().split_bf16(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), _stream())
+    return hi, lo
 
 
 def stem_conv_fwd(x_b1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mask: Optional[MaskInfo], bshift: int,

@@ -19,8 +19,14 @@ from .modules import ModelEma, SparK, ema_decay_for_epoch
 class AnatoMaskTrainer:
     def __init__(self, model: SparK, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  clip: float = 12.0, ema_decay: float = 0.999, total_epochs: int = 1000, guide: bool = True, seed: int = 4321,
-                 process_group=None, distributed: Optional[bool] = None, self_distill: bool = True, deterministic_wgrad: bool = False):
+                 process_group=None, distributed: Optional[bool] = None, self_distill: bool = True, deterministic_wgrad: bool = False,
+                 f32_split: bool = False):
         self.model = model
+        # fp32-storage models only: matrix-core products from bf16 hi / lo splits (ops.F32_SPLIT, AM_DT_F32S) instead of the exact fp32
+        # matrix instruction -- the fast reference-precision mode (the reference recipe is AMP = False, P/pretrain_AntoMask.py:239)
+        self.f32_split = bool(f32_split)
+        from . import ops as _ops
+        _ops.F32_SPLIT = self.f32_split
         self._capturing, self._graph, self._graph_key = False, None, None
         if deterministic_wgrad:
             # convolution weight gradients as per-slot partial sums folded in a fixed order instead of fp32 atomics (am_conv3d_wgrad's
@@ -158,6 +164,7 @@ class AnatoMaskTrainer:
         Returns device tensors only: {'loss','grad_norm','mask','recon_loss','rec_loss'}."""
         m, t = self.model, self.teacher.ema
         spec = m.spec
+        ops.F32_SPLIT = self.f32_split                  # (process-wide switch: this trainer's mode for everything it launches)
         x = inp_bchwd[:, 0].float().contiguous()
         B = x.shape[0]
         L = spec.fmap[0] * spec.fmap[1] * spec.fmap[2]

@@ -26,6 +26,10 @@ extern "C" {
 
 #define AM_DT_F32 0
 #define AM_DT_BF16 1
+/* fp32 tensors, channel contractions on the bf16 matrix cores from hi / lo splits of both operands (hi hi + hi lo + lo hi + lo lo, fp32
+ * accumulation): accepted by am_conv3d, am_pack_weight(s), am_packed_dims, am_conv3d_partials_rows wherever AM_DT_F32 is; every other entry
+ * point takes AM_DT_F32 for such tensors.  4x the rate of the exact-fp32 mode; 16 significant bits per operand. */
+#define AM_DT_F32S 2
 
 #define AM_CONV_FWD 0     /* y[o]  = sum_t x[o*stride + t - k/2] W_t        (k = 1|3, stride 1|2)            */
 #define AM_CONV_DGRAD 1   /* dx[i] = sum_t dy[(i + k/2 - t)/stride] W_t^T   (data gradient of AM_CONV_FWD)   */
@@ -90,7 +94,13 @@ int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, c
                     const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift, int fd, int fh, int fw,
                     float* det_workspace, long det_workspace_floats, void* stream);
 
-/* dst[t][r][k] = src[r*stride_r + k*stride_k + t] (zero in the padding): torch-layout fp32 master -> packed [taps][Rp][Kp]. */
+/* x (n floats, n % 4 == 0) -> hi = bf16(x), lo = bf16(x - hi) as two bf16 tensors of the same shape (AM_DT_F32S weight gradients: three
+ * bf16 am_conv3d_wgrad launches on the planes -- hi hi, lo hi, hi lo -- accumulate into ONE fp32 gradient).  The reference computes these
+ * contractions in fp32 (AMP = False, P/pretrain_AntoMask.py:239); the split keeps 16 significant bits per operand. */
+int am_split_bf16(const float* x, void* hi, void* lo, long n, void* stream);
+
+/* dst[t][r][k] = src[r*stride_r + k*stride_k + t] (zero in the padding): torch-layout fp32 master -> packed [taps][Rp][Kp].
+ * dtype AM_DT_F32S: rows of Kp fp32-sized elements whose every 16-channel group is [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] in bf16. */
 int am_pack_weight(int dtype, const float* src, void* dst, int R, int K, int taps, long stride_r, long stride_k, int Rp, int Kp,
                    void* stream);
 /* All weight repacks of a step in ONE launch (the masters are views of one flat buffer and the packed copies persist, so the

@@ -174,24 +174,39 @@ def test_config2_stunet_b_128_bf16_step_vs_oracle():
     assert n == m._flat.numel() - sum(((m._W[k].numel() + 3) // 4) * 4 for k in m._dead)
 
 
-def test_config2_stunet_b_128_fp32_storage_step_vs_oracle():
-    """The same step with fp32 storage (exact-f32 MFMA, the parity mode): every gradient tensor, loss, grad-norm and the teacher's
-    per-patch loss at reduction-order tolerances."""
+@pytest.mark.parametrize("f32_split", [False, True])
+def test_config2_stunet_b_128_fp32_storage_step_vs_oracle(f32_split):
+    """The same step with fp32 storage: every gradient tensor, loss, grad-norm and the teacher's per-patch loss at reduction-order
+    tolerances.  f32_split=False: exact-f32 MFMA (the parity mode).  f32_split=True: products from bf16 hi / lo splits of both operands
+    (AM_DT_F32S: 16 significant bits per operand, 4x the matrix rate) -- the SAME per-tensor / gradient-norm bounds, loss within 1e-5."""
+    from anatomask_amd import ops
     from anatomask_amd.trainer import AnatoMaskTrainer
     cfg, W0, x, mask1, keys, o = _oracle_step_b128()
     m = _build(cfg, W0, dtype=torch.float32)
-    tr = AnatoMaskTrainer(m, lr=1e-4, ema_decay=0.999, total_epochs=1000, distributed=False)
-    out = tr.step(x.to(DEV), epoch=0, mask1=mask1, keys=keys)
+    try:
+        tr = AnatoMaskTrainer(m, lr=1e-4, ema_decay=0.999, total_epochs=1000, distributed=False, f32_split=f32_split)
+        out = tr.step(x.to(DEV), epoch=0, mask1=mask1, keys=keys)
+        torch.cuda.synchronize()
+    finally:
+        ops.F32_SPLIT = False
+    loss_tol = 1e-5 if f32_split else F32_LOSS
+    l2_tol = 2e-5 if f32_split else F32_L2
+    # per gradient tensor: the exact mode sits at the reference's own fp32-vs-fp64 distance (median 4.2e-3, max 6.0e-3, bound 1.8e-2); the
+    # split products (2^-17 per operand instead of 2^-24) measure median 9.3e-3, max 1.87e-2 -- on the Cin = 1 stem weight, the END of the
+    # backward chain; 91 of the 92 tensors are inside the exact mode's 1.8e-2 -- stated bound for this mode: 2.5e-2, cosine >= 0.9995
+    rel_tol = 2.5e-2 if f32_split else F32_REL
     assert torch.equal(out["mask"].view(1, -1).bool().cpu(), o["mask"].view(1, -1))
     rec_h, rec_o = out["recon_loss"].cpu().numpy(), o["recon_loss"].numpy()
-    print("STUNet-B 128^3 fp32 vs oracle fp32: loss %.7f / %.7f  grad-norm %.6f / %.6f  teacher-l2 rel err %.2e"
-          % (out["loss"].item(), o["loss"], out["grad_norm"].item(), o["grad_norm"], np.abs(rec_h - rec_o).max() / rec_o.max()))
-    assert np.abs(rec_h - rec_o).max() < F32_L2 * rec_o.max()
-    assert abs(out["loss"].item() - o["loss"]) < F32_LOSS * o["loss"]
+    print("STUNet-B 128^3 fp32%s vs oracle fp32: loss %.7f / %.7f  grad-norm %.6f / %.6f  teacher-l2 rel err %.2e"
+          % (" (split products)" if f32_split else "", out["loss"].item(), o["loss"], out["grad_norm"].item(), o["grad_norm"], np.abs(rec_h - rec_o).max() / rec_o.max()))
+    assert np.abs(rec_h - rec_o).max() < l2_tol * rec_o.max()
+    assert abs(out["loss"].item() - o["loss"]) < loss_tol * o["loss"]
     assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < F32_GNORM
-    rows = _per_tensor_errors(m, o["grads"], "STUNet-B 128^3 fp32 storage")
+    rows = _per_tensor_errors(m, o["grads"], "STUNet-B 128^3 fp32 storage" + (" (split products)" if f32_split else ""))
     for k, n_el, rel, cos in rows:
-        assert rel <= F32_REL and cos >= 1 - F32_REL, (k, n_el, rel, cos)
+        assert rel <= rel_tol and cos >= (0.9995 if f32_split else 1 - F32_REL), (k, n_el, rel, cos)
+    if f32_split:
+        assert float(np.median([r_[2] for r_ in rows])) <= 1.2e-2 and sum(r_[2] > F32_REL for r_ in rows) <= 3
 
 
 def _student_step_vs_oracle(size, patch, mask_ratio, recompute, seed):

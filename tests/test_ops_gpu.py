@@ -331,6 +331,86 @@ def test_conv_fwd_dgrad_wgrad(ops, dtype, case, sparse):
     close(dw.cpu(), wr.grad, TOL[dtype], "conv wgrad")
 
 
+# ------------------------------------------------------------------ fp32 storage, split products (AM_DT_F32S, round 4)
+@pytest.mark.parametrize("case", [(32, 64, 3, 1), (64, 32, 3, 2), (40, 72, 1, 2), (16, 24, 3, 1), (64, 64, 4, 2)])
+@pytest.mark.parametrize("sparse", [False, True])
+def test_conv_f32_split_products(ops, case, sparse):
+    """ops.F32_SPLIT: fp32 tensors, channel contraction on the bf16 matrix cores from hi / lo splits of BOTH operands (hi hi + hi lo +
+    lo hi + lo lo forward / data gradient; the three leading terms in the weight gradient), fp32 accumulation.  Against F.conv3d /
+    F.conv_transpose3d autograd in fp32 on inputs that are NOT bf16-representable: <= 3e-5 of the tensor's max (the exact mode's bound is
+    2e-4 for reduction order alone; plain bf16 operands would be at 4e-3)."""
+    cin, cout, k, s = case
+    convt = k == 4
+    if convt and sparse:
+        pytest.skip("transposed convolutions are dense (the decoder)")
+    B, f, bs_out = 2, (2, 3, 2), 2
+    so = tuple(v << bs_out for v in f)
+    si = tuple(v * s for v in so)
+    dt, tol = torch.float32, 3e-5
+    mask = mk_mask(B, f, 5) if sparse else None
+    mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
+    mo = O.upsample_mask(mask, so).float() if sparse else None
+    mi_in = O.upsample_mask(mask, si).float() if sparse else None
+    ops.F32_SPLIT = True
+    try:
+        if convt:                                        # ConvTranspose3d k4 s2 p1: coarse `so` -> fine 2 * so
+            fine = tuple(2 * v for v in so)
+            x = rnd(B, cin, *so, seed=1)
+            w = rnd(cin, cout, 4, 4, 4, seed=2, scale=1.0 / np.sqrt(cin * 8))
+            dy = rnd(B, cout, *fine, seed=4)
+            xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+            yr = F.conv_transpose3d(xr, wr, None, stride=2, padding=1)
+            yr.backward(dy)
+            y = ops.conv3d(ops.CONVT_FWD, to_cl(x, dt), ops.pack_weight(w.to(DEV), dt, True, False), None, fine, 4, 2)
+            close(from_cl(y), yr.detach(), tol, "convT fwd (split)")
+            dx = ops.conv3d(ops.CONVT_DGRAD, to_cl(dy, dt), ops.pack_weight(w.to(DEV), dt, True, True), None, so, 4, 2)
+            close(from_cl(dx), xr.grad, tol, "convT dgrad (split)")
+            dwp = ops.conv3d_wgrad(ops.CONVT_FWD, to_cl(x, dt), to_cl(dy, dt), 4, 2)
+            dw = torch.zeros_like(w, device=DEV)
+            ops.unpack_grad(dwp, dw, transposed_conv=True, accumulate=False)
+            close(dw.cpu(), wr.grad, tol, "convT wgrad (split)")
+            return
+        x = rnd(B, cin, *si, seed=1)
+        w = rnd(cout, cin, k, k, k, seed=2, scale=1.0 / np.sqrt(cin * k ** 3))
+        bias = rnd(cout, seed=3)
+        dy = rnd(B, cout, *so, seed=4)
+        if sparse:
+            x, dy = x * mi_in, dy * mo
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yr = F.conv3d(xr, wr, bias, stride=s, padding=k // 2)
+        if sparse:
+            yr = yr * mo
+        yr.backward(dy)
+        bs_in = bs_out + (1 if s == 2 else 0)
+        y = ops.conv3d(ops.CONV_FWD, to_cl(x, dt), ops.pack_weight(w.to(DEV), dt, False, False), bias.to(DEV), so, k, s,
+                       in_mask=mi, in_bshift=bs_in, out_mask=mi, out_bshift=bs_out)
+        close(from_cl(y), yr.detach(), tol, "conv fwd (split)", mo)
+        dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dt), ops.pack_weight(w.to(DEV), dt, False, True), None, si, k, s,
+                        in_mask=mi, in_bshift=bs_out, out_mask=mi, out_bshift=bs_in)
+        close(from_cl(dx), xr.grad, tol, "conv dgrad (split)", mi_in)
+        for det in (False, True):
+            ops.DETERMINISTIC_WGRAD = det
+            try:
+                dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dt), to_cl(dy, dt), k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out)
+            finally:
+                ops.DETERMINISTIC_WGRAD = False
+            dw = torch.zeros_like(w, device=DEV)
+            ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+            close(dw.cpu(), wr.grad, tol, f"conv wgrad (split, det={det})")
+    finally:
+        ops.F32_SPLIT = False
+
+
+def test_split_bf16_planes(ops):
+    """am_split_bf16: hi = bf16(x) (round to nearest even), lo = bf16(x - hi); x - hi - lo is below 2^-16 |x|."""
+    x = (rnd(4, 8, 8, 16, 24, seed=5) * 37.0).to(DEV)
+    hi, lo = ops.split_bf16(x)
+    assert hi.dtype == torch.bfloat16 and lo.dtype == torch.bfloat16 and hi.shape == x.shape
+    assert torch.equal(hi, x.to(torch.bfloat16))
+    assert torch.equal(lo, (x - hi.float()).to(torch.bfloat16))
+    assert ((x - hi.float() - lo.float()).abs() <= 2.0 ** -16 * x.abs() + 1e-30).all()
+
+
 # ------------------------------------------------------------------ persistent LDS-DMA kernel (conv_k3.hip, round 4)
 # Dense k3 s1 forward / data gradient in bf16 with >= 512 units (8x4x16 bricks x 64-channel tiles) take the 8-wave persistent kernel:
 # P/decoder3D.py:20-22 (the decoder's conv3x3x3 pairs) at training sizes.  Cases cover one / two / three / four channel slabs, one / two /
