@@ -196,11 +196,15 @@ def secondary_lines(a, kw, dev, dtype_main):
     from anatomask_amd.trainer import AnatoMaskTrainer
     out = []
     torch.cuda.synchronize()
-    for what, size3, batch, dt, warm, steps in [("same workload at the reference's batch size 4", (a.patch,) * 3, 4, dtype_main, 5, 11),
-                                                ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False)", (112, 112, 128), 4, torch.float32, 2, 5)]:
+    from anatomask_amd import ops as _ops
+    for what, size3, batch, dt, warm, steps, split in [
+            ("same workload at the reference's batch size 4", (a.patch,) * 3, 4, dtype_main, 5, 11, False),
+            ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False), split-bf16 products (AM_DT_F32S: hi hi + hi lo + lo hi (+ lo lo), fp32 accumulation)",
+             (112, 112, 128), 4, torch.float32, 3, 7, True),
+            ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False), exact-f32 MFMA (the parity mode)", (112, 112, 128), 4, torch.float32, 2, 5, False)]:
         torch.manual_seed(0)
         model = M.build_spark(kw["dims"], kw["depth"], kw["width"], size3, a.mask_ratio, compute_dtype=dt).to(dev)
-        tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=4321, distributed=False)
+        tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=4321, distributed=False, f32_split=split)
         tr.set_epoch(500)
         x = torch.randn(batch, 1, *size3, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))
         for _ in range(warm):
@@ -220,6 +224,7 @@ def secondary_lines(a, kw, dev, dtype_main):
                     "ms_per_step_max": round(per[-1], 3), "value": round(batch / d, 3), "unit": "volumes/s", "steps": steps,
                     "final_loss": round(o["loss"].item(), 5)})
         del tr, model, x
+        _ops.F32_SPLIT = False
         torch.cuda.empty_cache()
     return out
 
