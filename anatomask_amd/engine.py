@@ -349,9 +349,15 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
 # Weight gradients leave the critical chain (norm backward -> dgrad -> norm backward ...): they run on a side HIP stream, where
 # the MFMA-bound wgrad kernels overlap the HBM-bound norm-backward passes of the next layer.  Ordering: the side stream waits
 # for an event recorded when dy exists; the main stream waits for the side stream before a parameter group is declared final
-# (all-reduce hook) and at the end of backward.  record_stream keeps the caching allocator from recycling x / dy early.
+# (all-reduce hook) and at the end of backward.  The operands of a side-stream launch (x, dy) are kept alive in _SIDE_KEEP until the
+# main stream has joined the side stream (`_join_side`): they are then freed on the main stream, behind the wait, like any other tensor.
+# (Until round 4 `Tensor.record_stream` did this job: the caching allocator parks such blocks until the side stream's events complete --
+# the whole backward, the side stream lags that far -- and meanwhile grows the pool: 140-213 GiB reserved for 47 GiB of live tensors at
+# B=16, allocation retries (device synchronisation + release of the whole cache) from B=24 on and in bench.py's second window:
+# profiles/r04_y_batch_cliff.txt.  That was the "batch cliff" of DESIGN.md 6.)
 FUSED_HEAD = True     # tools/step_ab.py engine.FUSED_HEAD=1,0: the projection head applies / differentiates the last BatchNorm itself
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
+_SIDE_KEEP: List[torch.Tensor] = []      # operands of side-stream launches not yet joined by the main stream
 _USE_SIDE = True      # tools/step_ab.py flips this attribute for same-process A/B timing; no environment switch exists
 
 
@@ -371,8 +377,7 @@ def _on_side(dev, tensors, fn):
     s2.wait_event(ev)
     with torch.cuda.stream(s2):
         fn()
-    for t in tensors:
-        t.record_stream(s2)
+    _SIDE_KEEP.extend(tensors)
 
 
 def _join_side(dev):
@@ -380,6 +385,7 @@ def _join_side(dev):
         ev = torch.cuda.Event()
         ev.record(_side_stream(dev))
         torch.cuda.current_stream().wait_event(ev)
+    _SIDE_KEEP.clear()                    # (freed on the main stream, which now runs behind everything the side stream was given)
 
 
 def _wgrad_into(G, name, mode, x, dy, k, stride, transposed=False, **masks):

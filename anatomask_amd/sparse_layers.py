@@ -33,17 +33,19 @@ from .hip import lib as _lib
 # ------------------------------------------------------------------ plumbing
 LAYER_REP = 64   # AM_LAYER_REP: replicated rows of the per-channel gradient accumulators
 COMPUTE_DTYPE = torch.float32   # activation dtype a Cin = 1 stem produces from the fp32 image (torch.bfloat16: bf16 storage downstream)
-_MASK_CACHE = {"key": None, "mi": None}
+_MASK_CACHE = {"act": None, "key": None, "mi": None}
 
 
 def current_mask(device) -> Optional[ops.MaskInfo]:
-    """MaskInfo of `modules._cur_active` (built once per mask tensor), or None (dense)."""
+    """MaskInfo of `modules._cur_active` (built once per mask tensor), or None (dense).
+    The cache holds the tensor ITSELF and compares by identity: an `id()` alone is reused by the next tensor object once the old one is
+    collected (same id, same _version 0, other contents: a stale patch list -- found as a sporadic pooling test failure in round 4)."""
     act = _M._cur_active
     if act is None:
         return None
-    key = (id(act), act._version, str(device))
-    if _MASK_CACHE["key"] != key:
-        _MASK_CACHE["key"], _MASK_CACHE["mi"] = key, ops.MaskInfo.from_bool(act, device)
+    key = (act._version, str(device))
+    if _MASK_CACHE["act"] is not act or _MASK_CACHE["key"] != key:
+        _MASK_CACHE["act"], _MASK_CACHE["key"], _MASK_CACHE["mi"] = act, key, ops.MaskInfo.from_bool(act, device)
     return _MASK_CACHE["mi"]
 
 
