@@ -40,7 +40,10 @@ constexpr int KWSLOT = 3 * 64 * 64;               // one run of weights: 3 taps 
 constexpr int KLDS_W = 2 * KBRICKB;
 constexpr int KLDS_TAB = KLDS_W + 2 * KWSLOT;     // 162 816: per-channel epilogue constants of the workgroup's channel tile (bias | scale | shift, 64 floats each)
 constexpr int KLDS = KLDS_TAB + 768;              // 163 584 of 163 840
-constexpr int K3_MIN_UNITS = 512;                 // below two units per CU the brick kernel of conv_igemm.hip fills the chip better
+#ifndef AM_K3_MIN_UNITS
+#define AM_K3_MIN_UNITS 256
+#endif
+constexpr int K3_MIN_UNITS = AM_K3_MIN_UNITS;     // below one unit per CU the brick kernel of conv_igemm.hip fills the chip better (A/B at B=4, tools/mkvariant.sh ... -DAM_K3_MIN_UNITS=512 vs 256: 512->512 @16^3 1 283-1 309 -> 1 479-1 483 TFLOP/s)
 
 struct K3Args {
   const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; float* partials;

@@ -412,7 +412,7 @@ def test_split_bf16_planes(ops):
 
 
 # ------------------------------------------------------------------ persistent LDS-DMA kernel (conv_k3.hip, round 4)
-# Dense k3 s1 forward / data gradient in bf16 with >= 512 units (8x4x16 bricks x 64-channel tiles) take the 8-wave persistent kernel:
+# Dense k3 s1 forward / data gradient in bf16 with >= 256 units (8x4x16 bricks x 64-channel tiles: one per CU) take the 8-wave persistent kernel:
 # P/decoder3D.py:20-22 (the decoder's conv3x3x3 pairs) at training sizes.  Cases cover one / two / three / four channel slabs, one / two /
 # three channel tiles (the grid is a multiple of the tile count: 255 workgroups for three), a unit count that is not a multiple of the grid,
 # volume borders on every face, bias, the statistics rows and the fused store epilogue.
@@ -434,7 +434,7 @@ def test_conv_k3_persistent_kernel_fwd_dgrad_stats(ops, case):
     y, part = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), ops.pack_weight(wd, dtype, False, False), bias.to(DEV), S, 3, 1, want_partials=True)
     units = B * (S[0] // 8) * (S[1] // 4) * (S[2] // 16) * (cout // 64)
     ny = cout // 64
-    assert units >= 512 and part.rows == 8 * (256 - 256 % ny), "the launch must have taken conv_k3_kernel (8 rows per workgroup)"
+    assert units >= 256 and part.rows == 8 * (256 - 256 % ny), "the launch must have taken conv_k3_kernel (8 rows per workgroup)"
     close(from_cl(y), yr.detach(), TOL[dtype], "conv_k3 fwd")
     # statistics rows == a separate pass over the stored output
     st_a, st_b = ops.NormStats(cout, DEV), ops.NormStats(cout, DEV)
