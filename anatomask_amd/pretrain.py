@@ -137,7 +137,9 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=4, help="per GPU (:229)")
     ap.add_argument("--lr", type=float, default=1e-4); ap.add_argument("--weight-decay", type=float, default=1e-5)
     ap.add_argument("--clip", type=float, default=12.0); ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32s"],
+                    help="storage / matrix-core arithmetic: bf16; f32 = exact fp32 products (the reference's AMP = False, P/pretrain_AntoMask.py:239, at "
+                         "1/16 of the bf16 matrix rate); f32s = fp32 storage, products from bf16 hi / lo splits (16 significant bits per operand, 2.6x f32)")
     ap.add_argument("--data", default=None); ap.add_argument("--out", default="anatomask_run")
     ap.add_argument("--workers", type=int, default=0,
                     help="loader threads per rank; 0 = min(8, host cores // ranks on this node - 1): 8 ranks x 8 threads on one host is not free")
@@ -163,7 +165,7 @@ def main(argv=None):
     model = build_spark(kw["dims"], kw["depth"], kw["width"], tuple(a.input_size), a.mask_ratio,
                         compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32, sbn=a.sync_bn).to(dev)
     trainer = AnatoMaskTrainer(model, lr=a.lr, weight_decay=a.weight_decay, clip=a.clip, total_epochs=a.epochs, seed=4321 + rank,
-                               self_distill=not a.plain_spark, deterministic_wgrad=a.deterministic)
+                               self_distill=not a.plain_spark, deterministic_wgrad=a.deterministic, f32_split=a.dtype == "f32s")
     trainer.rank = rank
     lrs = linear_warmup_cosine_lrs(a.epochs, a.lr, a.warmup, 1e-6)                    # :359
     feed = val_feed = None

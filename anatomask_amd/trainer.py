@@ -281,6 +281,7 @@ class AnatoMaskTrainer:
         """Validation pass of the plain-SparK driver (P/pretrain.py:426-441: model.eval(), no grad, random mask, the normalised
         masked MSE of P/spark3D.py:130-146): student in eval mode -- decoder BatchNorm on running statistics.  Returns loss[1]."""
         m, spec = self.model, self.model.spec
+        ops.F32_SPLIT = self.f32_split
         x = inp_bchwd[:, 0].float().contiguous()
         B, L = x.shape[0], spec.fmap[0] * spec.fmap[1] * spec.fmap[2]
         if mask is None:
