@@ -622,6 +622,16 @@ class SparK(nn.Module):
         a = active_b1ff.reshape(-1).to(device=inp.device, dtype=torch.uint8).contiguous()
         return _PatchLossFn.apply(inp.float(), rec.float(), a)
 
+    def forward_learning_loss(self, loss_pred, loss_target):
+        """P/AnatoMask.py:204-219: MSE between a predicted per-patch loss and the per-image normalised target (N, L) -- the objective of a
+        loss-prediction head that no module of the reference builds and no driver calls (`loss_decoder` of P/pretrain_AnatoMask_DDP.py:230-233
+        is not a parameter of SparK.__init__).  Same expression, same broadcasting, on whatever device the (tiny) tensors live; plain
+        torch arithmetic on B x L scalars, differentiable."""
+        mean = loss_target.mean(dim=1, keepdim=True)
+        var = loss_target.var(dim=1, keepdim=True)
+        loss_target = (loss_target - mean) / (var + 1.e-6) ** .5
+        return ((loss_pred - loss_target) ** 2).mean()
+
     def patchify(self, bchwd):
         p = self.downsample_ratio
         h, w, d = self.fmap_h, self.fmap_w, self.fmap_d

@@ -82,3 +82,13 @@ def test_easy_mask_is_the_band_below_the_hard_patches():
         hidden = set(order[b, m.len_keep:L - ll].tolist())             # ascending ranks [L - ll - easy_len, L - ll), easy_len = L - len_keep - ll
         assert hidden == set((~easy[b]).nonzero().flatten().tolist())
     assert torch.equal(m._easy_mask(loss, mask, 0), mask)                # random regime
+
+
+def test_forward_learning_loss_matches_its_definition():
+    """P/AnatoMask.py:204-219 (unused by the drivers): per-image normalised target, MSE against the prediction."""
+    m = build()
+    g = torch.Generator().manual_seed(9)
+    tgt, pred = torch.rand(3, 40, generator=g), torch.randn(3, 40, generator=g, requires_grad=True)
+    want = ((pred - (tgt - tgt.mean(1, keepdim=True)) / (tgt.var(1, keepdim=True) + 1e-6) ** .5) ** 2).mean()
+    got = m.forward_learning_loss(pred, tgt)
+    assert torch.allclose(got, want) and got.requires_grad
