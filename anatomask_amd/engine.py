@@ -36,6 +36,7 @@ class Spec:
     downsample: int = 16
     n_stage: int = 5
     sync_bn: bool = False        # decoder BatchNorm statistics over ALL ranks (nn.SyncBatchNorm, P/decoder3D.py:42-43)
+    dec_inorm: bool = False      # LightDecoder(sbn=False, use_IN=True): nn.InstanceNorm3d (no affine, no running statistics, P/decoder3D.py:44-45)
     enc_chs: List[int] = field(init=False)
     dec_chs: List[int] = field(init=False)
     fmap: Tuple[int, int, int] = field(init=False)
@@ -146,6 +147,39 @@ def _batch_norm(x, W, prefix, train: bool, part=None, update_running: bool = Tru
     return st
 
 
+_UNIT: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _unit_affine(C: int, dev) -> Tuple[torch.Tensor, torch.Tensor]:
+    k = (C, str(dev))
+    if k not in _UNIT:
+        _UNIT[k] = (torch.ones(C, device=dev), torch.zeros(C, device=dev))
+    return _UNIT[k]
+
+
+def _instance_norm(x, act: int, res=None) -> Tuple[torch.Tensor, List[NormStats]]:
+    """nn.InstanceNorm3d (affine=False, track_running_stats=False, eps 1e-5; the same in train and eval mode) + activation (+ residual):
+    the BatchNorm kernels on one sample at a time (a sample of a channels-last batch is a contiguous [1][D][H][W][C] view)."""
+    one, zero = _unit_affine(x.shape[-1], x.device)
+    out, sts = torch.empty_like(x), []
+    for b in range(x.shape[0]):
+        st = NormStats(x.shape[-1], x.device)
+        st.count_host = float(x[b].numel() // x.shape[-1])
+        ops.chan_stats(x[b:b + 1], None, 0, st)
+        ops.norm_finalize(st, one, zero, 1e-5)
+        ops.norm_apply(x[b:b + 1], st, act, res=None if res is None else res[b:b + 1], out=out[b:b + 1])
+        sts.append(st)
+    return out, sts
+
+
+def _instance_norm_backward(g, x, sts: List[NormStats], act: int) -> torch.Tensor:
+    one, _ = _unit_affine(x.shape[-1], x.device)
+    dx = torch.empty_like(x)
+    for b, st in enumerate(sts):
+        ops.norm_backward(g[b:b + 1], None, x[b:b + 1], st, one, act, None, 0, None, None, dx=dx[b:b + 1])
+    return dx
+
+
 class PackCache:
     """Compute-dtype MFMA-layout copies of the conv weights, rebuilt when the fp32 master changes.
     The first step packs each weight when it is first used; from then on the packed copies persist and ONE batched launch
@@ -223,13 +257,20 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
 
 
 def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False, out_skip=None, sync: bool = False,
-               head: bool = False):
+               head: bool = False, inorm: bool = False):
     """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record).
     head (last block, train mode): the block's final BatchNorm feeds only the 1x1 projection, which applies it on the fly
     (ops.proj_fwd(pre=st2)) -- the block returns the BatchNorm's INPUT c2 and the normalised map is never written."""
     q = f"{DEC}.{i}"
     so = tuple(2 * v for v in x.shape[1:4])
     u = ops.conv3d(CONVT_FWD, x, pk.get(W, f"{q}.up_sample.weight", True, False), W[f"{q}.up_sample.bias"], so, 4, 2)
+    if inorm:
+        assert not head
+        c1 = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1)
+        r, st1 = _instance_norm(c1, ACT_RELU6)
+        c2 = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1)
+        o, st2 = _instance_norm(c2, ACT_NONE, res=nxt)
+        return o, {"q": q, "xin": x, "u": u, "c1": c1, "st1": st1, "r": r, "c2": c2, "st2": st2, "inorm": True}
     if not train and fuse_eval:
         # eval-mode BatchNorm (running statistics: the EMA teacher) is a per-channel affine map: it is folded, with the ReLU6
         # and the skip add, into the store of the convolution that feeds it -- no separate pass over the 128^3 tensors
@@ -306,14 +347,14 @@ def decoder_forward(spec: Spec, W, pk: PackCache, to_dec, train: bool, tape: Opt
         fuse_eval = tape is None
     x = to_dec[0]
     # train mode: the last block's BatchNorm is applied inside the projection (and differentiated with it, ops.proj_norm_bwd)
-    head = bool(train and FUSED_HEAD and _sync_world(spec.sync_bn) <= 1)
+    head = bool(train and FUSED_HEAD and _sync_world(spec.sync_bn) <= 1 and not spec.dec_inorm)
     st_head = None
     for i in range(n_dec):
         nxt = to_dec[i + 1] if i + 1 < n_dec else None
         last = i == n_dec - 1
         o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=fuse_eval,
                              out_skip=needed_patches if (last and tape is None and not train) else None, sync=spec.sync_bn,
-                             head=head and last)
+                             head=head and last, inorm=spec.dec_inorm)
         if head and last:
             st_head = rec_["st2"]
         if tape is not None:
@@ -400,24 +441,31 @@ def _dec_block_backward(W, G, pk: PackCache, t: dict, g: Optional[torch.Tensor],
     arrives as drec, through the projection); accumulates the block's parameter gradients into G; returns the gradient wrt the block INPUT.
     bias_sum_into: densify_projs[i].bias gradient (= per-channel sum of the returned tensor), or None."""
     q = t["q"]
-    if t.get("head"):
+    if t.get("inorm"):
+        so = tuple(t["r"].shape[1:4])
+        dc2 = _instance_norm_backward(g, t["c2"], t["st2"], ACT_NONE)
+        dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1)
+        _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
+        dc1 = _instance_norm_backward(dr, t["c1"], t["st1"], ACT_RELU6)
+    elif t.get("head"):
         dc2 = ops.proj_norm_bwd(t["c2"], t["st2"], drec, W["dense_decoder.proj.weight"].view(-1), W[f"{q}.conv.4.weight"],
                                 W[f"{q}.conv.4.bias"], G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"],
                                 G["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.bias"])
     else:
         dc2 = ops.norm_backward(g, None, t["c2"], t["st2"], W[f"{q}.conv.4.weight"], ACT_NONE, None, 0,
                                 G[f"{q}.conv.4.weight"], G[f"{q}.conv.4.bias"])
-    so = tuple(t["r"].shape[1:4])
-    # (bf16) the reduce pass of the BatchNorm backward rides in this dgrad's epilogue: dr and c1 are not re-read for it.  Only where
-    # the dgrad contracts >= 128 channels: the epilogue's work per output tile is fixed (64 activation derivatives per lane), and
-    # on the 32- / 64-channel levels it costs as much as the pass it replaces (32->64 @128^3: 4.15 -> 5.61 ms for a 1.7 ms pass)
-    fuse = ops.FUSED_NORM_BWD_REDUCE and dc2.dtype == torch.bfloat16 and t["st1"].sync_world <= 1 and dc2.shape[-1] >= 128
-    dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1,
-                    norm_bwd=(t["c1"], t["st1"], ACT_RELU6) if fuse else None)
-    dr, red1 = dr if fuse else (dr, None)
-    _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
-    dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
-                            G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"], reduced=red1)
+    if not t.get("inorm"):
+        so = tuple(t["r"].shape[1:4])
+        # (bf16) the reduce pass of the BatchNorm backward rides in this dgrad's epilogue: dr and c1 are not re-read for it.  Only where
+        # the dgrad contracts >= 128 channels: the epilogue's work per output tile is fixed (64 activation derivatives per lane), and
+        # on the 32- / 64-channel levels it costs as much as the pass it replaces (32->64 @128^3: 4.15 -> 5.61 ms for a 1.7 ms pass)
+        fuse = ops.FUSED_NORM_BWD_REDUCE and dc2.dtype == torch.bfloat16 and t["st1"].sync_world <= 1 and dc2.shape[-1] >= 128
+        dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1,
+                        norm_bwd=(t["c1"], t["st1"], ACT_RELU6) if fuse else None)
+        dr, red1 = dr if fuse else (dr, None)
+        _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
+        dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
+                                G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"], reduced=red1)
     du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
     ptu.finalize(None, sum_accum=G[f"{q}.up_sample.bias"])  # ConvT bias gradient = per-channel sum of du
     _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
@@ -447,7 +495,8 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
     for i in reversed(range(n_dec)):
         t = tape.dec[i]
         if tape.recompute:                        # P/GC.py:68: re-run the block forward from its saved input
-            _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False, sync=spec.sync_bn, head=bool(t.get("head")))
+            _, t = _dec_block(W, pk, i, t["xin"], t["nxt"], True, update_running=False, sync=spec.sync_bn, head=bool(t.get("head")),
+                              inorm=spec.dec_inorm)
             tape.dec[i] = None
         if i + 1 < n_dec:
             dproj[i + 1] = g

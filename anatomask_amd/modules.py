@@ -267,13 +267,15 @@ class LightDecoder(nn.Module):
         super().__init__()
         self.width = width
         assert up_sample_ratio > 0 and up_sample_ratio & (up_sample_ratio - 1) == 0
-        if use_IN:
-            raise NotImplementedError("the drivers use use_IN=False (P/pretrain_AntoMask.py:212)")
+        # P/decoder3D.py:42-47: sbn takes precedence over use_IN.  use_IN (with sbn=False): nn.InstanceNorm3d -- no affine parameters, no
+        # running statistics, per-sample statistics in train AND eval mode (engine._instance_norm); module API only, the fused trainer refuses it
+        self.use_IN = bool(use_IN) and not sbn
         self.sbn = bool(sbn)              # nn.SyncBatchNorm in the reference (P/decoder3D.py:42-43; on in plain-SparK DDP, P/pretrain_DDP.py:225):
         # same parameters / buffers / state_dict keys as BatchNorm3d; the engine all-reduces the batch statistics when a process group is up
         n = round(math.log2(up_sample_ratio))
         channels = [self.width // 2 ** i for i in range(n + 1)]
-        self.dec = nn.ModuleList([UNetBlock(cin, cout, nn.BatchNorm3d) for cin, cout in zip(channels[:-1], channels[1:])])
+        bn3d = nn.InstanceNorm3d if self.use_IN else nn.BatchNorm3d
+        self.dec = nn.ModuleList([UNetBlock(cin, cout, bn3d) for cin, cout in zip(channels[:-1], channels[1:])])
         self.proj = nn.Conv3d(channels[-1], out_channel, kernel_size=1, stride=1, bias=True)
         self.initialize()
 
@@ -307,7 +309,7 @@ class LightDecoder(nn.Module):
             return owner.spec, owner._W, owner._pack, G
         sa = self.__dict__.setdefault("_sa", _Standalone(self, "dense_decoder.", self.compute_dtype))
         sa.dtype = self.compute_dtype
-        spec = Spec([8, 16, 32, 64, 128, 128], [1] * 6, self.width, (16, 16, 16))
+        spec = Spec([8, 16, 32, 64, 128, 128], [1] * 6, self.width, (16, 16, 16), dec_inorm=self.use_IN)
         assert spec.dec_chs == chans
         return spec, sa.weights(), sa.pack, (sa.grads() if want_grads else None)
 
@@ -446,7 +448,8 @@ class SparK(nn.Module):
             self.dense_decoder.compute_dtype = compute_dtype
             self._dead = set()
             return
-        self.spec = Spec(cnn.dims, cnn.depth, dense_decoder.width, tuple(input_size), sync_bn=bool(getattr(dense_decoder, "sbn", False)))
+        self.spec = Spec(cnn.dims, cnn.depth, dense_decoder.width, tuple(input_size), sync_bn=bool(getattr(dense_decoder, "sbn", False)),
+                         dec_inorm=bool(getattr(dense_decoder, "use_IN", False)))
         import weakref                       # sub-modules called on their own (model.sparse_encoder(x), model.dense_decoder(to_dec))
         cnn.__dict__["_owner"] = dense_decoder.__dict__["_owner"] = weakref.ref(self)   # run on THIS model's flat buffers
         n_dec = len(self.spec.dec_chs) - 1

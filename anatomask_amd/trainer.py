@@ -22,6 +22,9 @@ class AnatoMaskTrainer:
                  process_group=None, distributed: Optional[bool] = None, self_distill: bool = True, deterministic_wgrad: bool = False,
                  f32_split: bool = False):
         self.model = model
+        if model.spec.dec_inorm:
+            raise NotImplementedError("the fused trainer keeps the drivers' BatchNorm decoder (P/pretrain_AntoMask.py:212); a "
+                                      "LightDecoder(use_IN=True) model trains through the module API (SparK.forward / forward_loss / a torch optimizer)")
         # fp32-storage models only: matrix-core products from bf16 hi / lo splits (ops.F32_SPLIT, AM_DT_F32S) instead of the exact fp32
         # matrix instruction -- the fast reference-precision mode (the reference recipe is AMP = False, P/pretrain_AntoMask.py:239)
         self.f32_split = bool(f32_split)

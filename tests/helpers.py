@@ -158,3 +158,16 @@ def seeded_params(model):
                 p.copy_(r / float(np.sqrt(p.shape[0] * 8)))
             else:
                 p.copy_(r / float(np.sqrt(p[0].numel())))
+
+
+DECODER_IN_WIDTH = 128
+
+
+def decoder_in_inputs(B=2, f0=(2, 2, 3)):
+    """Inputs of tests/golden/make_decoder_in_fixture.py (both sides regenerate them): to_dec[i] of shape (B, WIDTH / 2^i, f0 * 2^i),
+    i = 0..3 (seeds 40 + i), and the probe the reconstruction is contracted with (seed 50)."""
+    import torch
+    maps = [torch.from_numpy(np.random.RandomState(40 + i).standard_normal((B, DECODER_IN_WIDTH >> i, *(v << i for v in f0))).astype(np.float32))
+            for i in range(4)]
+    probe = torch.from_numpy(np.random.RandomState(50).standard_normal((B, 1, *(v << 4 for v in f0))).astype(np.float32))
+    return maps, probe

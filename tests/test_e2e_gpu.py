@@ -9,6 +9,8 @@ tests/calibrate_tolerances.py, stated next to the constants in tests/test_oracle
       (oracle.storage("bf16")) shows against the same reference gradient, times a stated factor
   learning: 120 steps on one fixed batch follow the reference's loss curve and end below 0.1 (fp32 and bf16)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -676,6 +678,84 @@ def test_light_decoder_forward_and_grads_vs_oracle(fwd):
         a, b = to_dec[i].grad.cpu().double().flatten(), tin[i].grad.double().flatten()
         assert float((a - b).norm() / b.norm()) < 1e-2, i
     assert to_dec[4].grad is None
+
+
+def test_light_decoder_instance_norm_matches_the_reference():
+    """LightDecoder(sbn=False, use_IN=True) (P/decoder3D.py:44-45: nn.InstanceNorm3d, no affine parameters, per-sample statistics in train
+    and eval mode) against the reference's own class evaluated in float64 (tests/golden/decoder_in_tiny.npz, made by
+    tests/golden/make_decoder_in_fixture.py): state_dict keys, reconstruction, gradient wrt every input map and every parameter."""
+    from anatomask_amd import modules as M
+    from tests.helpers import seeded_params, decoder_in_inputs as inputs, DECODER_IN_WIDTH as WIDTH
+    F_ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decoder_in_tiny.npz"))
+    tol = 5e-4
+    dec = M.LightDecoder(16, sbn=False, width=WIDTH, use_IN=True, out_channel=1)
+    assert sorted(dec.state_dict().keys()) == list(F_["keys"])
+    assert M.LightDecoder(16, width=WIDTH, use_IN=True).use_IN is False            # sbn (the default) wins, P/decoder3D.py:42-45
+    seeded_params(dec)
+    dec = dec.to(DEV)
+    maps, probe = inputs()
+    want = torch.from_numpy(F_["train.rec"])
+    for mode in ("train", "eval"):
+        dec.train(mode == "train")
+        dec.zero_grad()
+        xs = [x.to(DEV).requires_grad_(True) for x in maps]
+        rec = dec(xs)
+        assert float((rec.detach().cpu().double() - want.double()).norm() / want.double().norm()) <= tol, mode
+        (rec * probe.to(DEV)).sum().backward()
+        for i, x in enumerate(xs):
+            w = torch.from_numpy(F_[f"train.gx{i}"]).double()
+            assert float((x.grad.cpu().double() - w).norm() / w.norm()) <= 4 * tol, (mode, i)
+        gtot = float(F_["train.gtot"])
+        for n, p_ in dec.named_parameters():
+            g = p_.grad.reshape(-1).float().cpu()
+            idx = np.linspace(0, g.numel() - 1, min(64, g.numel())).astype(np.int64)
+            want_n, want_s, floor = float(F_[f"train.gn.{n}"]), F_[f"train.gs.{n}"], float(F_[f"train.floor.{n}"])
+            bound = 3 * floor + 4 * tol
+            assert abs(float(g.norm()) - want_n) <= bound * max(want_n, 1e-3 * gtot), (mode, n, float(g.norm()), want_n, floor)
+            scale = max(float(np.abs(want_s).max()), 1e-3 * gtot / np.sqrt(g.numel()))
+            assert float(np.abs(g[torch.from_numpy(idx)].numpy() - want_s).max()) <= 2 * bound * scale + 1e-7, (mode, n, floor)
+    # bf16 storage: same function within storage noise
+    dec.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        rec = dec([x.to(DEV) for x in maps])
+    assert float((rec.cpu().double() - want.double()).norm() / want.double().norm()) <= 3e-2
+
+
+def test_spark_with_instance_norm_decoder_runs_end_to_end(fwd):
+    """SparK(dense_decoder=LightDecoder(sbn=False, use_IN=True)) through the module API: forward, loss, backward; the decoder inside the
+    model is the same function as the decoder alone (the stand-alone class is pinned to the reference by the test above)."""
+    from anatomask_amd import modules as M
+    from tests.helpers import seeded_params
+    cfg = tiny_cfg(fwd)
+    head = M.STUNet(1, 1, depth=cfg.depth, dims=cfg.dims)
+    enc = M.SparseEncoder(head, input_size=cfg.input_size, sbn=False)
+    dec = M.LightDecoder(enc.downsample_ratio, sbn=False, width=cfg.width, use_IN=True, out_channel=1)
+    model = M.SparK(sparse_encoder=enc, dense_decoder=dec, mask_ratio=cfg.mask_ratio, densify_norm="in").train()
+    seeded_params(model)
+    model = model.to(DEV)
+    assert not any("dense_decoder.dec" in k and (".conv.1." in k or ".conv.4." in k) for k in model.state_dict())
+    x = np_volume(2, cfg.input_size, 7).to(DEV)
+    mask = O.random_mask(cfg, 2, torch.Generator().manual_seed(2)).to(DEV)
+    inp, rec = model(x, active_b1ff=mask)
+    loss, _ = model.forward_loss(inp, rec, mask)
+    loss.backward()
+    assert np.isfinite(loss.item())
+    for n, p_ in model.named_parameters():
+        if n in model._dead:                       # level 4's densify norm / projection / token feed nothing (P/AnatoMask.py:163-171), as in the reference
+            continue
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), n
+    assert float(model.dense_decoder.dec[0].conv[0].weight.grad.norm()) > 0
+    # per-sample statistics: the reconstruction of sample 0 does not depend on what sample 1's decoder input was -- scale invariance of
+    # InstanceNorm per sample: scaling ONE sample's maps into the decoder by a constant leaves every sample's output where it was
+    maps = [torch.randn(2, c, *(v // 16 * 2 ** i for v in cfg.input_size), device=DEV) for i, c in enumerate(cfg.dec_chs[:4])]
+    with torch.no_grad():
+        a = model.dense_decoder(maps)
+        scaled = [torch.cat([m_[:1], 3.0 * m_[1:]]) for m_ in maps]
+        b = model.dense_decoder(scaled)
+    assert float((a[0] - b[0]).abs().max()) <= 1e-5 * float(a[0].abs().max())
+    with pytest.raises(NotImplementedError):
+        from anatomask_amd.trainer import AnatoMaskTrainer
+        AnatoMaskTrainer(model)
 
 
 def test_standalone_encoder_outside_spark_matches(fwd):
