@@ -149,7 +149,7 @@ __device__ __forceinline__ float act_grad_pre(float pre, int act) {   // derivat
 // ------------------------------------------------------------------ apply (forward)
 // y = act(x*scale + shift [+ res | + stem 1x1 shortcut]) on active voxels;
 // fill != nullptr: inactive voxels get the mask token (densify, P/AnatoMask.py:160-163), output dense.
-template <typename T, int NT = 256>
+template <typename T, int NT = 256, int ACT_ = -1>
 __global__ __launch_bounds__(NT) void norm_apply_kernel(const T* __restrict__ x, Geo g, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, int act, const T* __restrict__ res,
                                                          const float* __restrict__ stem_x, const float* __restrict__ stem_w,
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(NT) void norm_apply_kernel(const T* __restrict__ x,
         for (int i = 0; i < EPC; ++i) o[i] += stem_w[wk.cl * EPC + i] * xv + stem_b[wk.cl * EPC + i];
       }
 #pragma unroll
-      for (int i = 0; i < EPC; ++i) o[i] = act_fwd(o[i], act);
+      for (int i = 0; i < EPC; ++i) o[i] = act_fwd(o[i], ACT_ >= 0 ? ACT_ : act);
     } else if (fill) {
 #pragma unroll
       for (int i = 0; i < EPC; ++i) o[i] = fill[wk.cl * EPC + i];
@@ -259,13 +259,15 @@ __device__ __forceinline__ void dxsum_tail(double* rep, int nrep, int C, float* 
 
 // ------------------------------------------------------------------ backward: reduce
 // dpre = dout * act'(out);  bsum[c] = {sum dpre, sum dpre*xhat, sum_{inactive} dout (token grad)}
-template <typename T, int NT = 256>
+template <typename T, int NT = 256, int ACT_ = -1, int OUT_ = 0>
 __global__ __launch_bounds__(NT) void norm_bwd_reduce_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                               const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, int act, int fill,
                                                               double* __restrict__ bsum, const float* __restrict__ psc,
                                                               const float* __restrict__ psh, BwdFin fin) {
   constexpr int EPC = TT<T>::EPC;
+  const int actv = ACT_ >= 0 ? ACT_ : act;                     // compile-time activation / derivative source in the specialised instantiations:
+  const bool has_out = ACT_ >= 0 ? OUT_ != 0 : out != nullptr;  // the per-element code is then branch-free (the generic form compiled to scalar branches per element)
   __shared__ float red[NT * 3 * 8];
   Walk<T> wk(g.C, NT);
   float s1[EPC], s2[EPC], s3[EPC], mu[EPC], rs[EPC], qs[EPC], qh[EPC];
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(NT) void norm_bwd_reduce_kernel(const T* __restrict
 #pragma unroll
     for (int i = 0; i < EPC; ++i) {
       mu[i] = mean[wk.cl * EPC + i]; rs[i] = rstd[wk.cl * EPC + i];
-      if (!out && act != AM_ACT_NONE) { qs[i] = psc[wk.cl * EPC + i]; qh[i] = psh[wk.cl * EPC + i]; }
+      if (!has_out && actv != AM_ACT_NONE) { qs[i] = psc[wk.cl * EPC + i]; qh[i] = psh[wk.cl * EPC + i]; }
     }
     const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
     for (long v = v0 + wk.vl; v < v1; v += wk.vpp) {
@@ -291,15 +293,15 @@ __global__ __launch_bounds__(NT) void norm_bwd_reduce_kernel(const T* __restrict
       }
       float f[EPC];
       chunk_to_f<T>(*(const u32x4*)(x + off), f);
-      if (act != AM_ACT_NONE) {
-        if (out) {
+      if (actv != AM_ACT_NONE) {
+        if (has_out) {
           float o[EPC];
           chunk_to_f<T>(*(const u32x4*)(out + off), o);
 #pragma unroll
-          for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], actv);
         } else {                                     // same expression as norm_apply_kernel's forward
 #pragma unroll
-          for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], actv);
         }
       }
 #pragma unroll
@@ -352,7 +354,7 @@ __global__ void norm_bwd_finalize_kernel(const double* bsum, const double* count
 
 // ------------------------------------------------------------------ backward: apply
 // dx = k0*dpre - k1 - k2*xhat on active voxels; optionally store dpre (gradient of the residual branch)
-template <typename T, int NT = 256>
+template <typename T, int NT = 256, int ACT_ = -1, int OUT_ = 0>
 __global__ __launch_bounds__(NT) void norm_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                              const T* __restrict__ x, Geo g, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, const float* __restrict__ k0,
@@ -361,6 +363,8 @@ __global__ __launch_bounds__(NT) void norm_bwd_apply_kernel(const T* __restrict_
                                                              int dxrep, const float* __restrict__ psc, const float* __restrict__ psh,
                                                              float* __restrict__ dx_accum, unsigned* dx_ticket) {
   constexpr int EPC = TT<T>::EPC;
+  const int actv = ACT_ >= 0 ? ACT_ : act;                     // compile-time activation / derivative source in the specialised instantiations:
+  const bool has_out = ACT_ >= 0 ? OUT_ != 0 : out != nullptr;  // the per-element code is then branch-free (the generic form compiled to scalar branches per element)
   __shared__ float red[NT * 8];
   Walk<T> wk(g.C, NT);
   float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC], sx[EPC], qs[EPC], qh[EPC];
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(NT) void norm_bwd_apply_kernel(const T* __restrict_
     sx[i] = 0.f; qs[i] = qh[i] = 0.f;
     if (wk.live) {
       mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c];
-      if (!out && act != AM_ACT_NONE) { qs[i] = psc[c]; qh[i] = psh[c]; }
+      if (!has_out && actv != AM_ACT_NONE) { qs[i] = psc[c]; qh[i] = psh[c]; }
     }
   }
   const long v0 = (long)blockIdx.x * g.vpw, v1 = min(v0 + (long)g.vpw, g.nvox());
@@ -381,15 +385,15 @@ __global__ __launch_bounds__(NT) void norm_bwd_apply_kernel(const T* __restrict_
       float d[EPC], f[EPC];
       chunk_to_f<T>(*(const u32x4*)(dout + off), d);
       chunk_to_f<T>(*(const u32x4*)(x + off), f);
-      if (act != AM_ACT_NONE) {
-        if (out) {
+      if (actv != AM_ACT_NONE) {
+        if (has_out) {
           float o[EPC];
           chunk_to_f<T>(*(const u32x4*)(out + off), o);
 #pragma unroll
-          for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], actv);
         } else {
 #pragma unroll
-          for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+          for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], actv);
         }
       }
       if (dres) *(u32x4*)(dres + off) = f_to_chunk<T>(d);
@@ -577,12 +581,14 @@ __global__ __launch_bounds__(256) void chan_stats_rows_kernel(const T* __restric
 
 // backward reduce over the active rows (no fill: the densify norms, whose inactive voxels carry the token gradient, keep the
 // linear kernel)
-template <typename T>
+template <typename T, int ACT_ = -1, int OUT_ = 0>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_rows_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                                    const T* __restrict__ x, RowGeo g, const float* __restrict__ mean,
                                                                    const float* __restrict__ rstd, int act, double* __restrict__ bsum,
                                                                    const float* __restrict__ psc, const float* __restrict__ psh, BwdFin fin) {
   constexpr int EPC = TT<T>::EPC;
+  const int actv = ACT_ >= 0 ? ACT_ : act;                     // compile-time activation / derivative source in the specialised instantiations:
+  const bool has_out = ACT_ >= 0 ? OUT_ != 0 : out != nullptr;  // the per-element code is then branch-free (the generic form compiled to scalar branches per element)
   __shared__ float red[256 * 2 * 8];
   RowWalk<T> wk(g);
   float s1[EPC], s2[EPC], mu[EPC], rs[EPC], qs[EPC], qh[EPC];
@@ -592,7 +598,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_rows_kernel(const T* __re
 #pragma unroll
     for (int i = 0; i < EPC; ++i) {
       mu[i] = mean[wk.cl * EPC + i]; rs[i] = rstd[wk.cl * EPC + i];
-      if (!out && act != AM_ACT_NONE) { qs[i] = psc[wk.cl * EPC + i]; qh[i] = psh[wk.cl * EPC + i]; }
+      if (!has_out && actv != AM_ACT_NONE) { qs[i] = psc[wk.cl * EPC + i]; qh[i] = psh[wk.cl * EPC + i]; }
     }
     for (long rw = wk.row; rw < wk.row_end; rw += (long)UNR * wk.rpp) {
       long v[UNR]; u32x4 dv[UNR], xv[UNR], ov[UNR];
@@ -603,22 +609,22 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_rows_kernel(const T* __re
         if (v[u] < 0) continue;
         const size_t off = (size_t)v[u] * g.C + wk.cl * EPC;
         dv[u] = *(const u32x4*)(dout + off); xv[u] = *(const u32x4*)(x + off);
-        if (out && act != AM_ACT_NONE) ov[u] = *(const u32x4*)(out + off);
+        if (has_out && actv != AM_ACT_NONE) ov[u] = *(const u32x4*)(out + off);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         if (v[u] < 0) continue;
         float d[EPC], f[EPC];
         chunk_to_f<T>(dv[u], d); chunk_to_f<T>(xv[u], f);
-        if (act != AM_ACT_NONE) {
-          if (out) {
+        if (actv != AM_ACT_NONE) {
+          if (has_out) {
             float o[EPC];
             chunk_to_f<T>(ov[u], o);
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], actv);
           } else {
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], actv);
           }
         }
 #pragma unroll
@@ -649,7 +655,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_rows_kernel(const T* __re
   bwd_reduce_tail(bsum, g.C, fin);
 }
 
-template <typename T>
+template <typename T, int ACT_ = -1, int OUT_ = 0>
 __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                                   const T* __restrict__ x, RowGeo g, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, const float* __restrict__ k0,
@@ -658,6 +664,8 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
                                                                   int dxrep, const float* __restrict__ psc, const float* __restrict__ psh,
                                                                   float* __restrict__ dx_accum, unsigned* dx_ticket) {
   constexpr int EPC = TT<T>::EPC;
+  const int actv = ACT_ >= 0 ? ACT_ : act;                     // compile-time activation / derivative source in the specialised instantiations:
+  const bool has_out = ACT_ >= 0 ? OUT_ != 0 : out != nullptr;  // the per-element code is then branch-free (the generic form compiled to scalar branches per element)
   __shared__ float red[256 * 8];
   RowWalk<T> wk(g);
   float mu[EPC], rs[EPC], c0[EPC], c1[EPC], c2[EPC], sx[EPC], qs[EPC], qh[EPC];
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
     sx[i] = 0.f; qs[i] = qh[i] = 0.f;
     if (wk.live) {
       mu[i] = mean[c]; rs[i] = rstd[c]; c0[i] = k0[c]; c1[i] = k1[c]; c2[i] = k2[c];
-      if (!out && act != AM_ACT_NONE) { qs[i] = psc[c]; qh[i] = psh[c]; }
+      if (!has_out && actv != AM_ACT_NONE) { qs[i] = psc[c]; qh[i] = psh[c]; }
     }
   }
   if (wk.live)
@@ -680,7 +688,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
         if (v[u] < 0) continue;
         const size_t off = (size_t)v[u] * g.C + wk.cl * EPC;
         dv[u] = *(const u32x4*)(dout + off); xv[u] = *(const u32x4*)(x + off);
-        if (out && act != AM_ACT_NONE) ov[u] = *(const u32x4*)(out + off);
+        if (has_out && actv != AM_ACT_NONE) ov[u] = *(const u32x4*)(out + off);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -688,15 +696,15 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_rows_kernel(const T* __res
         const size_t off = (size_t)v[u] * g.C + wk.cl * EPC;
         float d[EPC], f[EPC];
         chunk_to_f<T>(dv[u], d); chunk_to_f<T>(xv[u], f);
-        if (act != AM_ACT_NONE) {
-          if (out) {
+        if (actv != AM_ACT_NONE) {
+          if (has_out) {
             float o[EPC];
             chunk_to_f<T>(ov[u], o);
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], act);
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad(o[i], actv);
           } else {
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], act);
+            for (int i = 0; i < EPC; ++i) d[i] *= act_grad_pre(f[i] * qs[i] + qh[i], actv);
           }
         }
         if (dres) *(u32x4*)(dres + off) = f_to_chunk<T>(d);
@@ -1697,7 +1705,10 @@ inline int walk_threads(int C, int dtype) { return C / (dtype == AM_DT_BF16 ? 8 
 inline int pick_vpw(long nvox, int C, int dtype, bool reduction) {
   const int epc = dtype == AM_DT_BF16 ? 8 : 4;
   int vpp = walk_threads(C, dtype) / (C / epc); if (vpp < 1) vpp = 1;
-  const long target = reduction ? 1024 : 2048;
+  long target = reduction ? 1024 : 2048;
+#ifdef AM_ABLATE
+  if (const char* e = getenv(reduction ? "AM_RED_TARGET" : "AM_MAP_TARGET")) target = atol(e);
+#endif
   long v = (nvox + target - 1) / target;
   v = (v + vpp - 1) / vpp * vpp;
   // small tensors: at least 16 passes (64 KB of a tensor) per workgroup, but never fewer than ~256 workgroups -- thousands of
@@ -1759,6 +1770,15 @@ inline int rows_threads(const RowGeo& r) { return r.rpp * r.rowchunks; }
 // entry points without a 512-thread instantiation (stem convs, projection head: Walk<T> kernels launched with 256 threads) refuse fp32 rows
 // wider than 1024 channels, as layer_ops.hip does -- with 256 threads such a row leaves every thread idle and the output untouched
 #define CHK_C_NARROW(C) do { CHK_C(C); if (dtype != AM_DT_BF16 && (C) > 1024) return -1; } while (0)
+
+// backward norm kernels: activation x derivative source (saved output / recomputed pre-activation) -> the specialised instantiation
+#define AM_BWD_SPEC(act_, has_out_, M_) do {                                                                        \
+    if ((act_) == AM_ACT_NONE) M_(0, 0);                                                                            \
+    else if ((act_) == AM_ACT_LRELU && (has_out_)) M_(1, 1);                                                        \
+    else if ((act_) == AM_ACT_LRELU) M_(1, 0);                                                                      \
+    else if ((act_) == AM_ACT_RELU6 && (has_out_)) M_(2, 1);                                                        \
+    else if ((act_) == AM_ACT_RELU6) M_(2, 0);                                                                      \
+    else M_(-1, 0); } while (0)
 
 extern "C" {
 
@@ -1842,11 +1862,15 @@ int am_norm_apply(int dtype, const void* x, int B, int D, int H, int W, int C, c
   }
   if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
-  DISPATCH_T(dtype,
-             AM_LAUNCH_F32W(C, norm_apply_kernel, dim3(nb), st, (const float*)x, g, scale, shift, act,
-                                (const float*)res, stem_x, stem_w, stem_b, fill, (float*)y),
-             AM_LAUNCH(norm_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, scale, shift, act,
-                                (const bf16_t*)res, stem_x, stem_w, stem_b, fill, (bf16_t*)y));
+#define AM_NA_(A_, O_) do {                                                                                                             \
+    if (dtype == AM_DT_BF16) AM_LAUNCH((norm_apply_kernel<bf16_t, 256, A_>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, g, scale, shift, act, \
+                                (const bf16_t*)res, stem_x, stem_w, stem_b, fill, (bf16_t*)y);                                           \
+    else if (C / 4 > 256) AM_LAUNCH((norm_apply_kernel<float, 512>), dim3(nb), dim3(512), 0, st, (const float*)x, g, scale, shift, act,   \
+                                (const float*)res, stem_x, stem_w, stem_b, fill, (float*)y);                                             \
+    else AM_LAUNCH((norm_apply_kernel<float, 256, A_>), dim3(nb), dim3(256), 0, st, (const float*)x, g, scale, shift, act,                \
+                                (const float*)res, stem_x, stem_w, stem_b, fill, (float*)y); } while (0)
+  AM_BWD_SPEC(act, false, AM_NA_);
+#undef AM_NA_
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -1872,21 +1896,28 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
   }
   RowGeo rg;
   if (mask && !fill && mkrows(rg, dtype, true, B, D, H, W, C, bshift, active_list, n_active)) {
-    DISPATCH_T(dtype,
-               AM_LAUNCH(norm_bwd_reduce_rows_kernel<float>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const float*)dout,
-                         (const float*)out, (const float*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift, fin),
-               AM_LAUNCH(norm_bwd_reduce_rows_kernel<bf16_t>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout,
-                         (const bf16_t*)out, (const bf16_t*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift, fin));
+#define AM_RR_(A_, O_)                                                                                                                  \
+    DISPATCH_T(dtype,                                                                                                                    \
+               AM_LAUNCH((norm_bwd_reduce_rows_kernel<float, A_, O_>), dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const float*)dout, \
+                         (const float*)out, (const float*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift, fin),                     \
+               AM_LAUNCH((norm_bwd_reduce_rows_kernel<bf16_t, A_, O_>), dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout, \
+                         (const bf16_t*)out, (const bf16_t*)x, rg, mean, rstd, act, bsum, pre_scale, pre_shift, fin))
+    AM_BWD_SPEC(act, out != nullptr, AM_RR_);
+#undef AM_RR_
     AM_CHECK_LAUNCH();
     return 0;
   }
   if (geo_bad) return -4;
   const int nb = nblk((long)B * D * H * W, g.vpw);
-  DISPATCH_T(dtype,
-             AM_LAUNCH_F32W(C, norm_bwd_reduce_kernel, dim3(nb), st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin),
-             AM_LAUNCH(norm_bwd_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,
-                                (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin));
+#define AM_RL_(A_, O_) do {                                                                                                             \
+    if (dtype == AM_DT_BF16) AM_LAUNCH((norm_bwd_reduce_kernel<bf16_t, 256, A_, O_>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout,   \
+                                (const bf16_t*)out, (const bf16_t*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin);       \
+    else if (C / 4 > 256) AM_LAUNCH((norm_bwd_reduce_kernel<float, 512>), dim3(nb), dim3(512), 0, st, (const float*)dout,                \
+                                (const float*)out, (const float*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin);         \
+    else AM_LAUNCH((norm_bwd_reduce_kernel<float, 256, A_, O_>), dim3(nb), dim3(256), 0, st, (const float*)dout,                         \
+                                (const float*)out, (const float*)x, g, mean, rstd, act, fill, bsum, pre_scale, pre_shift, fin); } while (0)
+  AM_BWD_SPEC(act, out != nullptr, AM_RL_);
+#undef AM_RL_
   AM_CHECK_LAUNCH();
   return 0;
 }
@@ -1927,17 +1958,25 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
   unsigned* dx_ticket = fused ? (unsigned*)(dxsum_scratch + (size_t)AM_DXREP * C) : nullptr;
   if (rep && !fused) hipMemsetAsync(dxsum_scratch, 0, sizeof(double) * AM_DXREP * C, st);
   if (rows) {
-    DISPATCH_T(dtype,
-               AM_LAUNCH(norm_bwd_apply_rows_kernel<float>, dim3(nb), dim3(rows_threads(rg)), 0, st, (const float*)dout, (const float*)out,
-                         (const float*)x, rg, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket),
-               AM_LAUNCH(norm_bwd_apply_rows_kernel<bf16_t>, dim3(nb), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                         (const bf16_t*)x, rg, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket));
-  } else
-  DISPATCH_T(dtype,
-             AM_LAUNCH_F32W(C, norm_bwd_apply_kernel, dim3(nb), st, (const float*)dout, (const float*)out,
-                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket),
-             AM_LAUNCH(norm_bwd_apply_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out,
-                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket));
+#define AM_AR_(A_, O_)                                                                                                                  \
+    DISPATCH_T(dtype,                                                                                                                    \
+               AM_LAUNCH((norm_bwd_apply_rows_kernel<float, A_, O_>), dim3(nb), dim3(rows_threads(rg)), 0, st, (const float*)dout, (const float*)out, \
+                         (const float*)x, rg, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket), \
+               AM_LAUNCH((norm_bwd_apply_rows_kernel<bf16_t, A_, O_>), dim3(nb), dim3(rows_threads(rg)), 0, st, (const bf16_t*)dout, (const bf16_t*)out, \
+                         (const bf16_t*)x, rg, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket))
+    AM_BWD_SPEC(act, out != nullptr, AM_AR_);
+#undef AM_AR_
+  } else {
+#define AM_AL_(A_, O_) do {                                                                                                             \
+    if (dtype == AM_DT_BF16) AM_LAUNCH((norm_bwd_apply_kernel<bf16_t, 256, A_, O_>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)out, \
+                                (const bf16_t*)x, g, mean, rstd, k0, k1, k2, act, (bf16_t*)dx, (bf16_t*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket); \
+    else if (C / 4 > 256) AM_LAUNCH((norm_bwd_apply_kernel<float, 512>), dim3(nb), dim3(512), 0, st, (const float*)dout, (const float*)out, \
+                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket); \
+    else AM_LAUNCH((norm_bwd_apply_kernel<float, 256, A_, O_>), dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)out,        \
+                                (const float*)x, g, mean, rstd, k0, k1, k2, act, (float*)dx, (float*)dres, dxs, nrep, pre_scale, pre_shift, dx_accum, dx_ticket); } while (0)
+    AM_BWD_SPEC(act, out != nullptr, AM_AL_);
+#undef AM_AL_
+  }
   AM_CHECK_LAUNCH();
   if (rep && !fused) { AM_LAUNCH(rep_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dxsum_scratch, AM_DXREP, C, dxsum_accum); AM_CHECK_LAUNCH(); }
   return 0;

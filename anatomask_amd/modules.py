@@ -696,7 +696,8 @@ class SparK(nn.Module):
         self._flat = flat
         self.__dict__.update(saved)
         import weakref                       # the copy's sub-modules belong to the copy
-        new.sparse_encoder.sp_cnn.__dict__["_owner"] = new.dense_decoder.__dict__["_owner"] = weakref.ref(new)
+        if not self._generic:                # (a generic composition has no flat engine buffers: its sub-modules stay stand-alone)
+            new.sparse_encoder.sp_cnn.__dict__["_owner"] = new.dense_decoder.__dict__["_owner"] = weakref.ref(new)
         for mod in (new.sparse_encoder.sp_cnn, new.dense_decoder):
             mod.__dict__.pop("_sa", None)
         return new
@@ -725,7 +726,7 @@ class ModelEma:
     @torch.no_grad()
     def update(self, model):
         src = model.module if hasattr(model, "module") and not self.ema_has_module else model
-        if isinstance(src, SparK) and isinstance(self.ema, SparK):
+        if isinstance(src, SparK) and isinstance(self.ema, SparK) and not src._generic:
             src._ensure_flat(); self.ema._ensure_flat()
             ops.ema(self.ema._flat, src._flat, self.decay)
             ops.ema(self.ema._bflat, src._bflat, self.decay)
@@ -737,6 +738,8 @@ class ModelEma:
         msd = src.state_dict()
         for k, ema_v in self.ema.state_dict().items():
             ema_v.copy_(ema_v * self.decay + (1. - self.decay) * msd[k].detach().to(ema_v.device))
+        if isinstance(self.ema, SparK):
+            self.ema.weights_changed()
 
 
 class LocalDDP(nn.Module):
