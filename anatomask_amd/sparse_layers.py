@@ -49,6 +49,28 @@ def current_mask(device) -> Optional[ops.MaskInfo]:
     return _MASK_CACHE["mi"]
 
 
+class _all_active:
+    """`with _all_active(x_cl):` -- the zoo's kernels walk an active-patch list; a DENSE branch (`sparse=False`, encoder3D.py:60-61,197-198)
+    is the same kernel under a mask with every patch active (grid = the tensor's extents / their largest common power of two <= 16)."""
+    _cache = {}
+
+    def __init__(self, x_cl: torch.Tensor):
+        B, D, H, W = x_cl.shape[:4]
+        g = 16
+        while g > 1 and (D % g or H % g or W % g):
+            g //= 2
+        key = (B, D // g, H // g, W // g, str(x_cl.device))
+        if key not in self._cache:
+            self._cache[key] = torch.ones(B, 1, D // g, H // g, W // g, dtype=torch.bool, device=x_cl.device)
+        self.act = self._cache[key]
+
+    def __enter__(self):
+        self.prev, _M._cur_active = _M._cur_active, self.act
+
+    def __exit__(self, *a):
+        _M._cur_active = self.prev
+
+
 def _bshift(mi: Optional[ops.MaskInfo], D: int) -> int:
     if mi is None:
         return 0
@@ -138,8 +160,13 @@ class SparseConvNeXtLayerNorm(nn.LayerNorm):
         self.data_format, self.sparse = data_format, sparse
 
     def forward(self, x):
-        if x.ndim != 5 or not self.sparse:
-            raise NotImplementedError("SparseConvNeXtLayerNorm: 5-D sparse input only")
+        if x.ndim != 5:
+            raise NotImplementedError("SparseConvNeXtLayerNorm: 5-D input only")
+        if not self.sparse:                             # encoder3D.py:197-198 / :207-212: plain LayerNorm over C at EVERY voxel
+            xc = x.contiguous() if self.data_format == "channels_last" else _cl(x)
+            with _all_active(xc):
+                y = _VoxelNormFn.apply(xc, self.weight, self.bias, 0, 1, self.eps)
+            return y if self.data_format == "channels_last" else _nc(y)
         if self.data_format == "channels_last":
             return _VoxelNormFn.apply(x.contiguous(), self.weight, self.bias, 0, 1, self.eps)
         return _nc(_VoxelNormFn.apply(_cl(x), self.weight, self.bias, 0, 1, self.eps))
@@ -227,9 +254,12 @@ class SparseAvgPooling(nn.AvgPool3d):
     """encoder3D.py:35-36."""
 
     def forward(self, x):
-        if self.divisor_override is not None:
-            raise NotImplementedError("SparseAvgPooling: divisor_override is not supported")
         k = _one(self.kernel_size)
+        if self.divisor_override is not None:           # window SUM / divisor: the count_include_pad average (sum / k^3) rescaled
+            if self.ceil_mode:
+                raise NotImplementedError("SparseAvgPooling: divisor_override together with ceil_mode (windows clipped at the padded end)")
+            y = _PoolFn.apply(_cl(x), 1, k, _one(self.stride if self.stride is not None else k), _one(self.padding), True, 1, bool(self.ceil_mode))
+            return _nc(y) * (float(k ** 3) / float(self.divisor_override))
         return _nc(_PoolFn.apply(_cl(x), 1, k, _one(self.stride if self.stride is not None else k), _one(self.padding), self.count_include_pad, 1,
                                  bool(self.ceil_mode)))
 

@@ -131,6 +131,68 @@ def test_pooling_ceil_mode_and_dilation(SL, case, dtype):
     assert ((xd.grad.float().cpu() - xr.grad) * mi_).abs().max().item() <= (1e-5 if dtype == torch.float32 else 3e-2) * max(1.0, xr.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_avg_pooling_divisor_override(SL, masked):
+    """nn.AvgPool3d(divisor_override=...) -- forwarded by the converter (encoder3D.py:318-320) -- : window sum / divisor."""
+    from anatomask_amd import modules
+    torch.manual_seed(6)
+    B, C, size = 2, 16, (16, 16, 16)
+    x = torch.randn(B, C, *size)
+    active = torch.rand(B, 1, 4, 4, 4) < 0.5
+    active[0, 0, 0, 0, 0] = True
+    if masked:
+        set_active(active)
+        x = x * up(active, size).float()
+    else:
+        modules._cur_active = None
+    ref, mod = torch.nn.AvgPool3d(3, 2, 1, divisor_override=5), SL.SparseAvgPooling(3, 2, 1, divisor_override=5)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    mo = up(active, yr.shape[2:]).float() if masked else torch.ones(1)
+    yr = yr * mo
+    g = torch.randn_like(yr)
+    (yr * g).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    y = mod(xd)
+    (y * g.to(DEV)).sum().backward()
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 1e-5 * max(1.0, yr.abs().max().item())
+    mi_ = up(active, size).float() if masked else torch.ones(1)
+    assert ((xd.grad.cpu() - xr.grad) * mi_).abs().max().item() <= 1e-5 * max(1.0, xr.grad.abs().max().item())
+    with pytest.raises(NotImplementedError):
+        SL.SparseAvgPooling(3, 2, 1, ceil_mode=True, divisor_override=5)(xd)
+    modules._cur_active = None
+
+
+@pytest.mark.parametrize("fmt", ["channels_first", "channels_last"])
+def test_layer_norm_dense_branch(SL, fmt):
+    """SparseConvNeXtLayerNorm(sparse=False) (encoder3D.py:197-198, 207-212): LayerNorm over C at EVERY voxel, whatever the current mask says."""
+    torch.manual_seed(7)
+    B, C, size = 2, 24, (8, 12, 16)
+    active = torch.rand(B, 1, 2, 3, 4) < 0.5
+    active[0, 0, 0, 0, 0] = True
+    set_active(active)                                                   # a mask IS set: the dense branch must ignore it ...
+    from anatomask_amd import modules
+    before = modules._cur_active
+    x = torch.randn(B, C, *size) if fmt == "channels_first" else torch.randn(B, *size, C)
+    mod = SL.SparseConvNeXtLayerNorm(C, eps=1e-6, data_format=fmt, sparse=False)
+    with torch.no_grad():
+        mod.weight.copy_(1 + 0.2 * torch.randn(C)); mod.bias.copy_(0.2 * torch.randn(C))
+    xr = x.clone().requires_grad_(True)
+    xl = xr if fmt == "channels_last" else xr.permute(0, 2, 3, 4, 1)
+    yr = torch.nn.functional.layer_norm(xl, (C,), mod.weight.detach(), mod.bias.detach(), 1e-6)
+    yr = yr if fmt == "channels_last" else yr.permute(0, 4, 1, 2, 3)
+    g = torch.randn_like(yr)
+    (yr * g).sum().backward()
+    mod = mod.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    y = mod(xd)
+    (y * g.to(DEV)).sum().backward()
+    assert (y.detach().cpu() - yr.detach()).abs().max().item() <= 2e-5 * max(1.0, yr.abs().max().item())
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
+    assert modules._cur_active is before                                 # ... and leave it in place
+    modules._cur_active = None
+
+
 def test_batch_norm_fixture(SL):
     bn = load_params(SL.SparseBatchNorm3d(16), "bn_train")
     run_fixture("bn_train", bn)
