@@ -371,3 +371,38 @@ def test_config4_stunet_l_160_mask07_bf16_vs_fp32_storage_full_size():
 
 def test_config5_stunet_h_192_recompute_bf16_vs_fp32_storage_full_size():
     _bf16_vs_fp32_storage_full_size("H", 192, 0.6, True, 141)
+
+
+def test_config2_bf16_training_tracks_fp32_storage_training():
+    """configs[1] at TRAINING level: 10 optimizer steps of STUNet-B 128^3 (B=2, one repeated batch, plain-SparK mode so that both runs see
+    the same random masks) in bf16 storage -- the dense convolutions on conv_k3_kernel -- against the same steps in fp32 storage
+    (split-bf16 products): the loss curve must fall, and the bf16 curve must follow the fp32 one step by step.  A per-step bias of the
+    bf16 kernels (a wrong tap, a dropped halo row, a statistics epilogue off by a brick) compounds over the steps and shows here even if
+    a single step's tensors pass the per-tensor bounds.  Measured (printed): loss 1.013 -> 0.775 (bf16) / 0.773 (fp32), max per-step relative distance 7e-3."""
+    from anatomask_amd import modules as M
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    kw = M.STUNET_CONFIGS["B"]
+    steps, lr = 10, 1e-3
+    torch.manual_seed(3)
+    base = M.build_spark(kw["dims"], kw["depth"], kw["width"], (128,) * 3, 0.6)
+    W0 = {k: v.clone() for k, v in base.state_dict().items()}
+    g = torch.Generator().manual_seed(17)
+    # a learnable volume: smooth structure + noise (pure noise has nothing to reconstruct and the curve would not move)
+    z = torch.randn(2, 1, 16, 16, 16, generator=g)
+    x = (torch.nn.functional.interpolate(z, size=(128,) * 3, mode="trilinear", align_corners=False) + 0.1 * torch.randn(2, 1, 128, 128, 128, generator=g)).to(DEV)
+    curves = {}
+    for name, dtype, split in (("bf16", torch.bfloat16, False), ("fp32", torch.float32, True)):
+        m = M.build_spark(kw["dims"], kw["depth"], kw["width"], (128,) * 3, 0.6, compute_dtype=dtype)
+        m.load_state_dict({k: v.clone() for k, v in W0.items()})
+        tr = AnatoMaskTrainer(m.to(DEV), lr=lr, total_epochs=1000, seed=99, distributed=False, self_distill=False, f32_split=split)
+        curves[name] = [tr.step(x, epoch=0)["loss"].item() for _ in range(steps)]
+        del tr, m
+        torch.cuda.empty_cache()
+    from anatomask_amd import ops
+    ops.F32_SPLIT = False
+    b, f = np.array(curves["bf16"]), np.array(curves["fp32"])
+    print("bf16 curve", np.round(b, 5).tolist()); print("fp32 curve", np.round(f, 5).tolist())
+    print("per-step relative distance", np.round(np.abs(b - f) / f, 5).tolist())
+    assert f[-1] < 0.9 * f[0], "the fp32-storage run must learn something on this batch"
+    assert np.all(np.abs(b - f) <= 1e-2 * f), (b, f)
+    assert abs((b[0] - b[-1]) - (f[0] - f[-1])) <= 0.1 * (f[0] - f[-1])             # the same amount of progress

@@ -17,7 +17,8 @@ SIZE, PATCH, MR = os.environ.get("AM_CENSUS_SIZE", "B"), int(os.environ.get("AM_
 ACT = 1.0 - MR                                   # active fraction: block-sparse launches are credited with the active voxels' flops
 kw = M.STUNET_CONFIGS[SIZE]                      # AM_CENSUS_SIZE=L AM_CENSUS_PATCH=160 AM_CENSUS_MASK=0.7 python tools/conv_census.py 4
 torch.manual_seed(0)
-model = M.build_spark(kw["dims"], kw["depth"], kw["width"], (PATCH,) * 3, MR, compute_dtype=torch.bfloat16).to(dev)
+model = M.build_spark(kw["dims"], kw["depth"], kw["width"], (PATCH,) * 3, MR, compute_dtype=torch.bfloat16,
+                      recompute=bool(int(os.environ.get("AM_CENSUS_RECOMPUTE", "0")))).to(dev)   # (recompute: the re-run forward launches are listed too)
 tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=1)
 x = torch.randn(B, 1, PATCH, PATCH, PATCH, device=dev)
 engine._USE_SIDE = False
