@@ -44,6 +44,8 @@ struct WgArgs {
   int split, ntile;           // brick-walk slots per (tile, group) ; (cy, cx) channel tiles
   int y_uni;                  // block-sparse dY whose bricks each lie inside ONE patch, grid = whole bricks: one mask lookup per brick
   int mask_off, mask_n;       // block-sparse operands: LDS byte offset of the two cached patch-mask arrays (dY's, X's) of ONE sample, bytes each (0: not cached)
+  const int* plist; int nlive, pbd, pbh, pbw;   // y_uni launches with an active-patch list: the walk runs over the LIVE bricks only (patch list entry
+                              // b << 24 | pd << 16 | ph << 8 | pw, pbd x pbh x pbw bricks per patch), so every slot gets the same number of them
   int walk, seg_len, nseg;    // walk 1: d-fastest segments of seg_len bricks, columns interleaved over the slots of an XCD (see the kernel)
   float* det_ws;              // deterministic mode: [split][k^3][Cy][Cx] per-slot partial sums (plain stores), folded in slot order
   long det_stride;            //   floats per slot
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
 
   const T* __restrict__ xg = (const T*)a.x;
   const T* __restrict__ yg = (const T*)a.dy;
-  const int nbrick = a.B * a.nbd * a.nbh * a.nbw;
+  const int nbrick = a.plist ? a.nlive : a.B * a.nbd * a.nbh * a.nbw;
   const size_t yplane = (size_t)a.Hy * a.Wy * a.Cy, xplane = (size_t)a.Hx * a.Wx * a.Cx;
   const bool masked = a.x_mask.m != nullptr || a.y_mask.m != nullptr;
   const int Dy_ = a.Dy, Hy_ = a.Hy, Wy_ = a.Wy, Dx_ = a.Dx, Hx_ = a.Hx, Wx_ = a.Wx, OS_ = a.OS, GS_ = a.GS;
@@ -178,8 +180,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   const int chunk = (nbrick + a.split - 1) / a.split;
   const int brick0 = slot * chunk, brick1 = brick0 + chunk < nbrick ? brick0 + chunk : nbrick;
   int bw_, bh_, bd_, b;
+  const int bpp_ = a.pbd * a.pbh * a.pbw, pbhw_ = a.pbh * a.pbw;
   {
-    int bid = brick0;
+    int bid = a.plist ? 0 : brick0;
     bw_ = bid % a.nbw; bid /= a.nbw;
     bh_ = bid % a.nbh; bid /= a.nbh;
     bd_ = bid % a.nbd; b = bid / a.nbd;
@@ -295,9 +298,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   }
   for (int step = 0; step < nstep; ++step) {
     if (a.walk) ++bd_;
+    else if (a.plist) {
+      // live bricks only, (active patch, brick inside it): a contiguous run of ALL bricks holds 40 % live ones on average, but the share
+      // of one slot's run spreads by +-45 % (64 patches per run at 16^3 patches) and the slowest slot is the launch
+      const int i = brick0 + step, ip = i / bpp_, j = i - ip * bpp_;
+      const int pk = __builtin_amdgcn_readfirstlane(a.plist[ip]);
+      b = (pk >> 24) & 255;
+      bd_ = ((pk >> 16) & 255) * a.pbd + j / pbhw_; bh_ = ((pk >> 8) & 255) * a.pbh + (j / a.pbw) % a.pbh; bw_ = (pk & 255) * a.pbw + j % a.pbw;
+    }
     else if (++bw_ == nbw_) { bw_ = 0; if (++bh_ == nbh_) { bh_ = 0; if (++bd_ == nbd_) { bd_ = 0; ++b; } } }
     const int q0d = bd_ * BD, q0h = bh_ * BH, q0w = bw_ * BW;
-    if (a.y_uni && a.mask_n) {
+    if (a.y_uni && a.mask_n && !a.plist) {
       // (uniform) block-sparse dY whose brick lies inside ONE patch of a grid of whole bricks: one lookup keeps or skips the brick,
       // before anything else is computed for it (60 % of the visits end here)
       if (b != mask_b) load_masks();
@@ -516,6 +527,15 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
   {
     const int pq = 1 << a.y_mask.bs;                 // patch edge in dY voxels
     a.y_uni = a.y_mask.m && a.OS == 1 && pq % BD == 0 && pq % BH == 0 && pq % BW == 0 && a.Dy % BD == 0 && a.Hy % BH == 0 && a.Wy % BW == 0;
+    // (measured, profiles/r04_experiments.md: 16^3 patches -5 ... -9 % on the level-0 launches of STUNet-B / L / H, 4^3 patches -6 %; 8^3 patches
+    // +-5 % either way -- a run of 8-wide bricks re-reads its w-halo from the neighbouring brick of the same patch row either way)
+    if (a.y_uni && a.plist && a.nlive > 0 && pq != 8 && a.B <= 255 && a.y_mask.fd <= 255 && a.y_mask.fh <= 255 && a.y_mask.fw <= 255) {
+      a.pbd = pq / BD; a.pbh = pq / BH; a.pbw = pq / BW;
+      a.nlive *= a.pbd * a.pbh * a.pbw;                  // (entry: active patches) -> live bricks
+      nbrick = a.nlive;
+    } else {
+      a.plist = nullptr; a.nlive = 0; a.pbd = a.pbh = a.pbw = 1;
+    }
   }
   if (a.x_mask.m || a.y_mask.m) {                 // one sample's patch masks ride along in LDS when they are small (8^3 .. 12^3 patches)
     const MaskView& mv = a.y_mask.m ? a.y_mask : a.x_mask;
@@ -597,12 +617,133 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
   return 0;
 }
 
+
+// ================================================================== gather form (patches smaller than a brick)
+// Levels whose patches are 1 or 2 voxels wide (the two deepest of a 16x down-sampling encoder) leave the brick kernel above with 30-40 %
+// live voxels in every brick it stages, a few thousand voxels in total and a [27][Cy][Cx] block of atomics per brick-walk slot:
+// 65-270 TFLOP/s on the 512 ... 1536-channel layers of STUNet-L / H.  Here the ACTIVE voxels are gathered once into K-major operands
+//     YT[cy][n] = dY[q_n][cy],      XT[t][cx][n] = X[q_n * stride + shift_t][cx]   (0 outside the volume / in an inactive patch),
+// n = 0 .. N-1 over the active dY voxels (patch list order), padded with zeros to a multiple of 32, and the weight gradient is 27 plain
+// GEMMs  dW[t] += YT . XT[t]^T  whose fragments are 16-byte global loads (both operands K-contiguous: no LDS, no transposing reads).
+struct WgGather {
+  const bf16_t* x; const bf16_t* dy;
+  int B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy;
+  int stride, k, pq, pq3;              // patch edge of the dY grid in voxels (1 or 2)
+  const int* plist; int N, Np;         // active patches; active dY voxels; Np = N rounded up to 32
+  MaskView x_mask;
+  int t0, nt;                          // taps [t0, t0 + nt) of this round
+  bf16_t* yt; bf16_t* xt;              // [Cy][Np], [nt][Cx][Np]
+};
+
+__global__ __launch_bounds__(256) void wg_gather_t_kernel(WgGather a) {
+  __shared__ bf16_t tile[32][72];                        // 32 voxels x 64 channels (+8: the transposed 2-byte reads spread over the banks)
+  const int tid = threadIdx.x, n0 = blockIdx.x * 32;
+  const bool is_y = blockIdx.y == 0;
+  const int t = a.t0 + (int)blockIdx.y - 1;
+  const int C = is_y ? a.Cy : a.Cx;
+  const bf16_t* src = is_y ? a.dy : a.x;
+  bf16_t* dst = is_y ? a.yt : a.xt + (size_t)(blockIdx.y - 1) * a.Cx * a.Np;
+  // source voxel of this thread's row (v = tid / 8): -1 = zeros
+  const int v = tid >> 3, ch = tid & 7, n = n0 + v;
+  long row = -1;
+  if (n < a.N) {
+    const int ip = n / a.pq3, j = n - ip * a.pq3;
+    const int pk = a.plist[ip];
+    const int b = (pk >> 24) & 255;
+    const int qd = ((pk >> 16) & 255) * a.pq + j / (a.pq * a.pq), qh = ((pk >> 8) & 255) * a.pq + (j / a.pq) % a.pq, qw = (pk & 255) * a.pq + j % a.pq;
+    if (is_y) row = (((long)b * a.Dy + qd) * a.Hy + qh) * a.Wy + qw;
+    else {
+      const int pad = a.k / 2, td = t / (a.k * a.k), th = (t / a.k) % a.k, tw = t % a.k;
+      const int id = qd * a.stride + td - pad, ih = qh * a.stride + th - pad, iw = qw * a.stride + tw - pad;
+      if (id >= 0 && id < a.Dx && ih >= 0 && ih < a.Hx && iw >= 0 && iw < a.Wx && a.x_mask.active(b, id, ih, iw))
+        row = (((long)b * a.Dx + id) * a.Hx + ih) * a.Wx + iw;
+    }
+  }
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    u32x4 val = u32x4{0u, 0u, 0u, 0u};
+    if (row >= 0 && c0 + ch * 8 < C) val = *(const u32x4*)(src + (size_t)row * C + c0 + ch * 8);
+    __syncthreads();                                     // the previous slab's column reads are done
+    *(u32x4*)&tile[v][ch * 8] = val;
+    __syncthreads();
+    const int c = tid >> 2, vg = tid & 3;                // channel c of the slab, voxels 8 vg .. 8 vg + 7
+    if (c0 + c < C) {
+      u32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (unsigned)tile[8 * vg + 2 * i][c] | ((unsigned)tile[8 * vg + 2 * i + 1][c] << 16);
+      *(u32x4*)(dst + (size_t)(c0 + c) * a.Np + n0 + 8 * vg) = o;
+    }
+  }
+}
+
+// dW[t][cy][cx] += sum_n YT[cy][n] XT[t][cx][n]: workgroup tile 128 cy x 64 cx, 2 x 2 waves of 64 x 32 (4 x 2 MFMA tiles), k-steps of 32 with the
+// next step's fragments in flight; grid (tiles, taps, k splits).  One k split: every element has one writer, plain read-modify-write
+// (deterministic); more: fp32 atomics.
+__global__ __launch_bounds__(256) void wg_gemm_nt_kernel(const bf16_t* __restrict__ yt, const bf16_t* __restrict__ xt, float* __restrict__ dw,
+                                                         int Cy, int Cx, int Np, int k, int t0, int ksplit) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, r16 = lane & 15;
+  const int ntx = Cx / 64, ty = blockIdx.x / ntx, tx = blockIdx.x % ntx;
+  const int cy0 = ty * 128 + (wave >> 1) * 64, cx0 = tx * 64 + (wave & 1) * 32;
+  const bf16_t* A = yt + (size_t)(cy0 + r16) * Np + 8 * g;
+  const bf16_t* Bm = xt + ((size_t)blockIdx.y * Cx + cx0 + r16) * Np + 8 * g;
+  const int steps = Np / 32, per = (steps + ksplit - 1) / ksplit;
+  const int s0 = blockIdx.z * per, s1 = s0 + per < steps ? s0 + per : steps;
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  if (s0 < s1) {
+    u32x4 a[4], b[2], an[4], bn[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *(const u32x4*)(A + (size_t)(16 * i) * Np + 32 * s0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const u32x4*)(Bm + (size_t)(16 * j) * Np + 32 * s0);
+    for (int s = s0; s < s1; ++s) {
+      const int sn = s + 1 < s1 ? s + 1 : s;             // (the last step re-loads itself: no branch around the loads)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) an[i] = *(const u32x4*)(A + (size_t)(16 * i) * Np + 32 * sn);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bn[j] = *(const u32x4*)(Bm + (size_t)(16 * j) * Np + 32 * sn);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mma_chunk<bf16_t>(a[i], b[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = an[i];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = bn[j];
+    }
+  }
+  // D row = cy 4g + r, col = cx r16
+  float* out = dw + (size_t)(t0 + blockIdx.y) * Cy * Cx;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* p = out + (size_t)(cy0 + 16 * i + 4 * g + r) * Cx + cx0 + 16 * j + r16;
+        if (ksplit == 1) *p += acc[i][j][r]; else atomicAdd(p, acc[i][j][r]);
+      }
+}
+
+// the gather form applies: bf16, conv k3 (stride 1 or 2), block-sparse dY with 1- or 2-voxel patches and an active-patch list, channel
+// counts that tile by 128 x 64
+inline bool wg_gather_ok(int mode, int dtype, int k, int stride, int Cx, int Cy, const uint8_t* y_mask, int y_bshift, const int32_t* list,
+                         int n_active, int B, int fd, int fh, int fw) {
+  // where it was measured ahead of the brick kernel (profiles/r04_experiments.md): one-voxel patches, and the strided layers into 2-voxel patches from
+  // 256 input channels on (the brick kernel stages 8 parity sub-lattices there).  Its GEMM is bound by L2 bandwidth at ~160 TFLOP/s (128 x 64
+  // tiles: 43 flop per byte), which the stride-1 layers of the 2-voxel-patch level already reach on the brick kernel.
+  if (!(y_bshift == 0 || (y_bshift == 1 && stride == 2 && Cx >= 256))) return false;
+  return mode == AM_CONV_FWD && dtype == AM_DT_BF16 && k == 3 && (stride == 1 || stride == 2) && y_mask && list && n_active > 0 &&
+         Cy % 128 == 0 && Cx % 64 == 0 && B <= 255 && fd <= 255 && fh <= 255 && fw <= 255;
+}
+
 }  // namespace
 
 extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, const void* dy, float* dw_packed,
                                int B, int Dx, int Hx, int Wx, int Cx, int Dy, int Hy, int Wy, int Cy,
                                const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift,
-                               int fd, int fh, int fw, float* det_workspace, long det_workspace_floats, void* stream) {
+                               int fd, int fh, int fw, float* det_workspace, long det_workspace_floats,
+                               const int32_t* active_list, int n_active, void* gather_workspace, long gather_workspace_bytes, void* stream) {
   if (Cx % 8 || Cy % 8) return -1;
   if ((size_t)8 * Hx * Wx * Cx * 4 >= 0x7fffff00ull || (size_t)8 * Hy * Wy * Cy * 4 >= 0x7fffff00ull) return -5;   // planes a brick spans
   WgArgs a;
@@ -613,7 +754,37 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   a.B = B; a.Dx = Dx; a.Hx = Hx; a.Wx = Wx; a.Cx = Cx; a.Dy = Dy; a.Hy = Hy; a.Wy = Wy; a.Cy = Cy;
   a.x_mask = MaskView{x_mask, fd, fh, fw, x_bshift};
   a.y_mask = MaskView{y_mask, fd, fh, fw, y_bshift};
+  const int* const plist0 = (y_mask && active_list && n_active > 0) ? active_list : nullptr;
   const int k = ksize;
+  if (gather_workspace && wg_gather_ok(mode, dtype, ksize, stride, Cx, Cy, y_mask, y_bshift, active_list, n_active, B, fd, fh, fw)) {
+    WgGather ga;
+    ga.x = (const bf16_t*)x; ga.dy = (const bf16_t*)dy;
+    ga.B = B; ga.Dx = Dx; ga.Hx = Hx; ga.Wx = Wx; ga.Cx = Cx; ga.Dy = Dy; ga.Hy = Hy; ga.Wy = Wy; ga.Cy = Cy;
+    ga.stride = stride; ga.k = ksize; ga.pq = 1 << y_bshift; ga.pq3 = ga.pq * ga.pq * ga.pq;
+    ga.plist = active_list; ga.N = n_active * ga.pq3; ga.Np = (ga.N + 31) / 32 * 32;
+    ga.x_mask = MaskView{x_mask, fd, fh, fw, x_bshift};
+    const long per_tap = (long)Cx * ga.Np * 2, ybytes = (long)Cy * ga.Np * 2;
+    const int ntaps = ksize * ksize * ksize;
+    int round = (int)((gather_workspace_bytes - ybytes) / per_tap);          // taps per round the workspace holds
+    if (round >= 1) {
+      if (round > ntaps) round = ntaps;
+      hipStream_t st = (hipStream_t)stream;
+      ga.yt = (bf16_t*)gather_workspace; ga.xt = (bf16_t*)((char*)gather_workspace + ybytes);
+      const int tiles = (Cy / 128) * (Cx / 64);
+      for (int t0 = 0; t0 < ntaps; t0 += round) {
+        ga.t0 = t0; ga.nt = t0 + round <= ntaps ? round : ntaps - t0;
+        // (every round rewrites the dY plane with the same values: one more row of blocks, no second kernel)
+        AM_LAUNCH(wg_gather_t_kernel, dim3((unsigned)(ga.Np / 32), (unsigned)(ga.nt + 1), 1), dim3(256), 0, st, ga);
+        AM_CHECK_LAUNCH();
+        int ksplit = 1;
+        if (!det_workspace && tiles * ga.nt < 512) { ksplit = (512 + tiles * ga.nt - 1) / (tiles * ga.nt); if (ksplit > ga.Np / 64) ksplit = ga.Np / 64 > 0 ? ga.Np / 64 : 1; }
+        AM_LAUNCH(wg_gemm_nt_kernel, dim3((unsigned)tiles, (unsigned)ga.nt, (unsigned)ksplit), dim3(256), 0, st, ga.yt, ga.xt, dw_packed, Cy, Cx, ga.Np,
+                  ksize, t0, ksplit);
+        AM_CHECK_LAUNCH();
+      }
+      return 0;
+    }
+  }
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WG_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
 #endif
@@ -721,6 +892,7 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     for (int gI = 0; gI < nunit; ++gI) if (ucount[gI] == ntap) a.zmap[a.ngroup++] = gI;
     if (!a.ngroup) continue;
     const int tiles = ((Cy + 16 * mi - 1) / (16 * mi)) * ((Cx + 16 * nwx - 1) / (16 * nwx)) * a.ngroup;
+    a.plist = plist0; a.nlive = plist0 ? n_active : 0; a.pbd = a.pbh = a.pbw = 1;      // (launch() turns patches into live bricks of ITS brick shape)
     int rc = -2;
 #define WG_CASE(TT_, BH_, BW_, NT_, NX_) rc = launch<TT_, 2, BH_, BW_, NT_, NX_>(a, maxvox, tiles, nbrick, det_slots, st)
     if (s2full) rc = bw == 8 ? launch<bf16_t, 1, 8, 8, 9, 5, 4, 2, true, true>(a, maxvox, tiles, nbrick, det_slots, st)
@@ -752,5 +924,17 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
 #undef WG_CASE
     if (rc) return rc;
   }
+  return 0;
+}
+
+extern "C" int am_conv3d_wgrad_gather_bytes(int mode, int dtype, int ksize, int stride, int B, int Cx, int Cy, int y_bshift, int has_y_mask, int n_active,
+                                            int fd, int fh, int fw, long* bytes) {
+  static const uint8_t one = 1; static const int32_t lst = 0;
+  if (!bytes) return -1;
+  *bytes = 0;
+  if (!wg_gather_ok(mode, dtype, ksize, stride, Cx, Cy, has_y_mask ? &one : nullptr, y_bshift, &lst, n_active, B, fd, fh, fw)) return 0;
+  const long pq3 = 1L << (3 * y_bshift), Np = ((long)n_active * pq3 + 31) / 32 * 32;
+  const long ntaps = (long)ksize * ksize * ksize, all = 2 * Np * (Cy + ntaps * Cx), third = 2 * Np * (Cy + (ntaps / 3) * Cx);
+  *bytes = all <= (640L << 20) ? all : third;            // all 27 taps in one round when that stays under 640 MB, else three rounds of 9
   return 0;
 }

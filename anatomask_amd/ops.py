@@ -268,6 +268,9 @@ def _det_workspace(device, floats_per_slot: int):
     return t
 
 
+GATHER_WGRAD = True      # (tools: same-process A/B of the gather-form weight gradient)
+
+
 def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int,
                  x_mask: Optional[MaskInfo] = None, x_bshift: int = 0, y_mask: Optional[MaskInfo] = None,
                  y_bshift: int = 0) -> torch.Tensor:
@@ -279,12 +282,22 @@ def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, strid
     mp, fd, fh, fw = _mk(mk)
     ws = _det_workspace(x.device, taps * Cy * Cx) if DETERMINISTIC_WGRAD else None
 
+    al = _al(y_mask)
+    # levels with 1- / 2-voxel patches: the gather form (K-major copies of the active voxels + plain GEMMs) needs scratch
+    gb = 0
+    if GATHER_WGRAD and al[1] > 0 and x.dtype == torch.bfloat16 and y_bshift <= 1:
+        out_b = _ct.c_long(0)
+        hip.lib().conv3d_wgrad_gather_bytes(mode, _dt(x), ksize, stride, B, Cx, Cy, y_bshift, int(y_mask is not None), al[1], fd, fh, fw, _ct.byref(out_b))
+        gb = int(out_b.value)
+    gws = torch.empty(gb, device=x.device, dtype=torch.uint8) if gb > 0 else None
+
     def launch(xx, yy):
         hip.lib().conv3d_wgrad(mode, _dt(xx), ksize, stride, xx.data_ptr(), yy.data_ptr(), dw.data_ptr(),
                                B, Dx, Hx, Wx, Cx, Dy, Hy, Wy, Cy,
                                x_mask.t.data_ptr() if x_mask else None, x_bshift,
                                y_mask.t.data_ptr() if y_mask else None, y_bshift, fd, fh, fw,
-                               ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream())
+                               ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, *al,
+                               gws.data_ptr() if gws is not None else None, gb, _stream())
     if x.dtype == torch.float32 and F32_SPLIT:
         # AM_DT_F32S: dW = X^T dY with X = Xh + Xl, dY = Yh + Yl (bf16 planes, am_split_bf16): three bf16 matrix-core contractions
         # accumulate into the ONE fp32 gradient (atomics, or the deterministic fold: both add into dw); the lo lo term (2^-16 of the

@@ -197,13 +197,19 @@ def secondary_lines(a, kw, dev, dtype_main):
     out = []
     torch.cuda.synchronize()
     from anatomask_amd import ops as _ops
-    for what, size3, batch, dt, warm, steps, split in [
-            ("same workload at the reference's batch size 4", (a.patch,) * 3, 4, dtype_main, 5, 11, False),
+    for what, size3, batch, dt, warm, steps, split, size, mr, rc in [
+            ("same workload at the reference's batch size 4", (a.patch,) * 3, 4, dtype_main, 5, 11, False, None, a.mask_ratio, False),
             ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False), split-bf16 products (AM_DT_F32S: hi hi + hi lo + lo hi (+ lo lo), fp32 accumulation)",
-             (112, 112, 128), 4, torch.float32, 3, 7, True),
-            ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False), exact-f32 MFMA (the parity mode)", (112, 112, 128), 4, torch.float32, 2, 5, False)]:
+             (112, 112, 128), 4, torch.float32, 3, 7, True, None, a.mask_ratio, False),
+            ("reference recipe: 112x112x128, batch 4, fp32 storage (AMP=False), exact-f32 MFMA (the parity mode)", (112, 112, 128), 4, torch.float32, 2, 5, False,
+             None, a.mask_ratio, False),
+            # BASELINE.json configs[3] / configs[4] (single-GPU rows): the larger backbones, full AnatoMask step, bf16
+            ("BASELINE configs[3]: STUNet-L AnatoMask step, 160^3, mask_ratio 0.7, batch 4, bf16", (160,) * 3, 4, torch.bfloat16, 2, 5, False, "L", 0.7, False),
+            ("BASELINE configs[4]: STUNet-H AnatoMask step, 192^3, mask_ratio 0.6, batch 2, bf16, activation recomputation (P/GC.py)", (192,) * 3, 2, torch.bfloat16,
+             2, 3, False, "H", 0.6, True)]:
         torch.manual_seed(0)
-        model = M.build_spark(kw["dims"], kw["depth"], kw["width"], size3, a.mask_ratio, compute_dtype=dt).to(dev)
+        kw_ = kw if size is None else M.STUNET_CONFIGS[size]
+        model = M.build_spark(kw_["dims"], kw_["depth"], kw_["width"], size3, mr, compute_dtype=dt, recompute=rc).to(dev)
         tr = AnatoMaskTrainer(model, lr=1e-4, total_epochs=1000, seed=4321, distributed=False, f32_split=split)
         tr.set_epoch(500)
         x = torch.randn(batch, 1, *size3, device=dev, generator=torch.Generator(device=dev).manual_seed(1234))

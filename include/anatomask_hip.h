@@ -92,7 +92,18 @@ int am_partials_reduce(const float* partials, int rows, int C, double* sums, flo
 int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, const void* dy, float* dw_packed,
                     int B, int Dx, int Hx, int Wx, int Cx, int Dy, int Hy, int Wy, int Cy,
                     const uint8_t* x_mask, int x_bshift, const uint8_t* y_mask, int y_bshift, int fd, int fh, int fw,
-                    float* det_workspace, long det_workspace_floats, void* stream);
+                    float* det_workspace, long det_workspace_floats,
+                    const int32_t* active_list, int n_active /* NULL / 0, or am_mask_compact's list of the patch mask (both masks are views of ONE
+                    patch mask): block-sparse dY whose bricks lie inside one patch is then walked over its LIVE bricks only, the same number
+                    per workgroup slot (a contiguous run of all bricks gives the slots 40 % +- 45 % live ones, and the slowest slot is the launch) */,
+                    void* gather_workspace, long gather_workspace_bytes /* NULL / 0, or scratch for the GATHER form (bf16, k3, stride 1 / 2, dY patches 1 or
+                    2 voxels wide, an active list, Cy % 128 == 0, Cx % 64 == 0): the active voxels are gathered into K-major operands YT[Cy][Np],
+                    XT[tap][Cx][Np] (Np = active dY voxels rounded up to 32) and the gradient is 27 plain GEMMs; holds YT + at least one tap:
+                    2 * Np * (Cy + taps_per_round * Cx) bytes, fewer taps per round = more rounds.  am_conv3d_wgrad_gather_bytes sizes it (0: the
+                    gather form does not apply to this launch) */,
+                    void* stream);
+int am_conv3d_wgrad_gather_bytes(int mode, int dtype, int ksize, int stride, int B, int Cx, int Cy, int y_bshift, int has_y_mask, int n_active,
+                                 int fd, int fh, int fw, long* bytes /* (host) out */);
 
 /* x (n floats, n % 4 == 0) -> hi = bf16(x), lo = bf16(x - hi) as two bf16 tensors of the same shape (AM_DT_F32S weight gradients: three
  * bf16 am_conv3d_wgrad launches on the planes -- hi hi, lo hi, hi lo -- accumulate into ONE fp32 gradient).  The reference computes these

@@ -120,12 +120,17 @@ def test_conv_wgrad_narrow_channels_wide_grid(ops, case, sparse):
 
 
 @pytest.mark.parametrize("case", [(64, 64, 3, 1, 3, (2, 2, 2)), (32, 32, 3, 1, 4, (1, 1, 2)), (64, 64, 3, 1, 2, (2, 4, 8)), (64, 96, 3, 1, 1, (4, 8, 8)),
-                                  (32, 64, 3, 2, 3, (1, 2, 2)), (64, 128, 3, 2, 2, (2, 4, 4)), (128, 64, 3, 2, 1, (4, 4, 8)), (64, 64, 1, 2, 3, (1, 2, 2))])
+                                  (32, 64, 3, 2, 3, (1, 2, 2)), (64, 128, 3, 2, 2, (2, 4, 4)), (128, 64, 3, 2, 1, (4, 4, 8)), (64, 64, 1, 2, 3, (1, 2, 2)),
+                                  # gather form (am_conv3d_wgrad gather_workspace: 1- / 2-voxel patches, Cy % 128 == 0, Cx % 64 == 0): K-major copies of the
+                                  # active voxels + plain GEMMs; odd grids, stride 1 and 2, one tile and several, k splits (atomics) and one writer (det)
+                                  (64, 128, 3, 1, 1, (4, 8, 8)), (128, 128, 3, 1, 0, (6, 5, 7)), (64, 128, 3, 2, 1, (3, 4, 5)), (192, 256, 3, 2, 0, (5, 6, 4)),
+                                  (256, 256, 3, 1, 0, (12, 12, 12)), (256, 128, 3, 2, 1, (3, 4, 5))])
 @pytest.mark.parametrize("det", [False, True])
 def test_conv_wgrad_block_sparse_ignores_inactive_voxels(ops, case, det):
-    """Block-sparse weight gradients at the patch widths of the encoder levels (dY patches 16 / 8 / 4 / 2 voxels wide): bricks inside
+    """Block-sparse weight gradients at the patch widths of the encoder levels (dY patches 16 / 8 / 4 / 2 / 1 voxels wide): bricks inside
     one patch are kept or skipped on ONE mask lookup (8-wide patches take 8x8 bricks for that), bricks that span patches test every
-    staged row.  The inactive voxels of X and dY hold NaN here: nothing may be read from them."""
+    staged row; the deepest levels' wide layers take the gather form.  The inactive voxels of X and dY hold NaN here: nothing may be read
+    from them."""
     cin, cout, k, s, bs_out, f = case
     dtype = torch.bfloat16
     B = 2
