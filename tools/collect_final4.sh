@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 cp $src/bench.json profiles/${tag}_bench.json
 cp $src/bench_stunet_L_160_m07_b4.json profiles/${tag}_bench_stunet_L_160_m07_b4.json
 cp $src/bench_stunet_H_192_recompute_b2.json profiles/${tag}_bench_stunet_H_192_recompute_b2.json
-for f in conv_census conv_census_stunet_L_160_m07_b4 phase_times_b16 batch_cliff conv_shapes_b16 k3_ablate_b16; do grep -v amdgpu.ids $src/$f.txt > profiles/${tag}_$f.txt; done
+for f in conv_census conv_census_stunet_L_160_m07_b4 conv_census_stunet_H_192_recompute_b2 norm_bench_b16 phase_times_b16 batch_cliff conv_shapes_b16 k3_ablate_b16; do [ -f $src/$f.txt ] && grep -v amdgpu.ids $src/$f.txt > profiles/${tag}_$f.txt; done
 { grep -v amdgpu.ids $src/pytest.txt | tail -12; echo "--- smoke"; tail -2 $src/smoke.txt; } > profiles/${tag}_gpu_tests.txt
 cp $(ls $src/step/*/*_kernel_stats.csv | head -1) profiles/${tag}_step_kernel_stats_b16.csv
 cp $(ls $src/step_iso/*/*_kernel_stats.csv | head -1) profiles/${tag}_step_kernel_stats_b16_isolated.csv

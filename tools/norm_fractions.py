@@ -84,7 +84,7 @@ def table(jpath, csv_step, csv_iso):
         tb += gb; ti += m_iso; ts += m_step
         print(f"| `{fam}` | {n:.0f} | {gb:.1f} | {m_iso:.2f} | {gb / m_iso:.2f} ({gb / m_iso / 8:.0%}) | {m_step:.2f} | {gb / m_step:.2f} ({gb / m_step / 8:.0%}) |")
     print(f"| all | | {tb:.1f} | {ti:.2f} | {tb / ti:.2f} ({tb / ti / 8:.0%}) | {ts:.2f} | {tb / ts:.2f} ({tb / ts / 8:.0%}) |")
-    print("\nIsolated, the apply families run at 4.4-5.2 TB/s (the copy ceiling of these boxes is 5-6 TB/s), the reduce families (read-only, 8-way replicated double accumulators) at 3.6-3.8;\nthe in-step figures are the same launches queued behind the persistent weight-gradient grid of the side stream (the isolated times sum to the step: DESIGN.md 4,\n`profiles/r04_experiments.md` 2).")
+    print("\nFamily averages over all launches of a step, small tensors included; on the decoder's 4.3 GB tensors every one of these kernels streams at 5.0-5.5 TB/s alone\n(`tools/norm_bench.py`, `profiles/r04_z_norm_bench_b16.txt`), the ceiling these boxes give a streaming kernel;\nthe in-step figures are the same launches queued behind the persistent weight-gradient grid of the side stream (the isolated times sum to the step: DESIGN.md 4,\n`profiles/r04_experiments.md` 2).")
 
 
 if __name__ == "__main__":
