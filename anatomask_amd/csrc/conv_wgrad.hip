@@ -60,6 +60,15 @@ struct WgArgs {
 #endif
 
 
+inline bool wg_no_dma() {                         // tools-only build: AM_WG_NODMA=1 -> the register-staged plane-brick kernel (same-process A/B)
+#ifdef AM_ABLATE
+  const char* e_ = getenv("AM_WG_NODMA");
+  return e_ && atoi(e_);
+#else
+  return false;
+#endif
+}
+
 inline int wg_slots(int occ) {                    // resident workgroups of the CURRENT device (CU count cached per device)
   static int ncu[64];
   static PerDeviceOnce once;
@@ -82,7 +91,14 @@ __device__ __forceinline__ s16x4 tr_read(const unsigned char* p) {
 // PF: the loads of the next live brick are issued BEFORE the contraction of the current one and land in the staging registers while
 // the matrix cores run (variants with registers to spare: the small bricks of the block-sparse stride-2 layers, whose 36 MFMAs per
 // wave and brick cannot hide a memory round trip behind the other workgroup of the CU).
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false, bool PF = false>
+// DMA (bf16, dense operands, one-plane 1x8x16 bricks, 64 x 64 tiles): the two bricks go global -> LDS by `buffer_load ... lds` (no staging registers,
+// no ds_write phase) into one of TWO buffers, so brick n+1 is in flight while brick n is contracted and a brick costs ONE barrier:
+//   s_waitcnt vmcnt(0) -> barrier -> issue brick n+1 -> contract brick n.
+// An LDS-DMA instruction fills 1 KB = 8 CONSECUTIVE 128-byte rows, so the rows cannot be padded to the conflict-free 160-byte stride of the
+// register-staged layout; instead the 32-byte channel groups of a row are XOR-swizzled with ((w >> 1) & 3) of the row's w coordinate -- on the SOURCE side
+// (lane l of the instruction fetches the channel chunk that belongs at its LDS position) -- which spreads the 8 voxel rows of a half-wave's
+// transposing read over all 64 banks; w + tap shift keeps the key a lane constant per w-tap.
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false, bool PF = false, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
   constexpr int EPC = TT<T>::EPC;
   constexpr int CT = 16 * MI, KT = 16 * NWX, KS = 4 / NWX;
@@ -152,14 +168,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     const int v = tid / CPRY + it * VPI_Y;
     const int vd = v / (BW * BH), vh = (v / BW) % BH, vw = v % BW;
     yq[it] = vd | (vh << 8) | (vw << 16);
-    yoffB[it] = (v < MV && ycok) ? (unsigned)(((((vd * a.OS) * a.Hy + vh * a.OS) * a.Wy + vw * a.OS) * a.Cy + cy0 + ychan) * (int)sizeof(T)) : OOB;
+    const int ych = DMA ? (((tid % CPRY) ^ (((vw >> 1) & 3) << 1)) * EPC) : ychan;      // DMA: the chunk that belongs at this lane's LDS position
+    yoffB[it] = (v < MV && (DMA || ycok)) ? (unsigned)(((((vd * a.OS) * a.Hy + vh * a.OS) * a.Wy + vw * a.OS) * a.Cy + cy0 + ych) * (int)sizeof(T)) : OOB;
   }
 #pragma unroll
   for (int it = 0; it < NITX; ++it) {
     const int e = tid / CPRX + it * VPI_X;
     const int ez = (e * mHW) >> 20, rem = e - ez * EHW, ey = (rem * mW) >> 20, ex = rem - ey * EW;
     xq[it] = ez | (ey << 8) | (ex << 16);
-    xoffB[it] = (e < nvox && xcok) ? (unsigned)((((ez * a.Hx + ey) * a.Wx + ex) * a.GS * a.Cx + cx0 + xchan) * (int)sizeof(T)) : OOB;
+    const int xch = DMA ? (((tid % CPRX) ^ (((ex >> 1) & 3) << 1)) * EPC) : xchan;
+    xoffB[it] = (e < nvox && (DMA || xcok)) ? (unsigned)((((ez * a.Hx + ey) * a.Wx + ex) * a.GS * a.Cx + cx0 + xch) * (int)sizeof(T)) : OOB;
   }
   const int ydst0 = (tid / CPRY) * RSY + (tid % CPRY) * 16, xdst0 = (tid / CPRX) * RSX + (tid % CPRX) * 16;
 
@@ -205,7 +223,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       if (tid / CPRX + it * VPI_X < nvox && !AM_DBG(a, 8)) *(u32x4*)(ldsX + xdst0 + it * VPI_X * RSX) = xs[it];
     __syncthreads();
   };
-  auto contract = [&]() {
+  constexpr int DYB = MV * 128, DXB = 184 * 128, DBUF = DYB + DXB;      // DMA: bytes of a dY brick / an X brick (180 rows + 4 of the last instruction) / one buffer
+  int dcur = 0;                                          // DMA: buffer the NEXT issue fills
+  auto contract = [&](int cb = 0) {
     // ---- contract over the brick's voxels ----
     if (!AM_DBG(a, 32)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
@@ -219,10 +239,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
         const int xa1 = (((v1 / (BW * BH)) * LS * EH + ((v1 / BW) % BH) * LS) * EW + (v1 % BW) * LS) * RSX + (16 * wx + 4 * p) * 2;
         const int xa2 = (((v2 / (BW * BH)) * LS * EH + ((v2 / BW) % BH) * LS) * EW + (v2 % BW) * LS) * RSX + (16 * wx + 4 * p) * 2;
         s16x4 alo[MI], ahi[MI];
+        if constexpr (DMA) {
+          // unpadded 128-byte rows, 32-byte channel groups swizzled by ((w >> 1) & 3): w = 4g + q for both voxel halves (rows h and h + 1)
+          const int wv = 4 * g + q, keyA = (wv >> 1) & 3;
+          const unsigned char* yb = lds + cb * DBUF + v1 * 128 + 8 * p;
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            alo[i] = tr_read(yb + ((i ^ keyA) << 5));
+            ahi[i] = tr_read(yb + ((i ^ keyA) << 5) + 16 * 128);
+          }
+        } else {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           alo[i] = tr_read(ldsY + v1 * RSY + (16 * i + 4 * p) * 2);
           ahi[i] = tr_read(ldsY + v2 * RSY + (16 * i + 4 * p) * 2);
+        }
         }
         typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
         bfx8 af[MI];
@@ -234,10 +265,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
           // halves of a k-step are the h-rows h and h+1 of the brick, so tap th needs the X rows h+th and h+th+1: the three th of
           // a tw share 4 rows -- 12 transposing reads per k-step instead of 18
           s16x4 xr[3][4];
+          if constexpr (DMA) {
+            const int wv = 4 * g + q;
+            const unsigned char* xb = lds + cb * DBUF + DYB + ((ks * 2) * 18 + wv) * 128 + 8 * p;     // X brick row (h = 2 ks, w) of this lane
+#pragma unroll
+            for (int tw = 0; tw < 3; ++tw) {
+              const int keyB = ((wv + tw) >> 1) & 3;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) xr[tw][r] = tr_read(xb + (r * 18 + tw) * 128 + ((wx ^ keyB) << 5));
+            }
+          } else {
 #pragma unroll
           for (int tw = 0; tw < 3; ++tw)
 #pragma unroll
             for (int r = 0; r < 4; ++r) xr[tw][r] = tr_read(ldsX + xa1 + (r * EW + tw) * RSX);
+          }
 #pragma unroll
           for (int t = 0; t < NTAP; ++t) {
             const s16x4 lo = xr[t % 3][t / 3], hi = xr[t % 3][t / 3 + 1];
@@ -413,6 +455,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     }
     // buffer loads: per-lane 32-bit byte offset (row offset + the brick's scalar origin, which may be negative for halo rows that
     // are then OOB-marked); hardware zero-fill for OOB rows
+    if constexpr (DMA) {
+      static_assert(!DMA || (sizeof(T) == 2 && BD == 1 && BH == 8 && BW == 16 && NTAP == 9 && MI == 4 && NWX == 4 && NITX == 6 && !S2 && !PF), "DMA variant: dense bf16 plane bricks");
+      if (have) {                                        // the previous brick has landed (this wave's part; the barrier covers the others') and
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave is done reading the buffer this issue overwrites (contracted two bricks ago)
+        __builtin_amdgcn_s_barrier();
+      }
+      const int wv_ = __builtin_amdgcn_readfirstlane(wave);
+      typedef __attribute__((address_space(3))) void* ldsp_t;
+#pragma unroll
+      for (int it = 0; it < NITY; ++it)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (ldsp_t)(lds + dcur * DBUF + it * 4096 + wv_ * 1024), 16,
+                                                 (int)((yo[it] == OOB || AM_DBG(a, 4)) ? OOB : yo[it] + (unsigned)ybaseB), 0, 0, 0);   // (an unsigned here: no stub is emitted for the host, silently)
+#pragma unroll
+      for (int it = 0; it < NITX; ++it)
+        if (it * 32 + wv_ * 8 < 184)                     // (rows 184 .. 191 of the last instruction round: beyond the 180-row brick, not allocated)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (ldsp_t)(lds + dcur * DBUF + DYB + it * 4096 + wv_ * 1024), 16,
+                                                   (int)((xo[it] == OOB || AM_DBG(a, 4)) ? OOB : xo[it] + (unsigned)xbaseB), 0, 0, 0);
+      if (have) contract(dcur ^ 1);                      // ... and flies while the previous brick is contracted
+      have = true; dcur ^= 1;
+    } else {
     if constexpr (PF) {
       if (have) { stage_to_lds(); }                      // the previous live brick's rows have landed: registers -> LDS
     }
@@ -429,7 +491,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       stage_to_lds();
       contract();
     }
+    }
   }
+  }
+  if constexpr (DMA) {
+    if (have) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      contract(dcur ^ 1);
+    }
+    __syncthreads();                                     // (the deterministic flush reuses the staging area)
   }
   if constexpr (PF) {
     if (have) { stage_to_lds(); contract(); }
@@ -517,12 +588,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_fold_kernel(WgArgs a, int ntap
 // two rounds costs a third round with the chip empty (measured: 1026 workgroups 2.24 ms, 1008 workgroups 1.77 ms).
 constexpr int AM_WG_ROUNDS = 2;
 
-template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false, bool PF = false>
+template <typename T, int BD, int BH, int BW, int NTAP, int NITX, int MI = 4, int NWX = 4, bool S2 = false, bool PF = false, bool DMA = false>
 int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipStream_t st) {
-  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX, S2, PF>;
+  auto kern = conv_wgrad_kernel<T, BD, BH, BW, NTAP, NITX, MI, NWX, S2, PF, DMA>;
   constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
   constexpr int CT = 16 * MI, KT = 16 * NWX;
   size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
+  if (DMA) lds = 2 * ((size_t)BD * BH * BW * 128 + 184 * 128);         // two buffers of unpadded rows (79 872 bytes: two workgroups per CU)
   a.mask_off = 0; a.mask_n = 0;
   {
     const int pq = 1 << a.y_mask.bs;                 // patch edge in dY voxels
@@ -911,7 +983,9 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     } else if (bf && bw == 4) {
       rc = ntap == 9 ? launch<bf16_t, 4, 4, 4, 9, 5>(a, maxvox, tiles, nbrick, det_slots, st) : -2;
     } else if (bf && bw == 16) {
-      if (ntap == 9 && bd == 1) rc = launch<bf16_t, 1, 8, 16, 9, 6>(a, maxvox, tiles, nbrick, det_slots, st);
+      if (ntap == 9 && bd == 1 && !x_mask && !y_mask && Cx % 64 == 0 && Cy % 64 == 0 && maxvox <= 180 && !wg_no_dma())
+        rc = launch<bf16_t, 1, 8, 16, 9, 6, 4, 4, false, false, true>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 9 && bd == 1) rc = launch<bf16_t, 1, 8, 16, 9, 6>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
       else if (ntap == 2) WG_CASE(bf16_t, 4, 16, 2, 8); else WG_CASE(bf16_t, 4, 16, 1, 8);
     } else if (bf) {
