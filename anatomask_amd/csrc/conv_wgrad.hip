@@ -60,14 +60,10 @@ struct WgArgs {
 #endif
 
 
-inline bool wg_no_dma() {                         // tools-only build: AM_WG_NODMA=1 -> the register-staged plane-brick kernel (same-process A/B)
 #ifdef AM_ABLATE
-  const char* e_ = getenv("AM_WG_NODMA");
-  return e_ && atoi(e_);
-#else
-  return false;
+inline bool mi_is4(int Cx, int Cy) { return Cx > 32 && Cy > 32; }
+inline bool wg_dma() { const char* e_ = getenv("AM_WG_DMA"); return e_ && atoi(e_); }     // tools-only build: the LDS-DMA plane-brick variant (same-process A/B)
 #endif
-}
 
 inline int wg_slots(int occ) {                    // resident workgroups of the CURRENT device (CU count cached per device)
   static int ncu[64];
@@ -223,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
       if (tid / CPRX + it * VPI_X < nvox && !AM_DBG(a, 8)) *(u32x4*)(ldsX + xdst0 + it * VPI_X * RSX) = xs[it];
     __syncthreads();
   };
-  constexpr int DYB = MV * 128, DXB = 184 * 128, DBUF = DYB + DXB;      // DMA: bytes of a dY brick / an X brick (180 rows + 4 of the last instruction) / one buffer
+  constexpr int XROWS = ((BH + 2) * 18 + 7) / 8 * 8;                     // DMA: X brick rows, rounded up to whole 8-row instructions (180 -> 184, 108 -> 112)
+  constexpr int DYB = MV * 128, DXB = XROWS * 128, DBUF = DYB + DXB;      // DMA: bytes of a dY brick / an X brick / one buffer
   int dcur = 0;                                          // DMA: buffer the NEXT issue fills
   auto contract = [&](int cb = 0) {
     // ---- contract over the brick's voxels ----
@@ -456,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
     // buffer loads: per-lane 32-bit byte offset (row offset + the brick's scalar origin, which may be negative for halo rows that
     // are then OOB-marked); hardware zero-fill for OOB rows
     if constexpr (DMA) {
-      static_assert(!DMA || (sizeof(T) == 2 && BD == 1 && BH == 8 && BW == 16 && NTAP == 9 && MI == 4 && NWX == 4 && NITX == 6 && !S2 && !PF), "DMA variant: dense bf16 plane bricks");
+      static_assert(!DMA || (sizeof(T) == 2 && BD == 1 && (BH == 8 || BH == 4) && BW == 16 && NTAP == 9 && MI == 4 && NWX == 4 && NITX == (BH == 8 ? 6 : 4) && !S2 && !PF), "DMA variant: dense bf16 plane bricks");
       if (have) {                                        // the previous brick has landed (this wave's part; the barrier covers the others') and
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave is done reading the buffer this issue overwrites (contracted two bricks ago)
         __builtin_amdgcn_s_barrier();
@@ -469,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgArgs a) {
                                                  (int)((yo[it] == OOB || AM_DBG(a, 4)) ? OOB : yo[it] + (unsigned)ybaseB), 0, 0, 0);   // (an unsigned here: no stub is emitted for the host, silently)
 #pragma unroll
       for (int it = 0; it < NITX; ++it)
-        if (it * 32 + wv_ * 8 < 184)                     // (rows 184 .. 191 of the last instruction round: beyond the 180-row brick, not allocated)
+        if (it * 32 + wv_ * 8 < XROWS)                   // (the last instruction round's rows beyond the brick are not allocated)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (ldsp_t)(lds + dcur * DBUF + DYB + it * 4096 + wv_ * 1024), 16,
                                                    (int)((xo[it] == OOB || AM_DBG(a, 4)) ? OOB : xo[it] + (unsigned)xbaseB), 0, 0, 0);
       if (have) contract(dcur ^ 1);                      // ... and flies while the previous brick is contracted
@@ -594,7 +591,7 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
   constexpr size_t RP = sizeof(T) == 2 ? 32 : 16;
   constexpr int CT = 16 * MI, KT = 16 * NWX;
   size_t lds = (size_t)BD * BH * BW * (CT * sizeof(T) + RP) + maxvox * (KT * sizeof(T) + RP);
-  if (DMA) lds = 2 * ((size_t)BD * BH * BW * 128 + 184 * 128);         // two buffers of unpadded rows (79 872 bytes: two workgroups per CU)
+  if (DMA) lds = 2 * ((size_t)BD * BH * BW * 128 + (size_t)(((BH + 2) * 18 + 7) / 8 * 8) * 128);   // two buffers of unpadded rows (1x8x16: 79 872 bytes; 1x4x16: 45 056)
   a.mask_off = 0; a.mask_n = 0;
   {
     const int pq = 1 << a.y_mask.bs;                 // patch edge in dY voxels
@@ -902,6 +899,9 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   { const char* e_ = getenv("AM_WG_PLANE"); if (e_ && !atoi(e_)) plane_brick = false; }
 #endif
   if (plane_brick) { bd = 1; bh = 8; bw = 16; }
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_WG_DMA_BH4"); if (e_ && atoi(e_) && plane_brick && Cx % 64 == 0 && Cy % 64 == 0 && mi_is4(Cx, Cy)) bh = 4; }   // tools: 1x4x16 DMA bricks (45 KB of LDS per workgroup)
+#endif
   if (s2full) { bd = 1; bh = 4; bw = 16; if (patch8) { bh = 8; bw = 8; } }
   // 32-channel operands: 32-wide tiles (MI = 2 cy tiles / NWX = 2 cx waves, the other waves split the voxels)
   int mi = 4, nwx = 4;
@@ -983,9 +983,16 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     } else if (bf && bw == 4) {
       rc = ntap == 9 ? launch<bf16_t, 4, 4, 4, 9, 5>(a, maxvox, tiles, nbrick, det_slots, st) : -2;
     } else if (bf && bw == 16) {
-      if (ntap == 9 && bd == 1 && !x_mask && !y_mask && Cx % 64 == 0 && Cy % 64 == 0 && maxvox <= 180 && !wg_no_dma())
+#ifdef AM_ABLATE
+      // LDS-DMA staging (tools build only, AM_WG_DMA=1 / AM_WG_DMA_BH4=1): +5 % on the launch alone, -1.3 ms on the STEP -- two double-buffered
+      // workgroups fill a CU's LDS and nothing of the main stream runs beside them any more (profiles/r04_experiments.md section 6)
+      if (ntap == 9 && bd == 1 && bh == 4 && !x_mask && !y_mask && Cx % 64 == 0 && Cy % 64 == 0 && maxvox <= 108)
+        rc = launch<bf16_t, 1, 4, 16, 9, 4, 4, 4, false, false, true>(a, maxvox, tiles, nbrick, det_slots, st);
+      else if (ntap == 9 && bd == 1 && !x_mask && !y_mask && Cx % 64 == 0 && Cy % 64 == 0 && maxvox <= 180 && wg_dma())
         rc = launch<bf16_t, 1, 8, 16, 9, 6, 4, 4, false, false, true>(a, maxvox, tiles, nbrick, det_slots, st);
-      else if (ntap == 9 && bd == 1) rc = launch<bf16_t, 1, 8, 16, 9, 6>(a, maxvox, tiles, nbrick, det_slots, st);
+      else
+#endif
+      if (ntap == 9 && bd == 1) rc = launch<bf16_t, 1, 8, 16, 9, 6>(a, maxvox, tiles, nbrick, det_slots, st);
       else if (ntap == 9) WG_CASE(bf16_t, 4, 16, 9, 7); else if (ntap == 8) WG_CASE(bf16_t, 4, 16, 8, 8); else if (ntap == 4) WG_CASE(bf16_t, 4, 16, 4, 8);
       else if (ntap == 2) WG_CASE(bf16_t, 4, 16, 2, 8); else WG_CASE(bf16_t, 4, 16, 1, 8);
     } else if (bf) {
