@@ -650,6 +650,21 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WG_OLDSPLIT"); if (e_ && atoi(e_)) split = (1024 + tiles - 1) / tiles; }
 #endif
+  // every slot flushes a [taps][64][64] block of fp32 atomics per tile (147 KB for 9 taps: ~12 us beside ~2.4 us of work per brick): a slot
+  // wants >= 64 bricks where the launch has them, even if that leaves part of the chip without a workgroup (STUNet-B 256->256 @16^3 at batch 4:
+  // 32 slots of 4 bricks each = 3 rounds of mostly atomics, 213 us for 80 us of work).  tools/ab_minb.sh, same box: the batch-4 step 36.3 ms
+  // without the rule, 35.6 / 35.3 / 35.1 / 36.3 with 16 / 32 / 64 / 128; batch 16, STUNet-L, STUNet-H unchanged
+  {
+    int minb = 64;
+#ifdef AM_ABLATE
+    { const char* e_ = getenv("AM_WG_MINB"); if (e_) minb = atoi(e_); }
+#endif
+    if (minb > 0) {
+      int capb = nbrick / minb / 8 * 8;
+      if (capb < 8) capb = 8;
+      if (split > capb) split = capb;
+    }
+  }
   if (split > nbrick) split = nbrick;
   if (a.det_ws && split > det_slots) split = det_slots;     // (the caller checked det_slots >= 1)
   a.split = split;
