@@ -659,7 +659,7 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
 #ifdef AM_ABLATE
     { const char* e_ = getenv("AM_WG_MINB"); if (e_) minb = atoi(e_); }
 #endif
-    if (minb > 0) {
+    if (minb > 0 && sizeof(T) == 2) {                  // (bf16 launches: with the exact-f32 MFMA a brick is 16 x the work and the flush does not show)
       int capb = nbrick / minb / 8 * 8;
       if (capb < 8) capb = 8;
       if (split > capb) split = capb;
