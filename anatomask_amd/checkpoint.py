@@ -81,19 +81,28 @@ FORMAT_VERSION = 3      # 3: tensors and python scalars only (loader / augmenter
 
 
 def read_checkpoint(path: str) -> Dict:
-    """The file as a dict, read ONCE (pretrain.py hands the same dict to the feed and to load_checkpoint).  Files of format 3 load with
-    torch's default `weights_only=True`; an older file of ours (format 2: numpy objects inside `feed_state`) fails that check -- it is
-    re-read with weights_only=False ONLY when the caller vouches for it (`trust_own_files`), and its feed state is dropped."""
+    """The file as a dict, read ONCE (pretrain.py hands the same dict to the feed and to load_checkpoint).  ALWAYS through torch's
+    restricted unpickler (`weights_only=True`): a file is data, never code.  Files of format 3 hold tensors and python scalars only and
+    load as they are.  An older file of ours (format 2: numpy RandomState tuples inside `feed_state`) is re-read with the restricted
+    unpickler allowed to rebuild plain numpy arrays (`_reconstruct`, `ndarray`, `dtype`, the uint32 dtype class -- nothing callable beyond
+    array construction) and its feed state is dropped (the loaders restart from their seeds).  Anything else -- a pickle that names
+    any other global -- is refused with torch's own UnpicklingError; there is no `weights_only=False` path."""
     import pickle
     try:
-        return torch.load(path, map_location="cpu")
-    except pickle.UnpicklingError as e:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as first:
+        import numpy as np
         import warnings
-        warnings.warn(f"{path}: not a format-{FORMAT_VERSION} checkpoint ({e}); re-reading it as a format-2 file of this package and "
-                      "dropping its loader state (the loaders restart from their seeds)")
-        ck = torch.load(path, map_location="cpu", weights_only=False)
-        if int(ck.get("anatomask_amd_version", 0)) >= FORMAT_VERSION:
-            raise
+        allow = [np._core.multiarray._reconstruct, np.ndarray, np.dtype, type(np.dtype(np.uint32))]
+        try:
+            with torch.serialization.safe_globals(allow):
+                ck = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError:
+            raise first
+        if not isinstance(ck, dict) or int(ck.get("anatomask_amd_version", 0)) >= FORMAT_VERSION:
+            raise first
+        warnings.warn(f"{path}: a format-{ck.get('anatomask_amd_version', 0)} checkpoint of this package (numpy objects in its loader state); "
+                      "its loader state is dropped, the loaders restart from their seeds")
         ck.pop("feed_state", None)
         return ck
 

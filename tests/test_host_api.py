@@ -65,6 +65,41 @@ def test_feed_rng_state_is_weights_only_safe_and_round_trips(tmp_path):
     assert 1 <= default_workers(8) <= 8 and default_workers(1) >= default_workers(8)
 
 
+def test_read_checkpoint_never_unpickles_code(tmp_path):
+    """checkpoint.read_checkpoint: a file is data.  A format-2 file of this package (numpy RandomState tuples in `feed_state`) is read
+    through the restricted unpickler with plain-ndarray reconstruction allowed and loses its feed state; a pickle that names any other
+    global (here: one whose unpickling would run `os.system`) is refused and its payload is NOT executed."""
+    import os
+    import pickle
+
+    import numpy as np
+    import pytest
+
+    from anatomask_amd import checkpoint
+    old = str(tmp_path / "format2.pt")
+    torch.save({"feed_state": {0: {"loader_rng": {0: np.random.RandomState(3).get_state()}}}, "anatomask_amd_version": 2,
+                "network_weights": {"module.x": torch.ones(2)}, "current_epoch": 4}, old)
+    with pytest.warns(UserWarning, match="loader state is dropped"):
+        ck = checkpoint.read_checkpoint(old)
+    assert "feed_state" not in ck and int(ck["current_epoch"]) == 4 and torch.equal(ck["network_weights"]["module.x"], torch.ones(2))
+
+    witness = str(tmp_path / "executed")
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, (f"touch {witness}",))
+    bad = str(tmp_path / "evil.pt")
+    torch.save({"network_weights": {}, "payload": Evil(), "anatomask_amd_version": 2}, bad)
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoint.read_checkpoint(bad)
+    assert not os.path.exists(witness)
+    # a file that CLAIMS format 3 but needs numpy globals is not ours either
+    liar = str(tmp_path / "liar.pt")
+    torch.save({"feed_state": np.arange(3), "anatomask_amd_version": 3}, liar)
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoint.read_checkpoint(liar)
+
+
 def test_easy_mask_is_the_band_below_the_hard_patches():
     """generate_mask's second output (P/AnatoMask.py:116-134): the `L - len_keep - len_loss` patches ranked just below the hard band are
     hidden, the other len_keep + len_loss are visible; in the random regime it is the mask itself.  (Host-side: SparK._easy_mask.)"""
