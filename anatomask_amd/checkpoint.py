@@ -127,6 +127,7 @@ def load_checkpoint(path, trainer, rank: int = 0) -> Dict:
         o, num = m._offs[k], m._W[k].numel()
         trainer.m[o:o + num].copy_(st["exp_avg"].reshape(-1)); trainer.v[o:o + num].copy_(st["exp_avg_sq"].reshape(-1))
     trainer.step_count = int(ck.get("step_count", max([int(float(s["step"])) for s in opt.get("state", {}).values()], default=0)))
+    trainer.reset_guard()                              # (the non-finite guard counts optimizer calls from here)
     if "rng_state" in ck:
         if rank == int(ck.get("rng_rank", 0)):
             trainer.gen.set_state(ck["rng_state"])

@@ -168,4 +168,6 @@ struct PerDeviceOnce {
 #define AM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 // launch with a clean error slate: hipGetLastError() is per-thread sticky and torch's own probing calls
 // can leave a benign error behind that would otherwise be mis-attributed to our launch
+// an API call inside an entry point that promises "0 or a hipError_t": its failure is the entry point's return value
+#define AM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define AM_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)

@@ -475,14 +475,16 @@ static int k3_grid(int B, int D, int H, int W, int Cout, int* units) {
   return G - G % ny > 0 ? G - G % ny : ny;
 }
 
-static bool k3_qualifies(int mode, int dtype, int ksize, int stride, int D, int H, int W, int Cin, int Cout, bool masks) {
+static bool k3_qualifies(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cin, int Cout, bool masks) {
   if (dtype != AM_DT_BF16 || ksize != 3 || stride != 1 || (mode != AM_CONV_FWD && mode != AM_CONV_DGRAD) || masks) return false;
   if (Cin % 32 || Cout % 64 || D % KBD || H % KBH || W % KBW) return false;
+  // `Item` packs the sample index and the three brick indices into 8-bit fields (IT_B / IT_Q0*): larger launches go to conv_igemm.hip
+  if (B > 255 || D / KBD > 255 || H / KBH > 255 || W / KBW > 255) return false;
   return true;
 }
 
 int conv_k3_rows(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cin, int Cout, int masks) {
-  if (!k3_qualifies(mode, dtype, ksize, stride, D, H, W, Cin, Cout, masks != 0)) return 0;
+  if (!k3_qualifies(mode, dtype, ksize, stride, B, D, H, W, Cin, Cout, masks != 0)) return 0;
   int units;
   const int G = k3_grid(B, D, H, W, Cout, &units);
   if (units < K3_MIN_UNITS) return 0;
@@ -490,7 +492,7 @@ int conv_k3_rows(int mode, int dtype, int ksize, int stride, int B, int D, int H
 }
 
 int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void* stream) {
-  if (!k3_qualifies(mode, dtype, ksize, stride, c.Di, c.Hi, c.Wi, c.Cin, c.Cout, c.in_mask.m || c.out_mask.m)) return 0;
+  if (!k3_qualifies(mode, dtype, ksize, stride, c.B, c.Di, c.Hi, c.Wi, c.Cin, c.Cout, c.in_mask.m || c.out_mask.m)) return 0;
   if (c.accumulate || c.nb_x) return 0;
   if (c.Di != c.Do || c.Hi != c.Ho || c.Wi != c.Wo) return 0;
   if ((size_t)(KED + 1) * c.Hi * c.Wi * c.Cin * 2 >= 0x7fffff00ull) return 0;     // the brick's planes must stay below 2 GB (32-bit offsets)

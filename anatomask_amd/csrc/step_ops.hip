@@ -81,7 +81,10 @@ __global__ __launch_bounds__(256) void patch_loss_bwd_kernel(const float* __rest
   const int z = threadIdx.x >> 4, y = threadIdx.x & 15;
   const size_t base = (((size_t)b * D + pd * 16 + z) * H + ph * 16 + y) * W + pw * 16;
   const bool vis = active[blockIdx.x] != 0;
-  const float k = vis ? 0.f : (gout ? gout[0] : 1.f) * lossinfo[1] * (2.f / 4096.f);
+  // a non-finite loss (P/pretrain_AntoMask.py:441-446 stops on it) must reach the optimizer's guard on EVERY rank: NaN gradients survive the
+  // all-reduce, an overflowed loss with finite gradients would not -- so the gradient of a non-finite loss is NaN by construction
+  const float lossv = lossinfo[0];
+  const float k = vis ? 0.f : (lossv - lossv == 0.f ? (gout ? gout[0] : 1.f) * lossinfo[1] * (2.f / 4096.f) : __builtin_nanf(""));
   const float mean = pmean[blockIdx.x], rstd = prstd[blockIdx.x];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -162,13 +165,28 @@ __global__ void sumsq_kernel(const float* __restrict__ g, long n, double* out) {
 __global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  float* __restrict__ ema, long n, float lr, float b1, float b2, float eps, float wd, float bc1,
                                  float bc2_sqrt, const double* __restrict__ sumsq, float max_norm, float ema_decay,
-                                 float grad_scale, float* __restrict__ gnorm_out, const float* __restrict__ dyn) {
+                                 float grad_scale, float* __restrict__ gnorm_out, const float* __restrict__ dyn, int* __restrict__ guard) {
   if (dyn) { lr = dyn[0]; bc1 = dyn[1]; bc2_sqrt = dyn[2]; ema_decay = dyn[3]; }   // hipGraph replays: the per-step scalars live in device memory
   // grad_scale: g holds the SUM of the ranks' gradients; the 1/world of DDP's mean is folded in here (norm and update see g*scale)
   const float total = sumsq ? (float)sqrt(sumsq[0]) * grad_scale : 0.f;
   float coef = sumsq ? max_norm / (total + 1e-6f) : 1.f;
   coef = (coef > 1.f ? 1.f : coef) * grad_scale;
   if (gnorm_out && blockIdx.x == 0 && threadIdx.x == 0) gnorm_out[0] = total;
+  if (guard) {
+    // per-step non-finite stop without a host round trip (P/pretrain_AntoMask.py:441-446 looks at loss.item() every step): a non-finite
+    // gradient norm -- a non-finite loss makes it so, am_patch_loss_bwd -- leaves p / m / v / ema untouched and latches guard[0]; once
+    // latched every later call is skipped too, so what the driver finds when it looks (once per epoch) is the state BEFORE the bad step.
+    // guard[2] counts the calls; guard[1] = the 1-based index of the first bad one.  (guard[0] can only change in a call whose norm is not
+    // finite, where every workgroup skips anyway: no ordering between the workgroups is needed.)
+    const bool bad = !(total - total == 0.f);
+    const bool latched = guard[0] != 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const int call = guard[2] + 1;
+      guard[2] = call;
+      if (bad && !latched) { guard[1] = call; guard[0] = 1; }
+    }
+    if (bad || latched) return;
+  }
   const float step_size = lr / bc1, decay_mul = 1.f - lr * wd;
   const long n4 = n >> 2;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -190,9 +208,24 @@ __global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict_
   }
 }
 
-__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float decay) {
+__global__ void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long n, float decay, const int* __restrict__ guard) {
+  if (guard && guard[0]) return;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
     ema[i] = ema[i] * decay + (1.f - decay) * p[i];
+}
+
+// timm's update on an integer state_dict entry (BatchNorm's num_batches_tracked): ema.copy_(ema * decay + (1 - decay) * model) --
+// int64 * python float promotes to float32, the sum is float32, copy_ into int64 truncates toward zero
+__global__ void ema_i64_kernel(long long* __restrict__ ema, const long long* __restrict__ p, int n, float decay, float one_minus, const int* __restrict__ guard) {
+  if (guard && guard[0]) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) ema[i] = (long long)((float)ema[i] * decay + one_minus * (float)p[i]);
+}
+
+// guard latched: put the snapshot taken before the step back (BatchNorm running statistics / counters the student's forward updated)
+__global__ void guard_restore_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ snap, long nwords, const int* __restrict__ guard) {
+  if (!guard[0]) return;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (long)gridDim.x * 256) dst[i] = snap[i];
 }
 
 }  // namespace
@@ -231,7 +264,7 @@ int am_mask_sampler(const float* loss, const float* keys, int B, int L, int len_
 
 int am_sumsq(const float* g, long n, double* out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(out, 0, sizeof(double), st);
+  AM_HIP(hipMemsetAsync(out, 0, sizeof(double), st));
   int nb = (int)((n / 4 + 255) / 256); if (nb > 2048) nb = 2048; if (nb < 1) nb = 1;
   AM_LAUNCH(sumsq_kernel, dim3(nb), dim3(256), 0, st, g, n, out);
   AM_CHECK_LAUNCH();
@@ -240,19 +273,36 @@ int am_sumsq(const float* g, long n, double* out, void* stream) {
 
 int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema, long n, double lr, double beta1, double beta2, double eps,
                  double weight_decay, int step, const double* sumsq, double max_norm, double ema_decay, double grad_scale,
-                 float* gnorm_out, const float* dyn_scalars, void* stream) {
+                 float* gnorm_out, const float* dyn_scalars, int* guard, void* stream) {
   if (n % 4) return -1;
   const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);   // as torch: python doubles
   int nb = (int)((n / 4 + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
   AM_LAUNCH(adamw_ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, n, (float)lr, (float)beta1, (float)beta2,
-                     (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2), sumsq, (float)max_norm, (float)ema_decay, (float)grad_scale, gnorm_out, dyn_scalars);
+                     (float)eps, (float)weight_decay, (float)bc1, (float)sqrt(bc2), sumsq, (float)max_norm, (float)ema_decay, (float)grad_scale, gnorm_out, dyn_scalars, guard);
   AM_CHECK_LAUNCH();
   return 0;
 }
 
-int am_ema(float* ema, const float* p, long n, double decay, void* stream) {
+int am_ema(float* ema, const float* p, long n, double decay, const int* guard, void* stream) {
   int nb = (int)((n + 255) / 256); if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
-  AM_LAUNCH(ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ema, p, n, (float)decay);
+  AM_LAUNCH(ema_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, ema, p, n, (float)decay, guard);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_ema_i64(long* ema, const long* p, int n, double decay, const int* guard, void* stream) {
+  if (n <= 0) return 0;
+  AM_LAUNCH(ema_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long*)ema, (const long long*)p, n, (float)decay,
+            (float)(1.0 - decay), guard);
+  AM_CHECK_LAUNCH();
+  return 0;
+}
+
+int am_guard_restore(void* dst, const void* snapshot, long nbytes, const int* guard, void* stream) {
+  if (nbytes % 4 || !guard) return -1;
+  if (nbytes == 0) return 0;
+  int nb = (int)((nbytes / 4 + 255) / 256); if (nb > 1024) nb = 1024;
+  AM_LAUNCH(guard_restore_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (unsigned*)dst, (const unsigned*)snapshot, nbytes / 4, guard);
   AM_CHECK_LAUNCH();
   return 0;
 }

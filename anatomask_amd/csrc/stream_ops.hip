@@ -1788,7 +1788,7 @@ int am_chan_stats(int dtype, const void* x, int B, int D, int H, int W, int C, c
   Geo g = mkgeo(dtype, true, B, D, H, W, C, mask, bshift, fd, fh, fw);
   const bool geo_bad = mask && !geo_ok(B, D, H, W);          // only the LINEAR kernels decode voxel indices by reciprocal multiply
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * NREP, st);
+  AM_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * NREP, st));
   RowGeo rg;
   if (mask && mkrows(rg, dtype, true, B, D, H, W, C, bshift, active_list, n_active)) {
     DISPATCH_T(dtype, AM_LAUNCH(chan_stats_rows_kernel<float>, dim3(rows_blocks(rg)), dim3(rows_threads(rg)), 0, st, (const float*)x, rg, sums),
@@ -1892,7 +1892,7 @@ int am_norm_bwd_reduce(int dtype, const void* dout, const void* out, const void*
     fin.count_ptr = count_ptr; fin.count_host = count_host; fin.gamma = gamma; fin.rstd = rstd;
     fin.k0 = k0; fin.k1 = k1; fin.k2 = k2; fin.dgamma = dgamma; fin.dbeta = dbeta; fin.dtoken = dtoken; fin.dbeta2 = dbeta2;
   } else {
-    hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C * NREP, st);
+    AM_HIP(hipMemsetAsync(bsum, 0, sizeof(double) * 3 * C * NREP, st));
   }
   RowGeo rg;
   if (mask && !fill && mkrows(rg, dtype, true, B, D, H, W, C, bshift, active_list, n_active)) {
@@ -1956,7 +1956,7 @@ int am_norm_bwd_apply(int dtype, const void* dout, const void* out, const void* 
   const bool fused = rep && scratch_is_zero_workspace;
   float* dx_accum = fused ? dxsum_accum : nullptr;
   unsigned* dx_ticket = fused ? (unsigned*)(dxsum_scratch + (size_t)AM_DXREP * C) : nullptr;
-  if (rep && !fused) hipMemsetAsync(dxsum_scratch, 0, sizeof(double) * AM_DXREP * C, st);
+  if (rep && !fused) AM_HIP(hipMemsetAsync(dxsum_scratch, 0, sizeof(double) * AM_DXREP * C, st));
   if (rows) {
 #define AM_AR_(A_, O_)                                                                                                                  \
     DISPATCH_T(dtype,                                                                                                                    \
@@ -2146,7 +2146,7 @@ int am_partials_reduce(const float* partials, int rows, int C, double* sums, flo
     int nb = rows / (rstep * 16); nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
     const int rpb = ((rows + nb - 1) / nb + rstep - 1) / rstep * rstep;
     nb = (rows + rpb - 1) / rpb;
-    if (sums) hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st);
+    if (sums) AM_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * C, st));
     AM_LAUNCH(partials_reduce2_kernel, dim3(nb), dim3(256), 0, st, partials, rows, C, rpb, sums, sum_accum);
     AM_CHECK_LAUNCH();
     return 0;

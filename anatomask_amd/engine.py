@@ -185,8 +185,9 @@ class PackCache:
     The first step packs each weight when it is first used; from then on the packed copies persist and ONE batched launch
     (`am_pack_weights_batched`) rebuilds all of them after every optimizer / EMA update (84 launches -> 1)."""
 
-    def __init__(self, dtype):
+    def __init__(self, dtype, f32_split: bool = False):
         self.dtype = dtype
+        self.f32_split = bool(dtype == torch.float32 and f32_split)      # fp32 storage: products from bf16 hi / lo splits (ops.py)
         self.store: Dict[Tuple[str, bool], torch.Tensor] = {}
         self.src: Dict[Tuple[str, bool], torch.Tensor] = {}
         self.dirty = False
@@ -198,14 +199,14 @@ class PackCache:
     def _refresh(self):
         pairs = [(self.src[k], self.store[k]) for k in self.store]
         if self.table is None or not self.table.matches(pairs):
-            self.table = ops.PackTable(pairs, self.dtype, pairs[0][1].device)
+            self.table = ops.PackTable(pairs, self.dtype, pairs[0][1].device, self.f32_split)
         self.table.repack()
         self.dirty = False
 
     def get(self, W, name: str, transposed: bool, dgrad: bool) -> torch.Tensor:
         key = (name, dgrad)
         t = self.store.get(key)
-        if t is not None and getattr(t, "split", False) != bool(self.dtype == torch.float32 and ops.F32_SPLIT):
+        if t is not None and ops._is_split(t) != self.f32_split:
             self.store.clear(); self.src.clear(); self.table = None; self.dirty = False      # (the fp32 product mode changed: other layout)
             t = None
         if t is not None and self.src[key].data_ptr() != W[name].data_ptr():    # the master moved (new flat buffer): start over
@@ -214,7 +215,7 @@ class PackCache:
         if t is None:
             if self.dirty:
                 self._refresh()
-            t = ops.pack_weight(W[name], self.dtype, transposed, dgrad)
+            t = ops.pack_weight(W[name], self.dtype, transposed, dgrad, self.f32_split)
             self.store[key] = t
             self.src[key] = W[name]
             self.table = None
@@ -398,12 +399,16 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
 # profiles/r04_y_batch_cliff.txt.  That was the "batch cliff" of DESIGN.md 6.)
 FUSED_HEAD = True     # tools/step_ab.py engine.FUSED_HEAD=1,0: the projection head applies / differentiates the last BatchNorm itself
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
-_SIDE_KEEP: List[torch.Tensor] = []      # operands of side-stream launches not yet joined by the main stream
+_SIDE_KEEP: Dict[int, List[torch.Tensor]] = {}   # per device: operands of side-stream launches not yet joined by the main stream
 _USE_SIDE = True      # tools/step_ab.py flips this attribute for same-process A/B timing; no environment switch exists
 
 
+def _dev_index(dev) -> int:
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
 def _side_stream(dev) -> "torch.cuda.Stream":
-    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    i = _dev_index(dev)
     if i not in _SIDE:
         _SIDE[i] = torch.cuda.Stream(device=dev)
     return _SIDE[i]
@@ -416,22 +421,25 @@ def _on_side(dev, tensors, fn):
     ev = torch.cuda.Event()
     ev.record()
     s2.wait_event(ev)
+    _SIDE_KEEP.setdefault(_dev_index(dev), []).extend(tensors)      # (before the launch: kept even if fn raises half-way)
     with torch.cuda.stream(s2):
         fn()
-    _SIDE_KEEP.extend(tensors)
 
 
 def _join_side(dev):
-    if _USE_SIDE and _SIDE:
+    """the main stream of `dev` waits for ITS side stream; that device's kept operands are released (another device's side stream may
+    still be reading its own)."""
+    i = _dev_index(dev)
+    if _USE_SIDE and i in _SIDE:
         ev = torch.cuda.Event()
-        ev.record(_side_stream(dev))
-        torch.cuda.current_stream().wait_event(ev)
-    _SIDE_KEEP.clear()                    # (freed on the main stream, which now runs behind everything the side stream was given)
+        ev.record(_SIDE[i])
+        torch.cuda.current_stream(dev).wait_event(ev)
+    _SIDE_KEEP.pop(i, None)               # (freed on the main stream, which now runs behind everything the side stream was given)
 
 
-def _wgrad_into(G, name, mode, x, dy, k, stride, transposed=False, **masks):
+def _wgrad_into(pk: PackCache, G, name, mode, x, dy, k, stride, transposed=False, **masks):
     def run():
-        dwp = ops.conv3d_wgrad(mode, x, dy, k, stride, **masks)
+        dwp = ops.conv3d_wgrad(mode, x, dy, k, stride, f32_split=pk.f32_split, **masks)
         ops.unpack_grad(dwp, G[name], transposed, accumulate=True)
     _on_side(x.device, (x, dy), run)
 
@@ -445,7 +453,7 @@ def _dec_block_backward(W, G, pk: PackCache, t: dict, g: Optional[torch.Tensor],
         so = tuple(t["r"].shape[1:4])
         dc2 = _instance_norm_backward(g, t["c2"], t["st2"], ACT_NONE)
         dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1)
-        _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
+        _wgrad_into(pk, G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
         dc1 = _instance_norm_backward(dr, t["c1"], t["st1"], ACT_RELU6)
     elif t.get("head"):
         dc2 = ops.proj_norm_bwd(t["c2"], t["st2"], drec, W["dense_decoder.proj.weight"].view(-1), W[f"{q}.conv.4.weight"],
@@ -463,18 +471,18 @@ def _dec_block_backward(W, G, pk: PackCache, t: dict, g: Optional[torch.Tensor],
         dr = ops.conv3d(CONV_DGRAD, dc2, pk.get(W, f"{q}.conv.3.weight", False, True), None, so, 3, 1,
                         norm_bwd=(t["c1"], t["st1"], ACT_RELU6) if fuse else None)
         dr, red1 = dr if fuse else (dr, None)
-        _wgrad_into(G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
+        _wgrad_into(pk, G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
         dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
                                 G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"], reduced=red1)
     du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
     ptu.finalize(None, sum_accum=G[f"{q}.up_sample.bias"])  # ConvT bias gradient = per-channel sum of du
-    _wgrad_into(G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
+    _wgrad_into(pk, G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
     si = tuple(t["xin"].shape[1:4])
     gin = ops.conv3d(CONVT_DGRAD, du, pk.get(W, f"{q}.up_sample.weight", True, True), None, si, 4, 2, want_partials=bias_sum_into is not None)
     if bias_sum_into is not None:
         gin, ptg = gin
         ptg.finalize(None, sum_accum=bias_sum_into)
-    _wgrad_into(G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
+    _wgrad_into(pk, G, f"{q}.up_sample.weight", CONVT_FWD, t["xin"], du, 4, 2, transposed=True)
     return gin
 
 
@@ -520,7 +528,7 @@ def densify_backward(spec: Spec, W, G, pk: PackCache, mask: MaskInfo, tape: Tape
         if t["k"]:
             pw = f"densify_projs.{i}.weight"
             dd = ops.conv3d(CONV_DGRAD, dp, pk.get(W, pw, False, True), None, tuple(dp.shape[1:4]), t["k"], 1)
-            _wgrad_into(G, pw, CONV_FWD, t["d"], dp, t["k"], 1)
+            _wgrad_into(pk, G, pw, CONV_FWD, t["d"], dp, t["k"], 1)
             if i == 0:                                            # (levels >= 1 got it from the ConvT-dgrad epilogue)
                 ops.chan_sum(dp, None, 0, G[f"densify_projs.{i}.bias"])
         else:
@@ -548,7 +556,7 @@ def _enc_block_backward(W, G, pk: PackCache, inp: torch.Tensor, mask: MaskInfo, 
     da1 = ops.conv3d(CONV_DGRAD, dy2, pk.get(W, f"{p}.conv2.weight", False, True), None, sp, 3, 1,
                      in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs)
     red1 = None           # (the fused norm-backward reduce, ops.conv3d(norm_bwd=...), does not pay on block-sparse tensors: 64->64 @64^3 +0.12 ms for a 0.05 ms pass)
-    _wgrad_into(G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
+    _wgrad_into(pk, G, f"{p}.conv2.weight", CONV_FWD, a1, dy2, 3, 1, x_mask=mask, x_bshift=bs, y_mask=mask, y_bshift=bs)
     dy1 = ops.norm_backward(da1, None, y1, t["st1"], W[f"{p}.norm1.weight"], ACT_LRELU, mask, bs,
                             G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"], reduced=red1)
     stride = t["stride"]
@@ -558,14 +566,14 @@ def _enc_block_backward(W, G, pk: PackCache, inp: torch.Tensor, mask: MaskInfo, 
         return None
     bsx = bs + (1 if stride == 2 else 0)
     spx = tuple(x.shape[1:4])
-    _wgrad_into(G, f"{p}.conv1.weight", CONV_FWD, x, dy1, 3, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
+    _wgrad_into(pk, G, f"{p}.conv1.weight", CONV_FWD, x, dy1, 3, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
     if free_saved:
         t["y1"] = t["a1"] = t["y2"] = t["out"] = None      # free as we go
     if t["first"]:
         # block input = output map of stage s-1: add onto its densify gradient if it has one
         gx = ops.conv3d(CONV_DGRAD, dy1, pk.get(W, f"{p}.conv1.weight", False, True), None, spx, 3, stride,
                         in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=base, accumulate=base is not None)
-        _wgrad_into(G, f"{p}.conv3.weight", CONV_FWD, x, dpre, 1, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
+        _wgrad_into(pk, G, f"{p}.conv3.weight", CONV_FWD, x, dpre, 1, stride, x_mask=mask, x_bshift=bsx, y_mask=mask, y_bshift=bs)
         ops.conv3d(CONV_DGRAD, dpre, pk.get(W, f"{p}.conv3.weight", False, True), None, spx, 1, stride,
                    in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bsx, out=gx, accumulate=True)
         return gx
@@ -620,8 +628,11 @@ def backward(spec: Spec, W: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor],
         def after_group(tag, _h=user_hook, _dev=inp.device):
             _join_side(_dev)
             _h(tag)
-    dproj = decoder_backward(spec, W, G, pk, tape, drec, after_group)
-    dfeat = densify_backward(spec, W, G, pk, mask, tape, dproj)
-    if after_group:
-        after_group("densify")
-    encoder_backward(spec, W, G, pk, inp, mask, tape, dfeat, after_group)
+    try:
+        dproj = decoder_backward(spec, W, G, pk, tape, drec, after_group)
+        dfeat = densify_backward(spec, W, G, pk, mask, tape, dproj)
+        if after_group:
+            after_group("densify")
+        encoder_backward(spec, W, G, pk, inp, mask, tape, dfeat, after_group)
+    finally:
+        _join_side(inp.device)            # (also when backward raises: the kept activations must not outlive the call)

@@ -438,6 +438,9 @@ class SparK(nn.Module):
             d_width //= 2
         cnn = sparse_encoder.sp_cnn
         self.compute_dtype = compute_dtype
+        # fp32 storage only: matrix products from bf16 hi / lo splits (AM_DT_F32S) instead of the exact fp32 matrix instruction; a property
+        # of THIS model (its PackCache marks every packed weight copy with it), see set_f32_split
+        self.f32_split = bool(ops.DEFAULT_F32_SPLIT)
         self._flat: Optional[torch.Tensor] = None
         self._after_group = None
         # Any encoder other than this package's STUNet (a dense backbone rewritten by the sparse layer zoo, SparseEncoder.__init__) runs
@@ -498,11 +501,29 @@ class SparK(nn.Module):
             b.data = v
             self._W[n] = v
             o += (b.numel() + 3) // 4 * 4
-        for n, b in self.named_buffers():
-            if not b.is_floating_point():
-                self._W[n] = b
+        # integer buffers (BatchNorm num_batches_tracked, int64): views of ONE flat int64 buffer, so the teacher's EMA over them
+        # (am_ema_i64) and the non-finite guard's snapshot / restore are one launch each
+        ibufs = [(n, b) for n, b in self.named_buffers() if not b.is_floating_point()]
+        assert all(b.dtype == torch.int64 for _, b in ibufs)
+        iflat = torch.zeros(max(sum(b.numel() for _, b in ibufs), 1), device=dev, dtype=torch.int64)
+        o = 0
+        for n, b in ibufs:
+            v = iflat[o:o + b.numel()].view(b.shape)
+            v.copy_(b.data)
+            b.data = v
+            self._W[n] = v
+            o += b.numel()
+        self._iflat, self._n_ibuf = iflat, o
         self._flat, self._gflat, self._bflat, self._live_end, self._offs = flat, gflat, bflat, offs["live_end"], offs
-        self._pack = engine.PackCache(self.compute_dtype)
+        self._pack = engine.PackCache(self.compute_dtype, self.f32_split)
+
+    def set_f32_split(self, flag: bool):
+        """fp32-storage model: True = products from bf16 hi / lo splits of both operands with fp32 accumulation (16 significant bits per
+        operand, 4x the matrix rate), False = the exact fp32 matrix instruction (parity mode).  The packed weight copies are re-made."""
+        self.f32_split = bool(flag)
+        if self._flat is not None and not self._generic:
+            self._pack = engine.PackCache(self.compute_dtype, self.f32_split)
+        return self
 
     def _apply(self, fn, *a, **k):               # .to()/.cuda() replace parameter storage: re-flatten lazily
         self._flat = None
@@ -683,7 +704,7 @@ class SparK(nn.Module):
     def __deepcopy__(self, memo):
         """deepcopy (ModelEma) must not share the flat buffers: copy the module tree with plain tensors."""
         flat, self._flat = self._flat, None
-        saved = {k: self.__dict__.pop(k) for k in ("_W", "_G", "_gflat", "_bflat", "_pack", "_offs") if k in self.__dict__}
+        saved = {k: self.__dict__.pop(k) for k in ("_W", "_G", "_gflat", "_bflat", "_iflat", "_pack", "_offs") if k in self.__dict__}
         cls = self.__class__
         new = cls.__new__(cls)
         memo[id(self)] = new
@@ -730,9 +751,8 @@ class ModelEma:
             src._ensure_flat(); self.ema._ensure_flat()
             ops.ema(self.ema._flat, src._flat, self.decay)
             ops.ema(self.ema._bflat, src._bflat, self.decay)
-            for (n, e), (_, m) in zip(self.ema.named_buffers(), src.named_buffers()):
-                if not e.is_floating_point():                     # int64 num_batches_tracked, as timm does it
-                    e.copy_(e * self.decay + (1. - self.decay) * m)
+            if src._n_ibuf:                                       # int64 num_batches_tracked, as timm does it (promotion to float32, truncation)
+                ops.ema_i64(self.ema._iflat[:src._n_ibuf], src._iflat[:src._n_ibuf], self.decay)
             self.ema.weights_changed()
             return
         msd = src.state_dict()

@@ -19,16 +19,23 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
-# fp32-storage models: False = exact fp32 products (v_mfma_f32_16x16x4_f32, the parity mode: 1/16 of the bf16 matrix rate);
-# True = AM_DT_F32S: products from bf16 hi / lo splits of both operands with fp32 accumulation (16 significant bits per operand, 1/4 of
-# the bf16 rate in the convolutions, three bf16 passes in the weight gradients).  Set by SparK / AnatoMaskTrainer(f32_split=True) BEFORE the
-# first forward (packed weight copies are made for one of the two); the reference computes in fp32 (AMP = False, P/pretrain_AntoMask.py:239).
-F32_SPLIT = False
+# fp32-storage models compute their matrix products in one of two ways: exact fp32 products (v_mfma_f32_16x16x4_f32, the parity mode: 1/16
+# of the bf16 matrix rate) or AM_DT_F32S: products from bf16 hi / lo splits of both operands with fp32 accumulation (16 significant bits
+# per operand, 1/4 of the bf16 rate in the convolutions, three bf16 passes in the weight gradients).  The mode is a property of a MODEL
+# (SparK.f32_split -> its PackCache): it travels with every packed weight copy (`_am_f32_split`, set by pack_weight) into conv3d and is an
+# explicit argument of conv3d_wgrad -- no process-wide switch.  DEFAULT_F32_SPLIT is only what a newly CONSTRUCTED model starts with
+# (anatomask_amd.set_f32_products).  The reference computes in fp32 (AMP = False, P/pretrain_AntoMask.py:239).
+DEFAULT_F32_SPLIT = False
 
 
-def _dtc(t: torch.Tensor) -> int:
+def _dtc(t: torch.Tensor, f32_split: bool) -> int:
     """dtype code of a CONVOLUTION operand (am_conv3d / am_pack_weight / am_packed_dims / am_conv3d_partials_rows)."""
-    return hip.DT_F32S if (t.dtype == torch.float32 and F32_SPLIT) else _dt(t)
+    return hip.DT_F32S if (t.dtype == torch.float32 and f32_split) else _dt(t)
+
+
+def _is_split(w_packed: torch.Tensor) -> bool:
+    """the fp32 product mode a packed weight copy was made for (False for anything pack_weight did not mark)."""
+    return getattr(w_packed, "_am_f32_split", False) is True
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -148,7 +155,7 @@ _ROWS_OUT = _ct.c_int(0)
 _ROWS_ADDR = _ct.addressof(_ROWS_OUT)
 
 
-def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_dgrad: bool) -> torch.Tensor:
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_dgrad: bool, f32_split: bool = False) -> torch.Tensor:
     """torch-layout fp32 weight -> packed [taps][rows][K] in `dtype`.
     Conv3d weight (Cout,Cin,k,k,k); ConvTranspose3d weight (Cin,Cout,k,k,k).
     forward: rows = output channels, K = input channels; dgrad: swapped."""
@@ -162,9 +169,10 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_
         R, K, sr, sk = cin, cout, s_in, s_out
     Rp, Kp = packed_dims(dtype, R, K)
     out = torch.empty(taps, Rp, Kp, device=w.device, dtype=dtype)
-    hip.lib().pack_weight(_dtc(out), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, Rp, Kp, _stream())
+    split = bool(out.dtype == torch.float32 and f32_split)
+    hip.lib().pack_weight(_dtc(out, split), w.data_ptr(), out.data_ptr(), R, K, taps, sr, sk, Rp, Kp, _stream())
     out.logical = (R, K)
-    out.split = bool(out.dtype == torch.float32 and F32_SPLIT)      # (what the copy was made for: PackCache re-makes it when the mode changes)
+    out._am_f32_split = split      # (what the copy was made for: conv3d launches the matching kernels, PackCache re-makes it when the mode changes)
     out.pack_args = (R, K, taps, sr, sk, Rp, Kp)
     return out
 
@@ -172,8 +180,9 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, transposed_conv: bool, for_
 class PackTable:
     """Device table of am_pack_desc for `am_pack_weights_batched`: every (master weight, packed copy) pair of a model."""
 
-    def __init__(self, pairs, dtype: torch.dtype, device):
+    def __init__(self, pairs, dtype: torch.dtype, device, f32_split: bool = False):
         import struct
+        self.f32_split = bool(dtype == torch.float32 and f32_split)
         blob, first = b"", 0
         for w, out in pairs:
             R, K, taps, sr, sk, Rp, Kp = out.pack_args
@@ -188,7 +197,7 @@ class PackTable:
         return len(pairs) == self.n and all(p == (w.data_ptr(), o.data_ptr()) for p, (w, o) in zip(self.ptrs, pairs))
 
     def repack(self):
-        code = hip.DT_BF16 if self.dtype == torch.bfloat16 else (hip.DT_F32S if F32_SPLIT else hip.DT_F32)
+        code = hip.DT_BF16 if self.dtype == torch.bfloat16 else (hip.DT_F32S if self.f32_split else hip.DT_F32)
         hip.lib().pack_weights_batched(code, self.dev.data_ptr(), self.n, self.blocks, _stream())
 
 
@@ -236,12 +245,12 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
                                part.t.data_ptr(), xp.data_ptr(), st.scale.data_ptr(), st.shift.data_ptr(), int(nact), _ROWS_ADDR, _stream())
         part.rows = _ROWS_OUT.value
         return out, part
-    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift, _dtc(x), Cin, aln) if want_partials else None
+    split = _is_split(w_packed)                                  # (the fp32 product mode rides on the packed weight copy)
+    part = ConvPartials(mode, ksize, stride, B, out_spatial, Cout, x.device, out_mask is not None, out_bshift, _dtc(x, split), Cin, aln) if want_partials else None
     if out is None:
         out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
     rows = _ROWS_OUT
-    assert getattr(w_packed, "split", False) == bool(x.dtype == torch.float32 and F32_SPLIT), "packed weight copy made for the other fp32 product mode"
-    hip.lib().conv3d(mode, _dtc(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
+    hip.lib().conv3d(mode, _dtc(x, split), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
                      B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
                      in_mask.t.data_ptr() if in_mask else None, in_bshift,
                      out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate),
@@ -273,7 +282,7 @@ GATHER_WGRAD = True      # (tools: same-process A/B of the gather-form weight gr
 
 def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int,
                  x_mask: Optional[MaskInfo] = None, x_bshift: int = 0, y_mask: Optional[MaskInfo] = None,
-                 y_bshift: int = 0) -> torch.Tensor:
+                 y_bshift: int = 0, f32_split: bool = False) -> torch.Tensor:
     B, Dx, Hx, Wx, Cx = x.shape
     _, Dy, Hy, Wy, Cy = dy.shape
     taps = ksize ** 3
@@ -298,7 +307,7 @@ def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, strid
                                y_mask.t.data_ptr() if y_mask else None, y_bshift, fd, fh, fw,
                                ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, *al,
                                gws.data_ptr() if gws is not None else None, gb, _stream())
-    if x.dtype == torch.float32 and F32_SPLIT:
+    if x.dtype == torch.float32 and f32_split:
         # AM_DT_F32S: dW = X^T dY with X = Xh + Xl, dY = Yh + Yl (bf16 planes, am_split_bf16): three bf16 matrix-core contractions
         # accumulate into the ONE fp32 gradient (atomics, or the deterministic fold: both add into dw); the lo lo term (2^-16 of the
         # result) is dropped.  The planes are transient (2 x 2 bytes per element = the size of the fp32 tensor).
@@ -576,9 +585,12 @@ def sumsq(g: torch.Tensor, out: torch.Tensor):
     hip.lib().sumsq(g.data_ptr(), g.numel(), out.data_ptr(), _stream())
 
 
-def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, ema_decay, gnorm_out, grad_scale: float = 1.0, dyn=None):
+def adamw_ema(p, g, m, v, ema, n, lr, betas, eps, wd, step, sumsq_t, max_norm, ema_decay, gnorm_out, grad_scale: float = 1.0, dyn=None,
+              guard: Optional[torch.Tensor] = None):
+    """guard: device int32[4] {latched, first bad call, calls, 0} -- the per-step non-finite stop (am_adamw_ema)."""
+    assert guard is None or (guard.dtype == torch.int32 and guard.numel() >= 4)
     hip.lib().adamw_ema(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _p(ema), n, lr, betas[0], betas[1], eps, wd, step,
-                        _p(sumsq_t), max_norm, ema_decay, grad_scale, _p(gnorm_out), _p(dyn), _stream())
+                        _p(sumsq_t), max_norm, ema_decay, grad_scale, _p(gnorm_out), _p(dyn), _p(guard), _stream())
 
 
 def adam_dyn_scalars(lr: float, betas, step: int, ema_decay: float):
@@ -587,8 +599,20 @@ def adam_dyn_scalars(lr: float, betas, step: int, ema_decay: float):
     return [float(lr), 1.0 - betas[0] ** step, math.sqrt(1.0 - betas[1] ** step), float(ema_decay)]
 
 
-def ema(ema_t: torch.Tensor, p: torch.Tensor, decay: float):
-    hip.lib().ema(ema_t.data_ptr(), p.data_ptr(), p.numel(), decay, _stream())
+def ema(ema_t: torch.Tensor, p: torch.Tensor, decay: float, guard: Optional[torch.Tensor] = None):
+    hip.lib().ema(ema_t.data_ptr(), p.data_ptr(), p.numel(), decay, _p(guard), _stream())
+
+
+def ema_i64(ema_t: torch.Tensor, p: torch.Tensor, decay: float, guard: Optional[torch.Tensor] = None):
+    """timm's ModelEma.update on int64 entries (num_batches_tracked), all of them in one launch."""
+    assert ema_t.dtype == p.dtype == torch.int64 and ema_t.numel() == p.numel() and ema_t.is_contiguous() and p.is_contiguous()
+    hip.lib().ema_i64(ema_t.data_ptr(), p.data_ptr(), p.numel(), decay, _p(guard), _stream())
+
+
+def guard_restore(dst: torch.Tensor, snapshot: torch.Tensor, guard: torch.Tensor):
+    """dst = snapshot where the non-finite guard is latched (device-side decision, no host round trip)."""
+    assert dst.dtype == snapshot.dtype and dst.numel() == snapshot.numel() and dst.is_contiguous() and snapshot.is_contiguous()
+    hip.lib().guard_restore(dst.data_ptr(), snapshot.data_ptr(), dst.numel() * dst.element_size(), guard.data_ptr(), _stream())
 
 
 # ------------------------------------------------------------------ data-feed augmentation (device side)

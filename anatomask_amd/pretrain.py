@@ -125,6 +125,57 @@ def all_ranks_finite(value: float, dev, world: int) -> bool:
     return bool(ok.item() > 0)
 
 
+def first_nonfinite_step(trainer, world: int):
+    """P/pretrain_AntoMask.py:441-446 looks at `loss.item()` after EVERY step; here the look is on the device (am_adamw_ema's guard: a
+    step whose loss / gradient norm is not finite changes nothing, and neither does any step after it) and the host reads the latch once
+    per epoch.  Returns None or the step; all ranks agree (the all-reduced gradient is non-finite everywhere; MIN over ranks for safety)."""
+    s = trainer.nonfinite_step()
+    if world > 1:
+        t = torch.tensor([float(s) if s is not None else float("inf")], device=trainer.guard.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        v = float(t.item())
+        s = None if math.isinf(v) else int(v)
+    return s
+
+
+class RunLog:
+    """The run's text log and per-epoch series (P/pretrain_AntoMask.py:244-275 `print_to_log_file`: a `training_log_<Y>_<M>_<D>_<h>_<m>_<s>.txt`
+    in the output folder, every line stamped, writes retried on IOError; `nnUNetLogger`'s dict of per-epoch lists,
+    nnunetv2/training/logging/nnunet_logger.py:9-52, logged at :381,453,467).  Rank 0 owns the file; every rank may `say` (errors)."""
+    SERIES = ("train_losses", "val_losses", "lrs", "epoch_start_timestamps", "epoch_end_timestamps")
+
+    def __init__(self, folder: str, rank: int, series=None):
+        from datetime import datetime
+        t = datetime.now()
+        self.rank = rank
+        self.path = os.path.join(folder, "training_log_%d_%d_%d_%02d_%02d_%02d.txt" % (t.year, t.month, t.day, t.hour, t.minute, t.second))
+        self.series = {k: list((series or {}).get(k, [])) for k in self.SERIES}
+
+    def say(self, *args, to_file=None):
+        from datetime import datetime
+        line = " ".join(str(a) for a in (f"{datetime.now()}:", *args))
+        if self.rank == 0 if to_file is None else to_file:
+            for attempt in range(5):
+                try:
+                    with open(self.path, "a+") as f:
+                        f.write(line + "\n")
+                    break
+                except IOError as e:
+                    print(f"{datetime.now()}: failed to log: {e}", flush=True)
+                    time.sleep(0.5)
+        print(line, flush=True)
+
+    def log(self, key: str, value, epoch: int):
+        """nnUNetLogger.log: one value per epoch; a repeated epoch overwrites its entry."""
+        s = self.series[key]
+        if len(s) == epoch:
+            s.append(value)
+        elif len(s) > epoch:
+            s[epoch] = value
+        else:
+            s.extend([None] * (epoch - len(s)) + [value])
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1, help="> 1 without a launcher: start one rank per GPU (anatomask_amd.launch)")
@@ -190,40 +241,51 @@ def main(argv=None):
                                 "close": lambda s: None})()
     start, epoch_loss, val_loss, ema_loss, best_val = 0, [], [], None, 1e9
     ck_resume = locals().get("ck_resume")
+    series = None
     if a.resume:
         ck = checkpoint.load_checkpoint(ck_resume if ck_resume is not None else a.resume, trainer, rank)
         ck_resume = None
         start = int(ck["current_epoch"]) + 1
         epoch_loss, val_loss, ema_loss = list(ck.get("train_loss", [])), list(ck.get("val_loss", [])), ck.get("ema_loss")
         best_val = ck.get("best_val_loss", best_val)
+        series = ck.get("logging")
+    log = RunLog(a.out, rank, series)
+    log.say(f"anatomask_amd pretraining: STUNet-{a.model} {tuple(a.input_size)} batch {a.batch_size} x {world} rank(s), mask ratio {a.mask_ratio}, "
+            f"{a.dtype}, {'plain SparK' if a.plain_spark else 'AnatoMask'}, epochs {start}..{a.epochs - 1}, {a.iters_per_epoch} iterations each"
+            + (f", resumed from {a.resume}" if a.resume else ""))
     for i in range(start, a.epochs):
         trainer.set_epoch(i); trainer.lr = lrs[i]                                     # :383-386, :452
         t0, acc = time.time(), torch.zeros(1, device=dev)
+        log.log("epoch_start_timestamps", t0, i); log.log("lrs", lrs[i], i)            # :381
         for _ in range(a.iters_per_epoch):
             out = trainer.step(next(feed), epoch=i)
             acc += out["loss"]
         loss = acc.item() / a.iters_per_epoch                                          # ONE host sync per epoch
-        if not all_ranks_finite(loss, dev, world):                                     # :443-446, on every rank together
-            print(f"[rk{rank:02d}] Loss is {loss}, stopping training!", flush=True)
+        bad = first_nonfinite_step(trainer, world)                                     # :441-446: the per-step check, made on the device
+        if bad is not None or not all_ranks_finite(loss, dev, world):                  # on every rank together
+            log.say(f"[rk{rank:02d}] Loss is {loss}" + (f" (first non-finite step: {bad}; weights, Adam state, teacher and BatchNorm buffers "
+                    f"are those before it)" if bad is not None else "") + ", stopping training!", to_file=True)
             sys.exit(-1)
         epoch_loss.append(loss)
         ema_loss = loss if ema_loss is None else 0.9 * ema_loss + 0.1 * loss           # :456-461
-        extra = {"ema_loss": ema_loss, "feed_state": gather_feed_states(feed, rank, world)}
+        log.log("train_losses", loss, i); log.log("epoch_end_timestamps", time.time(), i)          # :453, :467
+        extra = {"ema_loss": ema_loss, "feed_state": gather_feed_states(feed, rank, world), "logging": log.series}
         if a.plain_spark and val_feed is not None:                                     # P/pretrain.py:426-463: eval() pass, no grad, BN on running stats
             vacc = torch.zeros(1, device=dev)
             for _ in range(a.val_iters):
                 vacc += trainer.eval_loss(next(val_feed))
             v = vacc.item() / a.val_iters
             val_loss.append(v)
+            log.log("val_losses", v, i)
             if v < best_val and rank == 0:
                 best_val = v
                 checkpoint.save_checkpoint(os.path.join(a.out, f"STUNet_{a.model}_head_best.pt"), trainer, epoch_loss, i, val_loss,
                                            dict(extra, best_val_loss=best_val))
         if rank == 0:
             dt = time.time() - t0
-            print(f"Epoch {i} lr {lrs[i]:.2e} ema_decay {trainer.teacher.decay:.5f} train loss {loss:.4f} (ema {ema_loss:.4f})"
-                  + (f" val loss {val_loss[-1]:.4f} (best {best_val:.4f})" if val_loss else "")
-                  + f" {dt:.1f} s, {a.iters_per_epoch * a.batch_size * world / dt:.1f} volumes/s", flush=True)
+            log.say(f"Epoch {i} lr {lrs[i]:.2e} ema_decay {trainer.teacher.decay:.5f} train_loss {loss:.4f} (ema {ema_loss:.4f})"
+                    + (f" val_loss {val_loss[-1]:.4f} (best {best_val:.4f})" if val_loss else "")
+                    + f" Epoch time: {dt:.2f} s, {a.iters_per_epoch * a.batch_size * world / dt:.1f} volumes/s")          # :468-470
             checkpoint.save_checkpoint(os.path.join(a.out, f"STUNet_{a.model}_head_latest.pt"), trainer, epoch_loss, i,
                                        val_loss if a.plain_spark else None, dict(extra, best_val_loss=best_val))   # :472-479
     feed.close()

@@ -25,11 +25,11 @@ class AnatoMaskTrainer:
         if model.spec.dec_inorm:
             raise NotImplementedError("the fused trainer keeps the drivers' BatchNorm decoder (P/pretrain_AntoMask.py:212); a "
                                       "LightDecoder(use_IN=True) model trains through the module API (SparK.forward / forward_loss / a torch optimizer)")
-        # fp32-storage models only: matrix-core products from bf16 hi / lo splits (ops.F32_SPLIT, AM_DT_F32S) instead of the exact fp32
-        # matrix instruction -- the fast reference-precision mode (the reference recipe is AMP = False, P/pretrain_AntoMask.py:239)
-        self.f32_split = bool(f32_split)
-        from . import ops as _ops
-        _ops.F32_SPLIT = self.f32_split
+        # fp32-storage models only: matrix-core products from bf16 hi / lo splits (AM_DT_F32S) instead of the exact fp32 matrix
+        # instruction -- the fast reference-precision mode (the reference recipe is AMP = False, P/pretrain_AntoMask.py:239).  A property of
+        # the MODEL (SparK.f32_split, inherited by the teacher's deep copy): no process-wide switch
+        self.f32_split = bool(f32_split) or bool(getattr(model, "f32_split", False))
+        model.set_f32_split(self.f32_split)
         self._capturing, self._graph, self._graph_key = False, None, None
         if deterministic_wgrad:
             # convolution weight gradients as per-slot partial sums folded in a fixed order instead of fp32 atomics (am_conv3d_wgrad's
@@ -51,6 +51,12 @@ class AnatoMaskTrainer:
         self.sumsq = torch.zeros(1, device=dev, dtype=torch.float64)
         self.gnorm = torch.zeros(1, device=dev)
         self.step_count = 0
+        # per-step non-finite stop on the device (am_adamw_ema `guard`): {latched, first bad call, calls, 0}; the BatchNorm buffers the
+        # student's forward updates are snapshotted per step and put back by am_guard_restore when the guard latches
+        self.guard = torch.zeros(4, device=dev, dtype=torch.int32)
+        self._guard_step0 = 0
+        self._snap_b = torch.empty_like(model._bflat)
+        self._snap_i = torch.empty_like(model._iflat)
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed)
         self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
@@ -167,7 +173,6 @@ class AnatoMaskTrainer:
         Returns device tensors only: {'loss','grad_norm','mask','recon_loss','rec_loss'}."""
         m, t = self.model, self.teacher.ema
         spec = m.spec
-        ops.F32_SPLIT = self.f32_split                  # (process-wide switch: this trainer's mode for everything it launches)
         x = inp_bchwd[:, 0].float().contiguous()
         B = x.shape[0]
         L = spec.fmap[0] * spec.fmap[1] * spec.fmap[2]
@@ -195,6 +200,7 @@ class AnatoMaskTrainer:
         else:                                                     # plain SparK: the random mask IS the student mask
             recon, mk, mi = None, m1, mi1
         # 4. student forward + loss (:429-430)
+        self._snap_b.copy_(m._bflat); self._snap_i.copy_(m._iflat)   # (what a step that turns out non-finite must not have changed)
         tape = engine.Tape()
         rec = engine.forward(spec, m._W, m._pack, x, mi, train=True, tape=tape, recompute=m.recompute)
         l2m, pm, pr, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
@@ -216,16 +222,17 @@ class AnatoMaskTrainer:
             self.step_count += 1
         ops.adamw_ema(m._flat, m._gflat, self.m, self.v, t._flat if self.self_distill else None, n, self.lr if lr is None else lr,
                       self.betas, self.eps, self.wd, max(self.step_count, 1), self.sumsq, self.clip, decay, self.gnorm,
-                      grad_scale=self.grad_scale, dyn=dyn)
+                      grad_scale=self.grad_scale, dyn=dyn, guard=self.guard)
+        ops.guard_restore(m._bflat, self._snap_b, self.guard)
+        ops.guard_restore(m._iflat, self._snap_i, self.guard)
         if not self.self_distill:
             m.weights_changed()
             return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": None, "rec_loss": l2m}
         if m._flat.numel() > n:                                   # dead densify[4] tensors: EMA only (no optimizer step)
-            ops.ema(t._flat[n:], m._flat[n:], decay)
-        ops.ema(t._bflat, m._bflat, decay)                        # BN running stats are EMA'd too (timm: every state_dict entry)
-        for (_, e), (_, s_) in zip(t.named_buffers(), m.named_buffers()):
-            if not e.is_floating_point():
-                e.copy_(e * decay + (1. - decay) * s_)
+            ops.ema(t._flat[n:], m._flat[n:], decay, self.guard)
+        ops.ema(t._bflat, m._bflat, decay, self.guard)            # BN running stats are EMA'd too (timm: every state_dict entry)
+        if m._n_ibuf:                                             # ... and the int64 num_batches_tracked, with timm's float32 promotion
+            ops.ema_i64(t._iflat[:m._n_ibuf], m._iflat[:m._n_ibuf], decay, self.guard)
         m.weights_changed(); t.weights_changed()
         return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": recon, "rec_loss": l2m}
 
@@ -284,7 +291,6 @@ class AnatoMaskTrainer:
         """Validation pass of the plain-SparK driver (P/pretrain.py:426-441: model.eval(), no grad, random mask, the normalised
         masked MSE of P/spark3D.py:130-146): student in eval mode -- decoder BatchNorm on running statistics.  Returns loss[1]."""
         m, spec = self.model, self.model.spec
-        ops.F32_SPLIT = self.f32_split
         x = inp_bchwd[:, 0].float().contiguous()
         B, L = x.shape[0], spec.fmap[0] * spec.fmap[1] * spec.fmap[2]
         if mask is None:
@@ -295,6 +301,17 @@ class AnatoMaskTrainer:
         rec = engine.forward(spec, m._W, m._pack, x, mi, train=False)
         _, _, _, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
         return info[0:1]
+
+    def nonfinite_step(self) -> Optional[int]:
+        """None, or the optimizer step (1-based, as `step_count` counts them) whose loss / gradient norm was not finite: that step and
+        every later one left weights, Adam moments, teacher and BatchNorm buffers untouched (am_adamw_ema `guard`).  ONE host
+        synchronisation -- the driver calls it where the reference's per-step `loss.item()` check would sit, once per epoch."""
+        g = self.guard.tolist()
+        return self._guard_step0 + g[1] if g[0] else None
+
+    def reset_guard(self):
+        self.guard.zero_()
+        self._guard_step0 = self.step_count
 
     def set_epoch(self, i: int):
         """per-epoch EMA decay ramp (P/pretrain_AntoMask.py:383-386)."""

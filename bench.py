@@ -230,7 +230,6 @@ def secondary_lines(a, kw, dev, dtype_main):
                     "ms_per_step_max": round(per[-1], 3), "value": round(batch / d, 3), "unit": "volumes/s", "steps": steps,
                     "final_loss": round(o["loss"].item(), 5)})
         del tr, model, x
-        _ops.F32_SPLIT = False
         torch.cuda.empty_cache()
     return out
 

@@ -248,8 +248,18 @@ int am_adamw_ema(float* p, const float* g, float* m, float* v, float* ema /* may
                  float* gnorm_out,
                  const float* dyn_scalars /* NULL, or DEVICE float[4] = {lr, 1 - beta1^step, sqrt(1 - beta2^step), ema_decay} that override
                  the by-value arguments: a step captured in a hipGraph replays with per-step values the host writes before each launch */,
+                 int* guard /* NULL, or DEVICE int[4] = {latched, first bad call (1-based), calls, 0}: the per-step non-finite stop of
+                 P/pretrain_AntoMask.py:441-446 without a host round trip.  A call whose gradient norm is not finite (am_patch_loss_bwd makes the
+                 gradient of a non-finite loss NaN, so the all-reduced norm is non-finite on EVERY rank) writes nothing to p / m / v / ema
+                 and latches guard[0]; every later call is skipped as well, so the state the driver finds at its one per-epoch look is the
+                 state before the bad step */,
                  void* stream);
-int am_ema(float* ema, const float* p, long n, double decay, void* stream);
+int am_ema(float* ema, const float* p, long n, double decay, const int* guard /* NULL, or am_adamw_ema's: skipped when latched */, void* stream);
+/* ModelEma.update on the integer entries (BatchNorm num_batches_tracked): ema = int64(float32(ema) * decay + (1 - decay) * float32(p)),
+ * the promotion / truncation `ema_v.copy_(ema_v * decay + (1. - decay) * model_v)` performs on an int64 tensor (timm.utils.ModelEma). */
+int am_ema_i64(long* ema, const long* p, int n, double decay, const int* guard, void* stream);
+/* guard latched: dst = snapshot (the BatchNorm running statistics / counters the student's forward of the bad step updated). nbytes % 4 == 0. */
+int am_guard_restore(void* dst, const void* snapshot, long nbytes, const int* guard, void* stream);
 
 /* Device-side spatial augmentation of the data feed: batchgenerators' SpatialTransform (rotation, isotropic scale,
  * order-3 spline interpolation, constant border) + MirrorTransform as the reference configures them (P/pretrain_AntoMask.py:78-113),

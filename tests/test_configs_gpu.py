@@ -183,12 +183,9 @@ def test_config2_stunet_b_128_fp32_storage_step_vs_oracle(f32_split):
     from anatomask_amd.trainer import AnatoMaskTrainer
     cfg, W0, x, mask1, keys, o = _oracle_step_b128()
     m = _build(cfg, W0, dtype=torch.float32)
-    try:
-        tr = AnatoMaskTrainer(m, lr=1e-4, ema_decay=0.999, total_epochs=1000, distributed=False, f32_split=f32_split)
-        out = tr.step(x.to(DEV), epoch=0, mask1=mask1, keys=keys)
-        torch.cuda.synchronize()
-    finally:
-        ops.F32_SPLIT = False
+    tr = AnatoMaskTrainer(m, lr=1e-4, ema_decay=0.999, total_epochs=1000, distributed=False, f32_split=f32_split)
+    out = tr.step(x.to(DEV), epoch=0, mask1=mask1, keys=keys)
+    torch.cuda.synchronize()
     loss_tol = 1e-5 if f32_split else F32_LOSS
     l2_tol = 2e-5 if f32_split else F32_L2
     # per gradient tensor: the exact mode sits at the reference's own fp32-vs-fp64 distance (median 4.2e-3, max 6.0e-3, bound 1.8e-2); the
@@ -399,7 +396,6 @@ def test_config2_bf16_training_tracks_fp32_storage_training():
         del tr, m
         torch.cuda.empty_cache()
     from anatomask_amd import ops
-    ops.F32_SPLIT = False
     b, f = np.array(curves["bf16"]), np.array(curves["fp32"])
     print("bf16 curve", np.round(b, 5).tolist()); print("fp32 curve", np.round(f, 5).tolist())
     print("per-step relative distance", np.round(np.abs(b - f) / f, 5).tolist())

@@ -168,10 +168,7 @@ def test_trainer_n_steps_fp32_matches_reference(f32_split):
     reference-precision mode) -- SAME bounds as the exact-fp32 mode."""
     from anatomask_amd import ops
     r, f = load("train_tiny.npz"), load("forward_tiny.npz")
-    try:
-        cfg, W0, m, tr, out, snap = _run_trainer(torch.float32, r, f, f32_split=f32_split)
-    finally:
-        ops.F32_SPLIT = False
+    cfg, W0, m, tr, out, snap = _run_trainer(torch.float32, r, f, f32_split=f32_split)
     names = [str(n) for n in r["names"]]
     for s, o in enumerate(out):
         assert np.array_equal(o["mask"].numpy().astype(bool).reshape(r["mask"][s].shape), r["mask"][s]), f"sampler mask diverged at step {s}"
@@ -595,6 +592,83 @@ def test_two_ranks_on_one_gpu_stay_in_sync():
     # ... and what was exchanged IS the mean of the two ranks' local gradients (recomputed through the module API on each rank's
     # own input and mask from the common start weights), global norm included
     assert r.stdout.count("mean-of-gradients ok: True") == 2, r.stdout[-2000:]
+
+
+def test_nonfinite_step_is_skipped_on_the_device_and_latched():
+    """P/pretrain_AntoMask.py:441-446 checks `loss.item()` after every step.  Here the check is on the device (am_adamw_ema `guard`): a NaN
+    volume at step k must leave weights, Adam moments, EMA teacher and BatchNorm buffers (running statistics AND num_batches_tracked) of
+    student and teacher BIT-identical to what they were before step k, latch the flag with the step index, and keep later (clean) steps
+    from changing anything either -- the driver finds the pre-step-k state when it looks once per epoch.  Also the overflow case: a
+    loss of +inf with finite reconstructions elsewhere (am_patch_loss_bwd makes its gradient NaN)."""
+    from anatomask_amd import modules as M
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    for poison in (float("nan"), float("inf")):
+        torch.manual_seed(0)
+        model = M.build_spark([32, 32, 48, 64, 64, 64], [1] * 6, 128, (48, 48, 48), 0.6, compute_dtype=torch.bfloat16).to(DEV)
+        tr = AnatoMaskTrainer(model, lr=1e-3, total_epochs=100, seed=3)
+        t = tr.teacher.ema
+        x = np_volume(2, (48, 48, 48), 77).to(DEV)
+
+        def snap():
+            return [v.detach().clone() for v in (model._flat, model._bflat, model._iflat, tr.m, tr.v, t._flat, t._bflat, t._iflat)]
+        for _ in range(2):
+            o = tr.step(x, epoch=50)
+        assert tr.nonfinite_step() is None and tr.guard.tolist()[:3] == [0, 0, 2] and np.isfinite(o["loss"].item())
+        assert int(model._iflat[0]) == 2 and int(t._iflat[0]) == 0      # (student counted 2 batches; timm's int64 EMA truncates 0.002 to 0)
+        before = snap()
+        xb = x.clone()
+        xb[1, 0, 5:9, 17:21, 30:34] = poison
+        o = tr.step(xb, epoch=50)                                       # step 3: non-finite
+        assert not np.isfinite(o["loss"].item())
+        after_bad = snap()
+        for _ in range(2):
+            tr.step(x, epoch=50)                                        # clean steps after the latch: skipped as well
+        torch.cuda.synchronize()
+        names = ("weights", "BN running stats", "num_batches_tracked", "exp_avg", "exp_avg_sq", "teacher", "teacher BN stats", "teacher counters")
+        for n, a, b, c in zip(names, before, after_bad, snap()):
+            assert torch.equal(a, b) and torch.equal(a, c), n
+        assert all(torch.isfinite(v.float()).all() for v in before)
+        assert tr.guard.tolist()[:3] == [1, 3, 5] and tr.nonfinite_step() == 3
+        tr.reset_guard()                                               # (what a resume does) -> training continues from the clean state
+        o = tr.step(x, epoch=50)
+        assert np.isfinite(o["loss"].item()) and tr.nonfinite_step() is None and not torch.equal(model._flat, before[0])
+
+
+def test_nonfinite_guard_two_ranks_latch_together():
+    """a NaN volume on ONE rank: the all-reduced gradient is NaN on both, both latch at the same step and keep their pre-step state."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "tools", "guard_two_ranks_one_gpu.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("first non-finite step 3; state as before step 3: True") == 2, r.stdout[-2000:]
+
+
+def test_pretrain_driver_exits_minus_one_on_a_nonfinite_step(tmp_path, monkeypatch):
+    """the driver loop (anatomask_amd.pretrain): a non-finite volume in the feed -> exit code -1 at the end of that epoch (as
+    P/pretrain_AntoMask.py:446), message naming the step, and NO checkpoint of the poisoned epoch."""
+    from anatomask_amd import pretrain
+
+    def poisoned(batch, size, seed):
+        g, n = torch.Generator().manual_seed(seed), 0
+        while True:
+            v = torch.randn(batch, 1, *size, generator=g)
+            n += 1
+            if n == 5:                                                 # epoch 0 = steps 1..3 (saved), epoch 1 = steps 4..6
+                v[0, 0, :4, :4, :4] = float("nan")
+            yield {"data": v}
+    monkeypatch.setattr(pretrain, "synthetic_batches", poisoned)
+    out = str(tmp_path / "run")
+    with pytest.raises(SystemExit) as e:
+        pretrain.main(["--model", "S", "--input-size", "48", "48", "48", "--batch-size", "2", "--epochs", "3", "--iters-per-epoch", "3", "--out", out])
+    assert e.value.code == -1
+    ck = torch.load(os.path.join(out, "STUNet_S_head_latest.pt"))
+    assert int(ck["current_epoch"]) == 0 and all(torch.isfinite(v.float()).all() for v in ck["network_weights"].values())
+    log = [f for f in os.listdir(out) if f.startswith("training_log_")]
+    assert log and "first non-finite step: 5" in open(os.path.join(out, log[0])).read()
 
 
 # ------------------------------------------------------------------------------------------------------------------------

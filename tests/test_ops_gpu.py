@@ -340,7 +340,7 @@ def test_conv_fwd_dgrad_wgrad(ops, dtype, case, sparse):
 @pytest.mark.parametrize("case", [(32, 64, 3, 1), (64, 32, 3, 2), (40, 72, 1, 2), (16, 24, 3, 1), (64, 64, 4, 2)])
 @pytest.mark.parametrize("sparse", [False, True])
 def test_conv_f32_split_products(ops, case, sparse):
-    """ops.F32_SPLIT: fp32 tensors, channel contraction on the bf16 matrix cores from hi / lo splits of BOTH operands (hi hi + hi lo +
+    """f32_split=True (AM_DT_F32S): fp32 tensors, channel contraction on the bf16 matrix cores from hi / lo splits of BOTH operands (hi hi + hi lo +
     lo hi + lo lo forward / data gradient; the three leading terms in the weight gradient), fp32 accumulation.  Against F.conv3d /
     F.conv_transpose3d autograd in fp32 on inputs that are NOT bf16-representable: <= 3e-5 of the tensor's max (the exact mode's bound is
     2e-4 for reduction order alone; plain bf16 operands would be at 4e-3)."""
@@ -356,8 +356,7 @@ def test_conv_f32_split_products(ops, case, sparse):
     mi = ops.MaskInfo.from_bool(mask, DEV) if sparse else None
     mo = O.upsample_mask(mask, so).float() if sparse else None
     mi_in = O.upsample_mask(mask, si).float() if sparse else None
-    ops.F32_SPLIT = True
-    try:
+    if True:
         if convt:                                        # ConvTranspose3d k4 s2 p1: coarse `so` -> fine 2 * so
             fine = tuple(2 * v for v in so)
             x = rnd(B, cin, *so, seed=1)
@@ -366,11 +365,11 @@ def test_conv_f32_split_products(ops, case, sparse):
             xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
             yr = F.conv_transpose3d(xr, wr, None, stride=2, padding=1)
             yr.backward(dy)
-            y = ops.conv3d(ops.CONVT_FWD, to_cl(x, dt), ops.pack_weight(w.to(DEV), dt, True, False), None, fine, 4, 2)
+            y = ops.conv3d(ops.CONVT_FWD, to_cl(x, dt), ops.pack_weight(w.to(DEV), dt, True, False, f32_split=True), None, fine, 4, 2)
             close(from_cl(y), yr.detach(), tol, "convT fwd (split)")
-            dx = ops.conv3d(ops.CONVT_DGRAD, to_cl(dy, dt), ops.pack_weight(w.to(DEV), dt, True, True), None, so, 4, 2)
+            dx = ops.conv3d(ops.CONVT_DGRAD, to_cl(dy, dt), ops.pack_weight(w.to(DEV), dt, True, True, f32_split=True), None, so, 4, 2)
             close(from_cl(dx), xr.grad, tol, "convT dgrad (split)")
-            dwp = ops.conv3d_wgrad(ops.CONVT_FWD, to_cl(x, dt), to_cl(dy, dt), 4, 2)
+            dwp = ops.conv3d_wgrad(ops.CONVT_FWD, to_cl(x, dt), to_cl(dy, dt), 4, 2, f32_split=True)
             dw = torch.zeros_like(w, device=DEV)
             ops.unpack_grad(dwp, dw, transposed_conv=True, accumulate=False)
             close(dw.cpu(), wr.grad, tol, "convT wgrad (split)")
@@ -387,23 +386,21 @@ def test_conv_f32_split_products(ops, case, sparse):
             yr = yr * mo
         yr.backward(dy)
         bs_in = bs_out + (1 if s == 2 else 0)
-        y = ops.conv3d(ops.CONV_FWD, to_cl(x, dt), ops.pack_weight(w.to(DEV), dt, False, False), bias.to(DEV), so, k, s,
+        y = ops.conv3d(ops.CONV_FWD, to_cl(x, dt), ops.pack_weight(w.to(DEV), dt, False, False, f32_split=True), bias.to(DEV), so, k, s,
                        in_mask=mi, in_bshift=bs_in, out_mask=mi, out_bshift=bs_out)
         close(from_cl(y), yr.detach(), tol, "conv fwd (split)", mo)
-        dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dt), ops.pack_weight(w.to(DEV), dt, False, True), None, si, k, s,
+        dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dt), ops.pack_weight(w.to(DEV), dt, False, True, f32_split=True), None, si, k, s,
                         in_mask=mi, in_bshift=bs_out, out_mask=mi, out_bshift=bs_in)
         close(from_cl(dx), xr.grad, tol, "conv dgrad (split)", mi_in)
         for det in (False, True):
             ops.DETERMINISTIC_WGRAD = det
             try:
-                dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dt), to_cl(dy, dt), k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out)
+                dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dt), to_cl(dy, dt), k, s, x_mask=mi, x_bshift=bs_in, y_mask=mi, y_bshift=bs_out, f32_split=True)
             finally:
                 ops.DETERMINISTIC_WGRAD = False
             dw = torch.zeros_like(w, device=DEV)
             ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
             close(dw.cpu(), wr.grad, tol, f"conv wgrad (split, det={det})")
-    finally:
-        ops.F32_SPLIT = False
 
 
 def test_split_bf16_planes(ops):
@@ -450,6 +447,27 @@ def test_conv_k3_persistent_kernel_fwd_dgrad_stats(ops, case):
     # data gradient (the weight tap index is mirrored, the packed weight transposed)
     dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), ops.pack_weight(wd, dtype, False, True), None, S, 3, 1)
     close(from_cl(dx), xr.grad, TOL[dtype], "conv_k3 dgrad")
+
+
+def test_conv_k3_sample_index_beyond_the_packed_field(ops):
+    """conv_k3_kernel packs the sample index and the brick indices of a unit into 8-bit fields; B >= 256 (many small 16^3 maps: >= 256
+    units, so the shape qualifies otherwise) must not alias the sample index into the channel-tile field -- such launches go to
+    conv_igemm.hip.  Forward and data gradient of samples 0, 255, 256, 299 against F.conv3d; B = 255 still takes the persistent kernel."""
+    dtype = torch.bfloat16
+    cin, cout, S = 64, 64, (16, 16, 16)
+    w = q(rnd(cout, cin, 3, 3, 3, seed=172, scale=1.0 / np.sqrt(cin * 27)), dtype)
+    wd = w.to(DEV)
+    for B, k3 in ((300, False), (255, True)):
+        x = q(rnd(B, cin, *S, seed=171), dtype)
+        y, part = ops.conv3d(ops.CONV_FWD, to_cl(x, dtype), ops.pack_weight(wd, dtype, False, False), None, S, 3, 1, want_partials=True)
+        assert (part.rows == 8 * 256) == k3, "which kernel served the launch (conv_k3_kernel writes 8 rows per workgroup)"
+        dy = q(rnd(B, cout, *S, seed=173), dtype)
+        dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), ops.pack_weight(wd, dtype, False, True), None, S, 3, 1)
+        pick = [0, 1, B // 2, 254, B - 1] + ([255, 256] if B > 256 else [])
+        yr = F.conv3d(x[pick], w, None, padding=1)
+        close(from_cl(y[pick]), yr, TOL[dtype], f"k3 fwd B={B}")
+        dxr = F.conv_transpose3d(dy[pick], w, None, padding=1)     # data gradient of a k3 s1 conv = the transposed conv of dy
+        close(from_cl(dx[pick]), dxr, TOL[dtype], f"k3 dgrad B={B}")
 
 
 def test_conv_k3_persistent_kernel_fused_epilogue(ops):
