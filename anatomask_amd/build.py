@@ -10,6 +10,26 @@ SOURCES = ["conv_igemm.hip", "conv_k3.hip", "conv_rw.hip", "conv_gather.hip", "c
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
+def source_digest(ablate: bool = False) -> str:
+    """sha256 over everything the library is made of: the .hip sources, the three headers and the compiler flags.  `build` writes it to
+    <library>.stamp; the loader (hip.HipLib) recomputes it from the sources lying next to the library and refuses a binary that was
+    not built from them -- a prebuilt .so that travelled to a GPU box proves itself against the source that travelled with it."""
+    import hashlib
+    h = hashlib.sha256()
+    flags = FLAGS + (["-DAM_ABLATE"] if ablate else [])
+    h.update(" ".join(flags).encode())
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_plan.h"),
+                                                          os.path.join(os.path.dirname(HERE), "include", "anatomask_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def stamp_path(lib_path: str) -> str:
+    return lib_path + ".stamp"
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -39,11 +59,15 @@ def build(force: bool = False, verbose: bool = True, ablate: bool = False) -> st
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    if force or procs or _stale(out, objs):
+    digest = source_digest(ablate)
+    stamped = os.path.exists(stamp_path(out)) and open(stamp_path(out)).read().strip() == digest
+    if force or procs or _stale(out, objs) or not stamped:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(stamp_path(out), "w") as fh:
+            fh.write(digest + "\n")
     return out
 
 

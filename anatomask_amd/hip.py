@@ -42,6 +42,14 @@ class HipLib:
         # loading our library first would bring in a second runtime that knows nothing of torch's streams/allocations
         if not os.path.exists(path):
             raise RuntimeError(f"{path} not built: run `python -m anatomask_amd.build` (no fallback path exists)")
+        if os.path.abspath(path) == LIB_PATH:
+            # the product library must be the build of the sources lying next to it (build.py writes their digest beside the .so)
+            from . import build as _b
+            sp = _b.stamp_path(path)
+            have = open(sp).read().strip() if os.path.exists(sp) else None
+            if have != _b.source_digest():
+                raise RuntimeError(f"{path} was not built from the csrc/ + include/ sources next to it (stamp {str(have)[:12]}.. != sources "
+                                   f"{_b.source_digest()[:12]}..): run `python -m anatomask_amd.build`")
         self._lib = C.CDLL(path)
         self.functions = declared_functions()
         for name, argtypes in self.functions.items():

@@ -16,7 +16,29 @@ from . import engine, ops
 from .modules import ModelEma, SparK, ema_decay_for_epoch
 
 
+class _Range:
+    """roctx range around a phase of the step (torch.cuda.nvtx IS roctx on ROCm): `rocprofv3 --marker-trace` shows teacher / sampler /
+    student / backward / exchange / optimizer as named spans.  Off unless AnatoMaskTrainer.trace_ranges is set (tools/): a push / pop pair
+    per phase is host work the launch-bound configurations should not pay by default."""
+    __slots__ = ("on",)
+
+    def __init__(self, on: bool, name: str):
+        self.on = on
+        if on:
+            torch.cuda.nvtx.range_push(name)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 class AnatoMaskTrainer:
+    trace_ranges = False          # roctx ranges around the phases of step() (see _Range)
+
     def __init__(self, model: SparK, lr: float = 1e-4, weight_decay: float = 1e-5, betas=(0.9, 0.999), eps: float = 1e-8,
                  clip: float = 12.0, ema_decay: float = 0.999, total_epochs: int = 1000, guide: bool = True, seed: int = 4321,
                  process_group=None, distributed: Optional[bool] = None, self_distill: bool = True, deterministic_wgrad: bool = False,
@@ -123,30 +145,79 @@ class AnatoMaskTrainer:
         if sum(d - c for c, d in self._pending) * 4 >= self.FLUSH_BYTES:
             self._flush()
 
+    _COMM: Dict[int, "torch.cuda.Stream"] = {}     # per device: the stream the collectives are issued from (nothing else ever runs there)
+    _pieces = None                                  # timeline of the current step's collectives (exchange_timeline)
+    _t_begin = None
+
+    @classmethod
+    def _comm_stream(cls, dev) -> "torch.cuda.Stream":
+        i = dev.index if dev.index is not None else torch.cuda.current_device()
+        if i not in cls._COMM:
+            cls._COMM[i] = torch.cuda.Stream(device=dev)
+        return cls._COMM[i]
+
+    def _exchange_begin(self):
+        """start of a step's backward: the origin of the exchange timeline."""
+        import time
+        self.exchange_log.clear()
+        self._pieces, self._t_end = [], None
+        g = self.model._gflat
+        if g.is_cuda:
+            self._t_begin = torch.cuda.Event(enable_timing=True)
+            self._t_begin.record()
+        else:
+            self._t_begin = time.perf_counter()
+
     def _flush(self):
-        """async all-reduce(SUM) of every pending range, in pieces of at most BUCKET_BYTES.  On the GPU the collectives are issued from
-        the side stream's context: RCCL's stream then waits for the weight-gradient kernels that run THERE (and, through the event,
-        for the main stream up to this point) while the main stream goes on with backward un-joined."""
+        """async all-reduce(SUM) of every pending range, in pieces of at most BUCKET_BYTES.  On the GPU the collectives are issued from a
+        DEDICATED third stream that waits for (an event on the main stream, an event on the weight-gradient side stream) -- what has
+        been enqueued on both up to this point is exactly what the pending ranges need -- so RCCL's kernels never queue behind the
+        persistent weight-gradient grids that are launched on the side stream AFTER this point, and the main stream goes on with backward
+        un-joined.  Every piece carries an event pair (eligible to start, finished) on that stream: exchange_timeline()."""
         if not self._pending:
             return
+        import time
         if not self.exchange_log:
             self.first_sent_tag = getattr(self, "_last_tag", None)        # how early in backward the exchange starts (bench.py `exchange`)
+        if self._pieces is None:
+            self._exchange_begin()
         g = self.model._gflat
+        cuda = g.is_cuda
+        stream_wait = cuda and dist.get_backend(self.pg) == "nccl"       # RCCL: Work.wait() is a stream-level wait (the host does not block)
         ctx = None
-        if g.is_cuda and engine._USE_SIDE:
-            side = engine._side_stream(g.device)
+        if cuda:
+            comm = self._comm_stream(g.device)
             ev = torch.cuda.Event()
             ev.record()
-            side.wait_event(ev)
-            ctx = torch.cuda.stream(side)
+            comm.wait_event(ev)
+            if engine._USE_SIDE:
+                ev2 = torch.cuda.Event()
+                ev2.record(engine._side_stream(g.device))
+                comm.wait_event(ev2)
+            ctx = torch.cuda.stream(comm)
             ctx.__enter__()
         try:
             for a, b in sorted(self._pending, reverse=True):
                 npiece = max(1, -(-(b - a) * 4 // self.BUCKET_BYTES))
                 step = ((b - a + npiece - 1) // npiece + 3) // 4 * 4
                 for c in range(a, b, step):
-                    self._works.append(dist.all_reduce(g[c:min(c + step, b)], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-                    self.exchange_log.append((c, min(c + step, b)))
+                    d = min(c + step, b)
+                    rec = {"range": (c, d), "bytes": (d - c) * 4}
+                    if cuda:
+                        rec["e0"] = torch.cuda.Event(enable_timing=True)
+                        rec["e0"].record()
+                    else:
+                        rec["t0"] = time.perf_counter()
+                    w = dist.all_reduce(g[c:d], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    if stream_wait:
+                        w.wait()                                         # the comm stream waits for RCCL's stream; the main stream does not
+                        rec["e1"] = torch.cuda.Event(enable_timing=True)
+                        rec["e1"].record()
+                    else:
+                        rec["work"] = w
+                        self._works.append(w)
+                    self._pieces.append(rec)
+                    self.exchange_log.append((c, d))
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
@@ -155,10 +226,46 @@ class AnatoMaskTrainer:
     def _finish_exchange(self):
         if not self.distributed:
             return
+        import time
         self._flush()
-        for w in self._works:
-            w.wait()
-        self._works.clear()                        # the buffer now holds the SUM over ranks; 1/world is folded into am_adamw_ema
+        g = self.model._gflat
+        if g.is_cuda:
+            self._t_end = torch.cuda.Event(enable_timing=True)            # the main stream has enqueued all of backward: what it waits for
+            self._t_end.record()                                          # from here on is exposed communication
+        else:
+            self._t_end = time.perf_counter()
+        for rec in self._pieces or []:                                    # gloo (tests): Work.wait() blocks the host
+            if "work" in rec:
+                rec.pop("work").wait()
+                rec["t1"] = time.perf_counter()
+        self._works.clear()
+        if g.is_cuda:                                                     # RCCL: the main stream joins the comm stream once
+            ev = torch.cuda.Event()
+            ev.record(self._comm_stream(g.device))
+            torch.cuda.current_stream().wait_event(ev)
+        # the buffer now holds the SUM over ranks; 1/world is folded into am_adamw_ema
+
+    def exchange_timeline(self) -> Dict:
+        """The last step's collectives: per piece [issue_ms, done_ms] from the start of backward (issue = the piece's gradients were final
+        on both streams and it was handed to RCCL; done = its result was in the buffer), where backward ended on the main stream, and the
+        communication left exposed behind it.  Synchronises the device (bench / tests only)."""
+        if not self._pieces:
+            return {"pieces": [], "backward_end_ms": None, "exposed_ms": 0.0}
+        cuda = self.model._gflat.is_cuda
+        if cuda:
+            torch.cuda.synchronize()
+        out = []
+        for rec in self._pieces:
+            if "e1" in rec:
+                t0, t1 = self._t_begin.elapsed_time(rec["e0"]), self._t_begin.elapsed_time(rec["e1"])
+            elif cuda:                                                    # gloo over device tensors: issue on the device clock, done on the host's
+                t0 = self._t_begin.elapsed_time(rec["e0"]); t1 = None
+            else:
+                t0, t1 = (rec["t0"] - self._t_begin) * 1e3, (rec["t1"] - self._t_begin) * 1e3
+            out.append({"bytes": rec["bytes"], "issue_ms": round(t0, 3), "done_ms": None if t1 is None else round(t1, 3)})
+        end = self._t_begin.elapsed_time(self._t_end) if cuda else (self._t_end - self._t_begin) * 1e3
+        dones = [p["done_ms"] for p in out if p["done_ms"] is not None]
+        return {"pieces": out, "backward_end_ms": round(end, 3), "exposed_ms": round(max(0.0, max(dones) - end), 3) if dones else None}
 
     @property
     def grad_scale(self) -> float:
@@ -184,33 +291,40 @@ class AnatoMaskTrainer:
         else:
             m1 = mask1.reshape(B, L).to(device=dev, dtype=torch.uint8).contiguous()
         mi1 = ops.MaskInfo(m1.view(B, *spec.fmap), n_active=B * m.len_keep if mask1 is None else None)
+        tr_ = self.trace_ranges
         if self.self_distill:
             # 2. teacher pass + raw per-patch loss (:421-425)
             # (only the masked patches' teacher loss is used: the last decoder conv skips the visible 40 % of the volume)
-            need = ops.MaskInfo((1 - m1).view(B, *spec.fmap), n_active=B * (L - m.len_keep) if mask1 is None else None) if spec.input_size[0] // spec.fmap[0] == 16 else None
-            rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False, needed_patches=need)
-            recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
-            del rec1
+            with _Range(tr_, "anatomask.teacher_forward"):
+                need = ops.MaskInfo((1 - m1).view(B, *spec.fmap), n_active=B * (L - m.len_keep) if mask1 is None else None) if spec.input_size[0] // spec.fmap[0] == 16 else None
+                rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False, needed_patches=need)
+                recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
+                del rec1
             # 3. hard-mask sampler (:427)
-            ll = m.len_loss_for(L, m.len_keep, epoch, self.total_epochs - 1, self.guide)
-            if keys is None:
-                keys = torch.rand(B, L, device=dev, generator=self.gen)
-            mk = ops.mask_sampler(recon, keys.to(dev).float().contiguous(), m.len_keep, ll)
-            mi = ops.MaskInfo(mk.view(B, *spec.fmap), n_active=B * m.len_keep)      # the sampler leaves exactly len_keep visible per sample
+            with _Range(tr_, "anatomask.mask_sampler"):
+                ll = m.len_loss_for(L, m.len_keep, epoch, self.total_epochs - 1, self.guide)
+                if keys is None:
+                    keys = torch.rand(B, L, device=dev, generator=self.gen)
+                mk = ops.mask_sampler(recon, keys.to(dev).float().contiguous(), m.len_keep, ll)
+                mi = ops.MaskInfo(mk.view(B, *spec.fmap), n_active=B * m.len_keep)      # the sampler leaves exactly len_keep visible per sample
         else:                                                     # plain SparK: the random mask IS the student mask
             recon, mk, mi = None, m1, mi1
         # 4. student forward + loss (:429-430)
         self._snap_b.copy_(m._bflat); self._snap_i.copy_(m._iflat)   # (what a step that turns out non-finite must not have changed)
         tape = engine.Tape()
-        rec = engine.forward(spec, m._W, m._pack, x, mi, train=True, tape=tape, recompute=m.recompute)
-        l2m, pm, pr, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
-        drec = ops.patch_loss_bwd(x, rec, mi, pm, pr, info, None)
+        with _Range(tr_, "anatomask.student_forward"):
+            rec = engine.forward(spec, m._W, m._pack, x, mi, train=True, tape=tape, recompute=m.recompute)
+            l2m, pm, pr, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
+            drec = ops.patch_loss_bwd(x, rec, mi, pm, pr, info, None)
         # 5. backward (:435) with overlapped gradient exchange
-        m._gflat.zero_()
-        self.exchange_log.clear()
-        engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group if self.distributed else None, join_before_hook=False)
-        del tape
-        self._finish_exchange()
+        with _Range(tr_, "anatomask.backward"):
+            m._gflat.zero_()
+            self._exchange_begin()
+            engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group if self.distributed else None, join_before_hook=False)
+            del tape
+        with _Range(tr_, "anatomask.exchange_wait"):
+            self._finish_exchange()
+        rng_opt = _Range(tr_, "anatomask.optimizer_ema")
         # 6. clip + AdamW + EMA (:437-440), one pass over the live parameters
         n = m._live_end
         decay = self.teacher.decay if ema_decay is None else ema_decay
@@ -227,6 +341,7 @@ class AnatoMaskTrainer:
         ops.guard_restore(m._iflat, self._snap_i, self.guard)
         if not self.self_distill:
             m.weights_changed()
+            rng_opt.__exit__()
             return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": None, "rec_loss": l2m}
         if m._flat.numel() > n:                                   # dead densify[4] tensors: EMA only (no optimizer step)
             ops.ema(t._flat[n:], m._flat[n:], decay, self.guard)
@@ -234,6 +349,7 @@ class AnatoMaskTrainer:
         if m._n_ibuf:                                             # ... and the int64 num_batches_tracked, with timm's float32 promotion
             ops.ema_i64(t._iflat[:m._n_ibuf], m._iflat[:m._n_ibuf], decay, self.guard)
         m.weights_changed(); t.weights_changed()
+        rng_opt.__exit__()
         return {"loss": info[0:1], "grad_norm": self.gnorm, "mask": mk, "recon_loss": recon, "rec_loss": l2m}
 
     # ------------------------------------------------------------------ hipGraph replay of the step (launch-bound configurations)

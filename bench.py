@@ -237,7 +237,8 @@ def secondary_lines(a, kw, dev, dtype_main):
 def exchange_report(tr, grad_elems, world, dt, dtn, steps, backend):
     """`exchange` of the JSON line (N > 1): what was sent per step and what it cost (step time with the exchange off -> exposed ms)."""
     sizes = [(b - a) * 4 for a, b in tr.exchange_log]
-    return {"backend": backend, "ranks": world, "gradient_bytes_per_step": int(grad_elems) * 4, "collectives_per_step": len(sizes),
+    tl = tr.exchange_timeline()                              # the LAST step's collectives: [issue_ms, done_ms] per piece from the start of backward
+    return {"timeline": tl, "exposed_ms_last_step": tl["exposed_ms"], "backend": backend, "ranks": world, "gradient_bytes_per_step": int(grad_elems) * 4, "collectives_per_step": len(sizes),
             "largest_collective_bytes": max(sizes) if sizes else 0, "first_collective_after_tag": getattr(tr, "first_sent_tag", None),
             "ms_per_step_without_exchange": round(dtn / steps * 1e3, 3), "exposed_ms": round((dt - dtn) / steps * 1e3, 3)}
 
@@ -317,13 +318,14 @@ def dry_run_launch(a):
     m.spec = Spec(kw["dims"], kw["depth"], kw["width"], (48, 48, 48))
     tr = AnatoMaskTrainer.__new__(AnatoMaskTrainer)
     tr.model, tr.distributed, tr.pg, tr.world, tr._works, tr.exchange_log = m, True, None, world, [], []
+    tr._pieces = tr._t_begin = tr._t_end = None
     tr.BUCKET_BYTES, tr.FLUSH_BYTES = 8 << 20, 4 << 20
     tr._build_ranges()
     tags = ["proj"] + [f"dec{i}" for i in reversed(range(4))] + ["densify"] + [f"stage{s}.0" for s in reversed(range(5))]
 
     def step():
         m._gflat[:m._live_end] = float(rank + 1)
-        tr.exchange_log.clear()
+        tr._exchange_begin()
         for t in tags:
             tr._after_group(t)
         tr._finish_exchange()

@@ -21,3 +21,23 @@ def test_binding_fails_loudly_without_library(tmp_path):
     import pytest
     with pytest.raises(RuntimeError):
         hip.HipLib(str(tmp_path / "missing.so"))
+
+
+def test_loader_refuses_a_library_not_built_from_the_sources_next_to_it():
+    """build.py stamps the library with the sha256 of its sources + flags; hip.HipLib recomputes it: a prebuilt binary that travelled to
+    another box proves itself against the source that travelled with it, a stale one is refused."""
+    import pytest
+    path = build.build(verbose=False)
+    sp = build.stamp_path(path)
+    good = open(sp).read()
+    assert good.strip() == build.source_digest()
+    hip.HipLib(path)
+    try:
+        with open(sp, "w") as fh:
+            fh.write("0" * 64 + "\n")
+        with pytest.raises(RuntimeError, match="was not built from"):
+            hip.HipLib(path)
+    finally:
+        with open(sp, "w") as fh:
+            fh.write(good)
+    hip.HipLib(path)

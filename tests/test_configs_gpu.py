@@ -206,6 +206,60 @@ def test_config2_stunet_b_128_fp32_storage_step_vs_oracle(f32_split):
         assert float(np.median([r_[2] for r_ in rows])) <= 1.2e-2 and sum(r_[2] > F32_REL for r_ in rows) <= 3
 
 
+@functools.lru_cache(maxsize=None)
+def _oracle_step_recipe():
+    """ONE fp32 CPU oracle step of the reference's SHIPPED recipe shape: STUNet-B, input (112, 112, 128) (P/pretrain_AntoMask.py:188,209),
+    mask 0.6 (:215): feature map 7 x 7 x 8 = 392 patches, 157 visible; encoder grids 112/56/28/14/7 x ... x 128/64/32/16/8, decoder
+    grids 14 / 28 / 56 / 112 wide -- the ragged extents where the brick kernels run their tail / padding branches."""
+    cfg = O.Config.stunet_b((112, 112, 128), 0.6)
+    W0 = O.seeded_state(cfg, 6)
+    x = O.smooth_volume(1, cfg.input_size, 10)
+    g = torch.Generator().manual_seed(19)
+    mask1 = O.random_mask(cfg, 1, g)
+    keys = torch.rand(1, cfg.L, generator=g)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    st = O.StepState(cfg, W0)
+    o = O.train_step(st, x, mask1, keys, 0, 999, 1e-4, 0.999, return_grads=True)
+    return cfg, W0, x, mask1, keys, o
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32s", "bf16"])
+def test_reference_recipe_112x112x128_step_vs_oracle(mode):
+    """A full AnatoMask step on the reference's shipped recipe shape (P/pretrain_AntoMask.py:209,229,239: STUNet-B, 112 x 112 x 128, fp32)
+    against the CPU oracle's step on the same weights / volume / random draws -- the SAME assertions and bounds as the 128^3 tests
+    (test_config2_*): fp32 storage with exact products, fp32 storage with split-bf16 products, bf16 storage."""
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    cfg, W0, x, mask1, keys, o = _oracle_step_recipe()
+    assert (cfg.L, cfg.len_keep) == (392, 157)
+    dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+    m = _build(cfg, W0, dtype=dtype)
+    tr = AnatoMaskTrainer(m, lr=1e-4, ema_decay=0.999, total_epochs=1000, distributed=False, f32_split=mode == "f32s")
+    out = tr.step(x.to(DEV), epoch=0, mask1=mask1, keys=keys)
+    torch.cuda.synchronize()
+    assert torch.equal(out["mask"].view(1, -1).bool().cpu(), o["mask"].view(1, -1))
+    rec_h, rec_o = out["recon_loss"].cpu().numpy(), o["recon_loss"].numpy()
+    print("recipe 112x112x128 %s vs oracle fp32: loss %.7f / %.7f  grad-norm %.6f / %.6f  teacher-l2 rel err %.2e"
+          % (mode, out["loss"].item(), o["loss"], out["grad_norm"].item(), o["grad_norm"], np.abs(rec_h - rec_o).max() / rec_o.max()))
+    what = f"recipe 112x112x128 {mode}"
+    if mode == "bf16":
+        assert np.abs(rec_h - rec_o).max() < BF16_L2 * rec_o.max()
+        assert abs(out["loss"].item() - o["loss"]) < BF16_LOSS * o["loss"]
+        assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < BF16_GNORM
+        rows = _per_tensor_errors(m, o["grads"], what + " storage vs fp32 oracle")
+        _check_bf16_rows(rows, _emulated_bf16_grads(cfg, W0, x, o["mask"]), m, o["grads"], what)
+    else:
+        split = mode == "f32s"
+        assert np.abs(rec_h - rec_o).max() < (2e-5 if split else F32_L2) * rec_o.max()
+        assert abs(out["loss"].item() - o["loss"]) < (1e-5 if split else F32_LOSS) * o["loss"]
+        assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < F32_GNORM
+        rows = _per_tensor_errors(m, o["grads"], what + " storage")
+        for k, n_el, rel, cos in rows:
+            assert rel <= (2.5e-2 if split else F32_REL) and cos >= (0.9995 if split else 1 - F32_REL), (k, n_el, rel, cos)
+    # a second step in the hard-mask regime: sampler / dead-gradient / finiteness properties on the 7 x 7 x 8 patch grid
+    out2 = tr.step(x.to(DEV), epoch=500)
+    _step_properties(tr, cfg, out2, 1, 500, 999)
+
+
 def _student_step_vs_oracle(size, patch, mask_ratio, recompute, seed):
     """Plain-SparK step (teacher-forced mask, no teacher) of a large-model SHAPE at a reduced patch against the oracle's autograd --
     the kernel paths only STUNet-L/H reach (depth 2/3 identity-shortcut blocks, 64..1536 channels, one-voxel patches at level 4,

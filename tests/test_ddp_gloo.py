@@ -37,6 +37,7 @@ def _worker(rank, world, port, q):
         m._gflat = torch.zeros(tot)
         tr = AnatoMaskTrainer.__new__(AnatoMaskTrainer)
         tr.model, tr.distributed, tr.pg, tr.world, tr._works, tr.exchange_log = m, True, None, world, [], []
+        tr._pieces = tr._t_begin = tr._t_end = None
         tr.BUCKET_BYTES, tr.FLUSH_BYTES = 256 << 10, 96 << 10     # small limits so that this 3 M-parameter model splits and merges
         from anatomask_amd.engine import Spec
         m.spec = Spec([8, 16, 32, 64, 128, 128], [1] * 6, 128, (32, 48, 64))

@@ -438,6 +438,15 @@ def test_trainer_distributed_path_single_rank_nccl():
             outs.append((o["loss"].item(), o["grad_norm"].item()))
         assert abs(outs[0][0] - outs[1][0]) < 1e-6 and abs(outs[0][1] - outs[1][1]) < 1e-3 * outs[0][1], outs
         assert abs(outs[1][0] - r["losses"][0]) < 3e-4 * abs(r["losses"][0])
+        # the collectives were issued from the dedicated stream; every piece carries its (issue, done) event pair on the DEVICE clock
+        tl = tr.exchange_timeline()
+        assert len(tl["pieces"]) == len(tr.exchange_log) >= 1 and sum(p["bytes"] for p in tl["pieces"]) == m._live_end * 4
+        assert all(p["done_ms"] is not None and 0.0 <= p["issue_ms"] <= p["done_ms"] for p in tl["pieces"])
+        assert [p["issue_ms"] for p in tl["pieces"]] == sorted(p["issue_ms"] for p in tl["pieces"])
+        assert tl["backward_end_ms"] > 0 and tl["exposed_ms"] >= 0.0
+        from anatomask_amd import engine
+        comm = AnatoMaskTrainer._comm_stream(torch.device(DEV))
+        assert comm.cuda_stream not in (torch.cuda.current_stream().cuda_stream, engine._side_stream(torch.device(DEV)).cuda_stream)
     finally:
         dist.destroy_process_group()
 

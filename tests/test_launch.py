@@ -11,6 +11,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _check_timeline(ex):
+    """the per-collective record of the N > 1 JSON line (trainer.exchange_timeline): one [issue_ms, done_ms] pair per collective, measured
+    from the start of backward, issued in backward-completion order, every one done after it was issued, and the exposed remainder."""
+    tl = ex["timeline"]
+    pieces = tl["pieces"]
+    assert len(pieces) == ex["collectives_per_step"] and sum(p["bytes"] for p in pieces) == ex["gradient_bytes_per_step"]
+    issues = [p["issue_ms"] for p in pieces]
+    assert issues == sorted(issues) and issues[0] >= 0.0
+    assert all(p["done_ms"] is not None and p["done_ms"] >= p["issue_ms"] for p in pieces)
+    assert issues[0] <= tl["backward_end_ms"]                  # the exchange starts before backward has ended
+    assert tl["exposed_ms"] is not None and tl["exposed_ms"] >= 0.0 and ex["exposed_ms_last_step"] == tl["exposed_ms"]
+    assert abs(tl["exposed_ms"] - max(0.0, max(p["done_ms"] for p in pieces) - tl["backward_end_ms"])) < 2e-3
+
+
 @pytest.mark.timeout(180)
 def test_bench_self_launch_two_ranks_gloo():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
@@ -28,6 +42,7 @@ def test_bench_self_launch_two_ranks_gloo():
     assert ex["ranks"] == 2 and ex["backend"] == "gloo" and ex["gradient_bytes_per_step"] > 50e6          # STUNet-S: 13.3 M parameters
     assert ex["collectives_per_step"] >= 4 and ex["largest_collective_bytes"] <= 8 << 20
     assert ex["first_collective_after_tag"].startswith("dec") and ex["ms_per_step_without_exchange"] >= 0
+    _check_timeline(ex)
 
 
 @pytest.mark.timeout(400)
@@ -44,6 +59,7 @@ def test_bench_self_launch_eight_ranks_gloo():
     assert out["world"] == 8 and out["ranks_seen"] == 8 and out["rank_sum"] == 28.0 and out["mean_gradient_ok"]
     assert sorted(r_["rank"] for r_ in out["ranks"]) == list(range(8))
     assert out["exchange"]["ranks"] == 8 and out["exchange"]["collectives_per_step"] >= 4
+    _check_timeline(out["exchange"])
 
 
 def test_launch_command_and_noop_under_a_launcher(monkeypatch):
