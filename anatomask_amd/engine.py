@@ -258,7 +258,7 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
 
 
 def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, fuse_eval: bool = False, out_skip=None, sync: bool = False,
-               head: bool = False, inorm: bool = False):
+               head: bool = False, inorm: bool = False, stencil_tail: bool = False):
     """One UNetBlock (P/decoder3D.py:13-29) (+ the `x + to_dec[i+1]` of the next iteration, :59) -> (out, record).
     head (last block, train mode): the block's final BatchNorm feeds only the 1x1 projection, which applies it on the fly
     (ops.proj_fwd(pre=st2)) -- the block returns the BatchNorm's INPUT c2 and the normalised map is never written."""
@@ -281,6 +281,10 @@ def _dec_block(W, pk, i: int, x, nxt, train: bool, update_running: bool = True, 
         ops.norm_fold_running(st2, W[f"{q}.conv.4.weight"], W[f"{q}.conv.4.bias"], W[f"{q}.conv.4.running_mean"], W[f"{q}.conv.4.running_var"], 1e-5)
         r = ops.conv3d(CONV_FWD, u, pk.get(W, f"{q}.conv.0.weight", False, False), None, so, 3, 1,
                        ep_scale=st1.scale, ep_shift=st1.shift, ep_act=ACT_RELU6)
+        if stencil_tail and nxt is None and ops.head_stencil_supported(r):
+            # last block of an eval pass: conv2 -> BatchNorm(running statistics) -> projection is linear in r and is evaluated as one
+            # C -> 1 stencil on the needed patches (decoder_forward, ops.head_stencil); the block's output map never exists
+            return r, {"stencil": True, "st2": st2}
         # out_skip (last block of a loss-only teacher pass): patch mask of the output voxels anyone will read -- the rest of the
         # brick grid is not computed at all (P/pretrain_AntoMask.py:421-425 keeps the teacher's l2 of the MASKED patches only)
         o = ops.conv3d(CONV_FWD, r, pk.get(W, f"{q}.conv.3.weight", False, False), None, so, 3, 1,
@@ -340,9 +344,16 @@ def densify_forward(spec: Spec, W, pk: PackCache, feats, mask: MaskInfo, counts,
     return to_dec
 
 
+HEAD_STENCIL = True   # tools/step_ab.py engine.HEAD_STENCIL=1,0: the eval-mode tail conv -> BatchNorm -> projection as one C -> 1 stencil
+
+
 def decoder_forward(spec: Spec, W, pk: PackCache, to_dec, train: bool, tape: Optional[Tape] = None, recompute: bool = False,
-                    needed_patches: Optional[MaskInfo] = None, fuse_eval: Optional[bool] = None) -> torch.Tensor:
-    """LightDecoder.forward (P/decoder3D.py:55-63): x = 0; per block x += to_dec[i]; UNetBlock; 1x1 proj -> rec fp32 [B,D,H,W]."""
+                    needed_patches: Optional[MaskInfo] = None, fuse_eval: Optional[bool] = None, l2_of: Optional[tuple] = None) -> torch.Tensor:
+    """LightDecoder.forward (P/decoder3D.py:55-63): x = 0; per block x += to_dec[i]; UNetBlock; 1x1 proj -> rec fp32 [B,D,H,W].
+    needed_patches (eval passes without a tape): only these 16^3 patches of rec are defined.
+    l2_of = (inp fp32 [B,D,H,W], l2 fp32 [B,L]): where the eval-mode tail runs as the fused stencil (ops.head_stencil), the raw per-patch
+    l2 of the needed patches is written into l2 by the same kernel and None is returned instead of rec (the teacher pass,
+    P/pretrain_AntoMask.py:421-425, needs nothing else); otherwise rec is returned and l2 is left untouched."""
     n_dec = len(spec.dec_chs) - 1
     if fuse_eval is None:
         fuse_eval = tape is None
@@ -355,7 +366,22 @@ def decoder_forward(spec: Spec, W, pk: PackCache, to_dec, train: bool, tape: Opt
         last = i == n_dec - 1
         o, rec_ = _dec_block(W, pk, i, x, nxt, train, fuse_eval=fuse_eval,
                              out_skip=needed_patches if (last and tape is None and not train) else None, sync=spec.sync_bn,
-                             head=head and last, inorm=spec.dec_inorm)
+                             head=head and last, inorm=spec.dec_inorm,
+                             stencil_tail=bool(HEAD_STENCIL and last and tape is None and not train and fuse_eval and not spec.dec_inorm))
+        if rec_ is not None and rec_.get("stencil"):
+            q = f"{DEC}.{i}"
+            weff, beff = ops.head_fold(W[f"{q}.conv.3.weight"], rec_["st2"].scale, rec_["st2"].shift, W["dense_decoder.proj.weight"].view(-1),
+                                       W["dense_decoder.proj.bias"])
+            B_, D_, H_, W_ = o.shape[:4]
+            patches = needed_patches
+            if patches is None:                              # the whole volume: every patch is needed
+                patches = MaskInfo(torch.ones(B_, D_ // 16, H_ // 16, W_ // 16, device=o.device, dtype=torch.uint8), n_active=B_ * (D_ // 16) * (H_ // 16) * (W_ // 16))
+            if l2_of is not None:
+                ops.head_stencil(o, weff, beff, patches, inp=l2_of[0], l2=l2_of[1])
+                return None
+            rec = torch.empty(B_, D_, H_, W_, device=o.device, dtype=torch.float32)
+            ops.head_stencil(o, weff, beff, patches, rec=rec)
+            return rec
         if head and last:
             st_head = rec_["st2"]
         if tape is not None:
@@ -369,7 +395,7 @@ def decoder_forward(spec: Spec, W, pk: PackCache, to_dec, train: bool, tape: Opt
 
 def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Tensor, mask: MaskInfo, train: bool,
             tape: Optional[Tape] = None, want_feats: bool = False, encoder_only: bool = False, recompute: bool = False,
-            want_to_dec0: bool = False, needed_patches: Optional[MaskInfo] = None):
+            want_to_dec0: bool = False, needed_patches: Optional[MaskInfo] = None, l2_out: Optional[torch.Tensor] = None):
     """inp: fp32 [B,D,H,W] (single channel).  Returns rec fp32 [B,D,H,W] (and the 5 encoder maps).
     recompute=True is the P/GC.py policy (torch.utils.checkpoint per encoder stage :324 and per decoder block :68): the tape
     keeps only stage / block INPUTS; backward re-runs that stage's forward before differentiating it."""
@@ -381,7 +407,7 @@ def forward(spec: Spec, W: Dict[str, torch.Tensor], pk: PackCache, inp: torch.Te
     if encoder_only:
         return feats
     to_dec = densify_forward(spec, W, pk, feats, mask, counts, tape)
-    rec = decoder_forward(spec, W, pk, to_dec, train, tape, recompute, needed_patches)
+    rec = decoder_forward(spec, W, pk, to_dec, train, tape, recompute, needed_patches, l2_of=(inp, l2_out) if l2_out is not None else None)
     if want_to_dec0:                         # coarsest densified map, channels-last (SparK.forward(return_feat=True), P/AnatoMask.py:172-173)
         return rec, to_dec[0]
     return (rec, feats) if want_feats else rec

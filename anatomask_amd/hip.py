@@ -37,6 +37,8 @@ def declared_functions(header: str = HEADER):
 
 
 class HipLib:
+    ANSWERS = ("am_head_stencil_supported", "am_version")     # entry points whose return value is an answer, not an error code: call them on ._lib
+
     def __init__(self, path: str = LIB_PATH):
         import torch  # noqa: F401  torch's bundled HIP runtime must be the one in the process (same soname as /opt/rocm's):
         # loading our library first would bring in a second runtime that knows nothing of torch's streams/allocations
@@ -56,7 +58,8 @@ class HipLib:
             fn = getattr(self._lib, name)       # AttributeError if the .so lacks a declared symbol
             fn.argtypes = argtypes
             fn.restype = C.c_int
-            setattr(self, name[3:], self._wrap(name, fn))
+            if name not in self.ANSWERS:
+                setattr(self, name[3:], self._wrap(name, fn))
 
     @staticmethod
     def _wrap(name, fn):

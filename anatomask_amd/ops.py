@@ -551,6 +551,36 @@ def proj_bwd(x: torch.Tensor, drec: torch.Tensor, w: torch.Tensor, dw_accum: tor
     return dx
 
 
+def head_stencil_supported(x: torch.Tensor) -> bool:
+    """am_head_stencil serves this channels-last tensor (16^3 patches of a [B,D,H,W,C] map, C in {32, 64, 128, 192})."""
+    B, D, H, W, C = x.shape
+    ok = hip.lib()._lib.am_head_stencil_supported(_dt(x), C) == 1
+    return bool(ok and D % 16 == 0 and H % 16 == 0 and W % 16 == 0 and max(B, D // 16, H // 16, W // 16) <= 255)
+
+
+def head_fold(w2: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, wproj: torch.Tensor, bproj: torch.Tensor):
+    """conv3x3x3 (Cmid, Cin, 3, 3, 3; no bias) -> eval BatchNorm (scale, shift) -> 1x1 projection, folded into (W_eff [27, Cin], b_eff [1])."""
+    cmid, cin = w2.shape[0], w2.shape[1]
+    assert tuple(w2.shape[2:]) == (3, 3, 3) and w2.is_contiguous() and wproj.numel() == cmid
+    weff = torch.empty(27, cin, device=w2.device, dtype=torch.float32)
+    beff = torch.empty(1, device=w2.device, dtype=torch.float32)
+    hip.lib().head_fold(w2.data_ptr(), cmid, cin, scale.data_ptr(), shift.data_ptr(), wproj.data_ptr(), bproj.data_ptr(), weff.data_ptr(),
+                        beff.data_ptr(), _stream())
+    return weff, beff
+
+
+def head_stencil(r: torch.Tensor, weff: torch.Tensor, beff: torch.Tensor, patches: MaskInfo, rec: Optional[torch.Tensor] = None,
+                 inp: Optional[torch.Tensor] = None, l2: Optional[torch.Tensor] = None):
+    """rec[q] = b_eff + sum_t W_eff[t] . r[q + t] on the ACTIVE 16^3 patches of `patches` (fp32 [B,D,H,W], other patches untouched) and / or
+    their raw per-patch l2 against inp (fp32 [B, L] entries of those patches)."""
+    B, D, H, W, C = r.shape
+    lst, n = patches.active_list()
+    assert lst is not None and (patches.fd, patches.fh, patches.fw) == (D // 16, H // 16, W // 16) and r.is_contiguous()
+    assert rec is None or (rec.dtype == torch.float32 and tuple(rec.shape) == (B, D, H, W) and rec.is_contiguous())
+    assert l2 is None or (inp is not None and l2.dtype == torch.float32 and l2.numel() == B * patches.fd * patches.fh * patches.fw)
+    hip.lib().head_stencil(_dt(r), r.data_ptr(), B, D, H, W, C, weff.data_ptr(), beff.data_ptr(), lst.data_ptr(), n, _p(rec), _p(inp), _p(l2), _stream())
+
+
 def patch_loss_fwd(inp: torch.Tensor, rec: torch.Tensor, mask: MaskInfo, normalized: bool, want_loss: bool = True):
     """inp/rec fp32 [B,D,H,W] -> (l2m [B,L], pmean, prstd, lossinfo[2] or None)."""
     B, D, H, W = inp.shape

@@ -297,8 +297,11 @@ class AnatoMaskTrainer:
             # (only the masked patches' teacher loss is used: the last decoder conv skips the visible 40 % of the volume)
             with _Range(tr_, "anatomask.teacher_forward"):
                 need = ops.MaskInfo((1 - m1).view(B, *spec.fmap), n_active=B * (L - m.len_keep) if mask1 is None else None) if spec.input_size[0] // spec.fmap[0] == 16 else None
-                rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False, needed_patches=need)
-                recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
+                # (STUNet-B / L / H: the decoder's eval-mode tail and the per-patch l2 are ONE stencil kernel, ops.head_stencil -- rec1 never exists)
+                recon = torch.zeros(B, L, device=dev) if need is not None else None
+                rec1 = engine.forward(spec, t._W, t._pack, x, mi1, train=False, needed_patches=need, l2_out=recon)
+                if rec1 is not None:
+                    recon, _, _, _ = ops.patch_loss_fwd(x, rec1, mi1, normalized=False, want_loss=False)
                 del rec1
             # 3. hard-mask sampler (:427)
             with _Range(tr_, "anatomask.mask_sampler"):
@@ -414,7 +417,9 @@ class AnatoMaskTrainer:
             mi = ops.MaskInfo(mk.view(B, *spec.fmap), n_active=B * m.len_keep)
         else:
             mi = ops.MaskInfo(mask.reshape(B, *spec.fmap).to(device=x.device, dtype=torch.uint8).contiguous())
-        rec = engine.forward(spec, m._W, m._pack, x, mi, train=False)
+        # (the normalised loss reads rec on the masked patches only: the eval-mode tail is evaluated there)
+        need = ops.MaskInfo((1 - mi.t).contiguous(), n_active=(B * (L - m.len_keep)) if mask is None else None) if spec.input_size[0] // spec.fmap[0] == 16 else None
+        rec = engine.forward(spec, m._W, m._pack, x, mi, train=False, needed_patches=need)
         _, _, _, info = ops.patch_loss_fwd(x, rec, mi, normalized=True)
         return info[0:1]
 

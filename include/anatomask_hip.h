@@ -207,6 +207,23 @@ int am_chan_sum(int dtype, const void* x, int B, int D, int H, int W, int C, con
                 int fw, float* out_accum, void* stream);   /* conv bias gradients */
 int am_add(int dtype, const void* a, const void* b, void* y, long n_elems, void* stream);   /* x + to_dec[i], P/decoder3D.py:59 */
 
+/* The decoder's tail in EVAL mode as ONE C -> 1 stencil (the EMA teacher's pass, P/pretrain_AntoMask.py:421-425, and the validation pass
+ * of P/pretrain.py:426-441): the last UNetBlock ends conv3x3x3(C -> Cmid, no bias) -> BatchNorm3d(running statistics) -> Conv3d(Cmid -> 1, k1)
+ * (P/decoder3D.py:20-22,51,61), which without batch statistics is linear in the block's ReLU6 output r:
+ *   rec[q] = b_eff + sum_t sum_ci W_eff[t][ci] r[q + t][ci],  W_eff[t][ci] = sum_c w_proj[c] scale[c] W2[c][ci][t],  b_eff = b_proj + sum_c w_proj[c] shift[c]
+ * am_head_fold: w2 = the conv's torch-layout weight (Cmid, Cin, 3, 3, 3), scale / shift = the folded BatchNorm (am_norm_fold_running)
+ * -> weff fp32 [27][Cin], beff fp32 [1].  am_head_stencil: r channels-last [B][D][H][W][C] (bf16: W_eff enters as hi + lo bf16 parts, fp32
+ * accumulation; fp32 storage, either product mode: exact fp32 products), evaluated on the 16^3 patches of patch_list (am_mask_compact
+ * entries) only; rec fp32 [B][D][H][W] (NULL: not written; other patches untouched); l2 (NULL or fp32 [B][fd*fh*fw]): the raw per-patch
+ * mean((rec - inp)^2) of the listed patches (inp fp32 [B][D][H][W]); entries of other patches untouched.
+ * am_head_stencil_supported(dtype, C) -> 1 / 0 (the one entry point whose return value is an answer, not an error code). */
+int am_head_fold(const float* w2, int cmid, int cin, const float* scale, const float* shift, const float* wproj, const float* bproj,
+                 float* weff, float* beff, void* stream);
+int am_head_stencil(int dtype, const void* r, int B, int D, int H, int W, int C, const float* weff, const float* beff,
+                    const int32_t* patch_list, int n_patches, float* rec /* may be NULL */, const float* inp /* NULL unless l2 */,
+                    float* l2 /* may be NULL */, void* stream);
+int am_head_stencil_supported(int dtype, int C);
+
 /* 1x1 projection C -> 1 (P/decoder3D.py:51,61) and its backward. rec/drec are fp32 [B][D][H][W]. */
 int am_proj_fwd(int dtype, const void* x, long nvox, int C, const float* w, const float* b,
                 const float* pre_scale, const float* pre_shift /* NULL, or x is the INPUT of a per-channel affine map (the train-mode

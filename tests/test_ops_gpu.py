@@ -499,6 +499,55 @@ def test_conv_k3_persistent_kernel_is_deterministic(ops):
     assert torch.equal(y1, y2) and torch.equal(p1.t[:p1.rows], p2.t[:p2.rows])
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C", [32, 64, 128, 192])
+def test_head_stencil_equals_conv_bn_proj_chain(ops, dtype, C):
+    """am_head_fold + am_head_stencil: the decoder's eval-mode tail conv3x3x3(C -> C/2, no bias) -> BatchNorm3d(running statistics) ->
+    Conv3d(C/2 -> 1, k1, bias) (P/decoder3D.py:20-22,51,61) as ONE C -> 1 stencil on the needed 16^3 patches, against the three-op chain
+    in fp32 on the same (storage-rounded) input: rec on the needed patches (other patches untouched), the raw per-patch l2 against a
+    volume (P/pretrain_AntoMask.py:423), border patches (zero padding) included.  fp32 storage: <= 2e-4 of max (summation order);
+    bf16 storage: the input is exact in bf16 and the folded weights enter as hi + lo parts: <= 1e-3 of max."""
+    B, S = 2, (32, 32, 48)
+    cmid = C // 2
+    r = q(rnd(B, C, *S, seed=301).clamp(0, 6), dtype)                       # a ReLU6 output
+    w2 = rnd(cmid, C, 3, 3, 3, seed=302, scale=1.0 / np.sqrt(C * 27))
+    gamma, beta = rnd(cmid, seed=303).abs() + 0.5, rnd(cmid, seed=304) * 0.2
+    rmean, rvar = rnd(cmid, seed=305) * 0.3, rnd(cmid, seed=306).abs() + 0.3
+    wp, bp = rnd(1, cmid, 1, 1, 1, seed=307, scale=0.3), rnd(1, seed=308)
+    inp = rnd(B, *S, seed=309)
+    chain = F.conv3d(F.batch_norm(F.conv3d(r, w2, None, padding=1), rmean, rvar, gamma, beta, training=False, eps=1e-5), wp, bp)[:, 0]
+    f = tuple(v // 16 for v in S)
+    need = mk_mask(B, f, 7, seed=11)                                        # 7 of 12 patches per sample, corner patches among them
+    mi = ops.MaskInfo.from_bool(need, DEV)
+    st = ops.NormStats(cmid, DEV)
+    ops.norm_fold_running(st, gamma.to(DEV), beta.to(DEV), rmean.to(DEV), rvar.to(DEV), 1e-5)
+    weff, beff = ops.head_fold(w2.to(DEV), st.scale, st.shift, wp.view(-1).to(DEV), bp.to(DEV))
+    # the folded stencil itself, against its definition
+    sc = gamma / torch.sqrt(rvar + 1e-5)
+    weff_ref = torch.einsum("c,coxyz->xyzo", wp.view(-1) * sc, w2).reshape(27, C)
+    assert (weff.cpu() - weff_ref).abs().max().item() <= 1e-6 * weff_ref.abs().max().item() + 1e-8
+    x_cl = to_cl(r, dtype)
+    assert ops.head_stencil_supported(x_cl)
+    rec = torch.full((B, *S), 777.0, device=DEV)
+    l2 = torch.full((B, f[0] * f[1] * f[2]), -1.0, device=DEV)
+    ops.head_stencil(x_cl, weff, beff, mi, rec=rec, inp=inp.to(DEV), l2=l2)
+    up = O.upsample_mask(need, S)[:, 0]
+    tol = 2e-4 if dtype == torch.float32 else 1e-3
+    scale = chain.abs().max().item()
+    got = rec.cpu()
+    assert (got - chain)[up].abs().max().item() <= tol * scale, ((got - chain)[up].abs().max().item(), scale)
+    assert (got[~up] == 777.0).all(), "a patch outside the list was written"
+    e = ((chain - inp) ** 2).reshape(B, f[0], 16, f[1], 16, f[2], 16).mean(dim=(2, 4, 6)).reshape(B, -1)
+    nm = need.reshape(B, -1)
+    l2c = l2.cpu()
+    assert (l2c[nm] - e[nm]).abs().max().item() <= 2 * tol * e[nm].max().item()
+    assert (l2c[~nm] == -1.0).all()
+    # l2 alone (the teacher pass: rec never exists) gives the same numbers
+    l2b = torch.zeros_like(l2)
+    ops.head_stencil(x_cl, weff, beff, mi, inp=inp.to(DEV), l2=l2b)
+    assert torch.equal(l2b.cpu()[nm], l2c[nm])
+
+
 # ------------------------------------------------------------------ kernel branches only STUNet-L / STUNet-H reach
 # (P/pretrain_AnatoMask_DDP.py:222-229: depth 2/3, dims 64..1024 / 96..1536, patches 160^3 / 192^3 -> 10^3 / 12^3 grids of
 # one-voxel patches at level 4, 20- / 24-wide decoder grids, 96-channel level 0).  Every case: forward, data gradient and weight
