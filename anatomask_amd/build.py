@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libanatomask_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_k3.hip", "conv_rw.hip", "conv_gather.hip", "conv_wgrad.hip", "stream_ops.hip", "step_ops.hip", "head_ops.hip", "aug_ops.hip", "layer_ops.hip"]
+SOURCES = ["conv_igemm.hip", "conv_k3.hip", "conv_rw.hip", "conv_gather.hip", "conv_wgrad.hip", "conv_wgk3.hip", "stream_ops.hip", "step_ops.hip", "head_ops.hip", "aug_ops.hip", "layer_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 

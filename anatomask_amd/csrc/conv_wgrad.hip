@@ -24,6 +24,12 @@
 #include "common.h"
 #include "../../include/anatomask_hip.h"
 
+namespace amconv {
+// conv_wgk3.hip: dense bf16 k3 s1 weight gradients with 64 x 64 channel tiles on the 8-wave LDS-DMA kernel; 1 = served, 0 = does not qualify
+int conv_wgk3_launch(const void* x, const void* dy, float* dw, int B, int D, int H, int W, int Cx, int Cy, void* stream);
+bool conv_wgk3_qualifies(int B, int D, int H, int W, int Cx, int Cy);
+}
+
 namespace {
 
 struct WgArgs {
@@ -873,6 +879,10 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   { const char* e_ = getenv("AM_WG_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
 #endif
   const bool bf = dtype == AM_DT_BF16;
+  if (bf && mode == AM_CONV_FWD && ksize == 3 && stride == 1 && !x_mask && !y_mask && !det_workspace && Dx == Dy && Hx == Hy && Wx == Wy) {
+    const int rc = amconv::conv_wgk3_launch(x, dy, dw_packed, B, Dy, Hy, Wy, Cx, Cy, stream);
+    if (rc != 0) return rc == 1 ? 0 : rc;
+  }
   // units: taps that share the dY operand AND one dense X sub-brick
   //   conv stride 1: one unit per d-tap (9 taps, no d-halo);  ConvT: the 8 output parities (8 taps each);
   //   conv stride 2: the 8 parity sub-lattices of X (1,2,2,2,4,4,4,8 taps): X[2q + s] = X_sub[r][q + u], s = 2u + r
@@ -1021,6 +1031,12 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
     if (rc) return rc;
   }
   return 0;
+}
+
+extern "C" int am_conv3d_wgrad_uses_k3(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cx, int Cy, int has_masks,
+                                       int deterministic) {
+  return (dtype == AM_DT_BF16 && mode == AM_CONV_FWD && ksize == 3 && stride == 1 && !has_masks && !deterministic &&
+          amconv::conv_wgk3_qualifies(B, D, H, W, Cx, Cy)) ? 1 : 0;
 }
 
 extern "C" int am_conv3d_wgrad_gather_bytes(int mode, int dtype, int ksize, int stride, int B, int Cx, int Cy, int y_bshift, int has_y_mask, int n_active,

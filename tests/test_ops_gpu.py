@@ -499,6 +499,40 @@ def test_conv_k3_persistent_kernel_is_deterministic(ops):
     assert torch.equal(y1, y2) and torch.equal(p1.t[:p1.rows], p2.t[:p2.rows])
 
 
+@pytest.mark.parametrize("case", [(64, 64, (32, 32, 32), 2), (128, 64, (16, 32, 32), 4), (64, 128, (24, 16, 48), 6), (64, 64, (9, 8, 16), 64)])
+def test_conv_wgrad_k3_dense_8wave_dma_kernel(ops, case):
+    """conv_wgk3.hip (round 5): the dense bf16 k3 s1 weight gradient with 64 x 64 channel tiles on the persistent 8-wave LDS-DMA kernel
+    (both operands by DMA into swizzled unpadded rows, transposing fragment reads, the two waves of a SIMD in antiphase) against
+    F.conv3d autograd on the same bf16-rounded operands: 2e-2 of max (the bf16 bound of every conv test here; the sums are fp32).  Cases:
+    one tile / two cx tiles / two cy tiles with a ragged depth / a one-brick-per-plane grid with an odd depth and many samples (every
+    brick is a border brick in h and w: the zero-filled halo rows).  The same launch in deterministic mode runs conv_wgrad.hip's
+    ordered fold: the two kernels must agree to fp32 summation order."""
+    cin, cout, S, B = case
+    dtype = torch.bfloat16
+    x = q(rnd(B, cin, *S, seed=401), dtype)
+    dy = q(rnd(B, cout, *S, seed=402), dtype)
+    from anatomask_amd import hip
+    assert hip.lib()._lib.am_conv3d_wgrad_uses_k3(ops.CONV_FWD, hip.DT_BF16, 3, 1, B, *S, cin, cout, 0, 0) == 1, "the case must reach the new kernel"
+    assert hip.lib()._lib.am_conv3d_wgrad_uses_k3(ops.CONV_FWD, hip.DT_BF16, 3, 1, B, *S, cin, cout, 0, 1) == 0
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(x, w, None, padding=1).backward(dy)
+    dwp = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dtype), to_cl(dy, dtype), 3, 1)
+    dw = torch.zeros(cout, cin, 3, 3, 3, device=DEV)
+    ops.unpack_grad(dwp, dw, transposed_conv=False, accumulate=False)
+    close(dw.cpu(), w.grad, TOL[dtype], "conv_wgk3 weight gradient")
+    ops.DETERMINISTIC_WGRAD = True
+    try:
+        dwp2 = ops.conv3d_wgrad(ops.CONV_FWD, to_cl(x, dtype), to_cl(dy, dtype), 3, 1)
+    finally:
+        ops.DETERMINISTIC_WGRAD = False
+    close(dwp.cpu(), dwp2.cpu(), 1e-4, "conv_wgk3 vs conv_wgrad (deterministic fold)")
+    # every tap separately (a wrong tap index or a shifted halo shows here even if the maximum hides it)
+    ref = w.grad.permute(2, 3, 4, 0, 1).reshape(27, cout, cin)
+    got = dwp.cpu()
+    for t in range(27):
+        assert (got[t] - ref[t]).abs().max().item() <= TOL[dtype] * ref[t].abs().max().item() + 1e-6, f"tap {t}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C", [32, 64, 128, 192])
 def test_head_stencil_equals_conv_bn_proj_chain(ops, dtype, C):
