@@ -76,14 +76,15 @@ struct Item { int u, k, c0, c1; };                  // c0 = bw | bh << 8 | bd <<
 #define IT_Q0H(it) ((((it).c0 >> 8) & 255) * KBH)
 #define IT_Q0D(it) ((((it).c0 >> 16) & 255) * KBD)
 #define IT_B(it) ((it).c1 & 255)
-#define IT_CO0(it) (((it).c1 >> 8) * 64)
+#define IT_CO0(it) (((it).c1 >> 8) * NT)
 
 // EP: the fused store epilogue (eval-mode BatchNorm scale / shift, skip tensor, activation: the teacher's decoder) is its own instantiation --
 // its scale / shift registers would push the plain kernel over 256.  ST: the statistics rows (16 more registers), likewise
 template <int NS, bool EP, bool ST>
 __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
-  static_assert(NS == 4, "64-channel output tiles");
+  static_assert(NS == 4 || NS == 2, "64- or 32-channel output tiles (NS = 2: the decoder's last conv, C -> C / 2 = 32 at STUNet-B; a wave then owns 8 accumulator tiles)");
   constexpr int VS = 4, NT = 16 * NS;
+  constexpr int NCH = VS * NS / 2;                  // 16-byte store chunks per lane and unit
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   auto issue_weights = [&](const Item& it, const int run, const int slot) __attribute__((always_inline)) {
     // run = zd * 3 + xw; its taps th = 0..2 are the h-shifts; X wave wq brings cout tile wq of each tap
     const int zd = run / 3, xw = run - zd * 3;
+    if (wq >= NS) return;                              // (NS = 2: waves 0, 1 bring the two cout tiles)
 #pragma unroll
     for (int th = 0; th < 3; ++th) {
       const int t = zd * 9 + th * 3 + xw, widx = a.flip ? 26 - t : t;
@@ -282,9 +284,9 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       }
     }
   };
-  // chunk c = 2 j + h of the pending unit: one 16-byte store per lane (+ the statistics of the stored values)
+  // chunk c = (NS / 2) j + h of the pending unit: one 16-byte store per lane (+ the statistics of the stored values)
   auto store_chunk = [&](const int c, const bool tail) __attribute__((always_inline)) {
-    const int j = c >> 1, h = c & 1;
+    const int j = c / (NS / 2), h = c % (NS / 2);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)k3_uni_ptr(yg + pk_off), 0, 0x7fffff00, 0x00020000);
 #ifdef AM_ABLATE
     if (!(a.dbg & 1))
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
     for (int c = lane; c < a.Cout * 2; c += 64) part[c] = 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  if (tid < 64) {                                        // (the channel tile of a workgroup never changes: the grid is a multiple of ny)
+  if (tid < NT) {                                        // (the channel tile of a workgroup never changes: the grid is a multiple of ny)
     const int c = IT_CO0(cur) + tid;
     ((float*)(lds + KLDS_TAB))[tid] = a.bias ? a.bias[c] : 0.f;
     ((float*)(lds + KLDS_TAB))[64 + tid] = a.ep_scale ? a.ep_scale[c] : 1.f;
@@ -388,9 +390,9 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
         if (run < 8) issue_weights(cur, run + 1, par ^ 1);
         else if (has_next) issue_weights(nxt, 0, par ^ 1);
         if (has_next && npx > 0) issue_pieces(nxt, sb ^ 1, pk0, pk0 + npx);
-        if (spend && run < 8) store_chunk(run, false);   // (behind the weights: the counted wait below leaves it in flight)
+        if (spend && run < NCH) store_chunk(run, false); // (behind the weights: the counted wait below leaves it in flight)
       } else {
-        if (spend && run < 8) store_chunk(run, false);
+        if (spend && run < NCH) store_chunk(run, false);
         if (has_next && npy > 0) issue_pieces(nxt, sb ^ 1, pk0, pk0 + npy);
       }
       // ONE barrier per run and wave.  Between two barriers X runs [L(n) M(n)] and Y runs [M(n - 1) L(n)]: X fetches while Y multiplies, then
@@ -422,13 +424,13 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       // deferred store); at the end of M(8) the whole next slab.  Y: at the end of M(7) its share of the next slab (a store issued in L(7) is
       // the youngest operation and stays in flight).
       if (isX) {
-        const int nbehind = (has_next ? npx : 0) + ((spend && run < 8) ? 1 : 0);
+        const int nbehind = (has_next ? npx : 0) + ((spend && run < NCH) ? 1 : 0);
         if (nbehind == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (nbehind == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if (nbehind == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
       } else if (run == 7) {
-        if (spend) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (spend && 7 < NCH) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       K3_STAMP(tM);
@@ -445,8 +447,8 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   }
   finish_unit(pc0, pc1);
 #pragma unroll
-  for (int c = 0; c < 8; ++c) store_chunk(c, true);
-  if (want_stats) flush_stats((pc1 >> 8) * 64);
+  for (int c = 0; c < NCH; ++c) store_chunk(c, true);
+  if (want_stats) flush_stats((pc1 >> 8) * NT);
 #ifdef AM_ABLATE
   if (stamps && a.partials) {
     K3_STAMP(tE);
@@ -464,7 +466,7 @@ namespace amconv {
 
 // rows of partial sums a launch of this kernel writes (8 per workgroup), or 0 when the shape does not qualify
 static int k3_grid(int B, int D, int H, int W, int Cout, int* units) {
-  const int nb = B * (D / KBD) * (H / KBH) * (W / KBW), ny = Cout / 64;
+  const int nb = B * (D / KBD) * (H / KBH) * (W / KBW), ny = Cout == 32 ? 1 : Cout / 64;
   *units = nb * ny;
   int cus = 256;
   static int cached = 0;
@@ -477,7 +479,7 @@ static int k3_grid(int B, int D, int H, int W, int Cout, int* units) {
 
 static bool k3_qualifies(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cin, int Cout, bool masks) {
   if (dtype != AM_DT_BF16 || ksize != 3 || stride != 1 || (mode != AM_CONV_FWD && mode != AM_CONV_DGRAD) || masks) return false;
-  if (Cin % 32 || Cout % 64 || D % KBD || H % KBH || W % KBW) return false;
+  if (Cin % 32 || (Cout % 64 && Cout != 32) || D % KBD || H % KBH || W % KBW) return false;
   // `Item` packs the sample index and the three brick indices into 8-bit fields (IT_B / IT_Q0*): larger launches go to conv_igemm.hip
   if (B > 255 || D / KBD > 255 || H / KBH > 255 || W / KBW > 255) return false;
   return true;
@@ -501,12 +503,13 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
   if (units < K3_MIN_UNITS) return 0;
 #ifdef AM_ABLATE
   if (getenv("AM_CV_NOK3")) return 0;
+  { const char* e_ = getenv("AM_K3_NO32"); if (e_ && atoi(e_) && c.Cout == 32) return 0; }
 #endif
   K3Args a;
   a.x = (const bf16_t*)c.x; a.w = (const bf16_t*)c.w; a.bias = c.bias; a.y = (bf16_t*)c.y; a.partials = c.partials;
   a.ep_scale = c.ep_scale; a.ep_shift = c.ep_shift; a.ep_res = (const bf16_t*)c.ep_res; a.ep_act = c.ep_act;
   a.B = c.B; a.D = c.Di; a.H = c.Hi; a.W = c.Wi; a.Cin = c.Cin; a.Cout = c.Cout; a.Cinp = c.Cinp; a.Coutp = c.Coutp;
-  a.nbd = c.Di / KBD; a.nbh = c.Hi / KBH; a.nbw = c.Wi / KBW; a.ny = c.Cout / 64; a.nunit = units; a.nslab = c.Cinp / 32;
+  a.nbd = c.Di / KBD; a.nbh = c.Hi / KBH; a.nbw = c.Wi / KBW; a.ny = c.Cout == 32 ? 1 : c.Cout / 64; a.nunit = units; a.nslab = c.Cinp / 32;
   a.flip = mode == AM_CONV_DGRAD;
   a.nt_store = (size_t)c.B * c.Do * c.Ho * c.Wo * c.Cout * 2 >= ((size_t)384 << 20);
   a.w_bytes = (unsigned)c.w_bytes;
@@ -516,11 +519,15 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
   const bool ep = a.ep_scale || a.ep_res || a.ep_act != AM_ACT_NONE;
   if (ep && a.partials) return 0;                  // (no caller fuses a store epilogue AND asks for statistics: conv_igemm.hip serves it)
   auto kern = ep ? conv_k3_kernel<4, true, false> : (a.partials ? conv_k3_kernel<4, false, true> : conv_k3_kernel<4, false, false>);
+  if (c.Cout == 32) kern = ep ? conv_k3_kernel<2, true, false> : (a.partials ? conv_k3_kernel<2, false, true> : conv_k3_kernel<2, false, false>);
   static PerDeviceOnce lds_cap;
   lds_cap.run([&](int) {
     (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
   });
   AM_LAUNCH(kern, dim3(G), dim3(512), KLDS, (hipStream_t)stream, a);
