@@ -699,12 +699,14 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
                        int Cout, const uint8_t* in_mask, int in_bshift, const uint8_t* out_mask, int out_bshift,
                        int fd, int fh, int fw, int accumulate, float* partials, const float* ep_scale, const float* ep_shift,
                        const void* ep_res, int ep_act, const int32_t* active_list, int n_active, int* partial_rows_written,
-                       const void* nb_x, const float* nb_scale, const float* nb_shift, int nb_act, void* stream) {
+                       const void* nb_x, const float* nb_scale, const float* nb_shift, int nb_act, void* stream,
+                       const float* in_scale = nullptr, const float* in_shift = nullptr, int in_act = 0) {
   if (Cin % 8 || Cout % 8) return -1;
   if (ep_scale && !ep_shift) return -1;
   Plan P;
   ConvArgs& a = P.a;
   a.nb_x = nb_x; a.nb_scale = nb_scale; a.nb_shift = nb_shift; a.nb_act = nb_act;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   // ---- thin layers with everything resident in LDS: conv_rw.hip ----
   {
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y; a.partials = partials;
@@ -720,7 +722,7 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
     if (getenv("AM_CV_NORW")) goto generic;
 #endif
     a.plist = nullptr;
-    {                                              // dense k3 s1 at decoder sizes: the persistent LDS-DMA kernel (conv_k3.hip)
+    if (!in_scale) {                               // dense k3 s1 at decoder sizes: the persistent LDS-DMA kernel (conv_k3.hip)
       const int rk = conv_k3_launch(mode, dtype, ksize, stride, a, stream);
       if (rk < 0) return rk;
       if (rk == 1) {
@@ -734,6 +736,7 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
       if (partial_rows_written) *partial_rows_written = conv_rw_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_mask != nullptr, out_bshift, n_active);
       return 0;
     }
+    if (in_scale) return -7;                       // (the fused input norm lives in conv_rw.hip only: am_conv3d_prenorm_supported says when)
     const int rg = conv_gather_launch(mode, dtype, ksize, stride, a, active_list, n_active, stream);   // deep block-sparse levels: rows = active voxels
     if (rg < 0) return rg;
     if (rg == 1) {
@@ -810,6 +813,27 @@ extern "C" int am_conv3d(int mode, int dtype, int ksize, int stride, const void*
   return conv3d_impl(mode, dtype, ksize, stride, x, w_packed, bias, y, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, in_mask, in_bshift, out_mask,
                      out_bshift, fd, fh, fw, accumulate, partials, ep_scale, ep_shift, ep_res, ep_act, active_list, n_active,
                      partial_rows_written, nullptr, nullptr, nullptr, 0, stream);
+}
+
+// Forward convolution of act(x * in_scale + in_shift) -- a (pooled sparse Instance)Norm + activation folded into the consumer's source
+// staging, so that the normalised map is never written or read (the EMA teacher's stage-0 conv2 and every encoder pass that keeps no
+// tape: P/STUNet_head.py:96-103 `y = LReLU(IN(conv1 x)); conv2(y)`).  Inactive / out-of-volume source rows stay zero, as the dense-conv-
+// then-mask semantics of P/encoder3D.py:12-15 has them.  Served by conv_rw.hip only (bf16, Cin <= 32, k3): am_conv3d_prenorm_supported.
+extern "C" int am_conv3d_prenorm_supported(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout,
+                                           int sparse, int in_bshift, int out_bshift, int n_active) {
+  if (mode != AM_CONV_FWD || !sparse || n_active <= 0 || in_bshift != out_bshift + (stride == 2 ? 1 : 0)) return 0;
+  return conv_rw_rows(mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, sparse, out_bshift, n_active) > 0 ? 1 : 0;
+}
+
+extern "C" int am_conv3d_prenorm(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed, const float* bias, void* y,
+                                 int B, int Di, int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, const uint8_t* mask, int in_bshift,
+                                 int out_bshift, int fd, int fh, int fw, float* partials, const float* in_scale, const float* in_shift,
+                                 int in_act, const int32_t* active_list, int n_active, int* partial_rows_written, void* stream) {
+  if (!in_scale || !in_shift || !mask || !active_list) return -1;
+  if (in_act != AM_ACT_NONE && in_act != AM_ACT_LRELU && in_act != AM_ACT_RELU6) return -1;
+  return conv3d_impl(mode, dtype, ksize, stride, x, w_packed, bias, y, B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, mask, in_bshift, mask, out_bshift,
+                     fd, fh, fw, 0, partials, nullptr, nullptr, nullptr, AM_ACT_NONE, active_list, n_active, partial_rows_written,
+                     nullptr, nullptr, nullptr, 0, stream, in_scale, in_shift, in_act);
 }
 
 // A data-gradient (or any) convolution whose output y is the gradient wrt a = act(nb_x * nb_scale + nb_shift), the output of a

@@ -11,6 +11,10 @@ struct ConvArgs {
   // norm-backward reduce fused into a data-gradient launch (bf16): y is the gradient wrt a = act(nb_x * nb_scale + nb_shift); the
   // partial rows then hold (sum g, sum g * nb_x) with g = y * act'(.) instead of (sum y, sum y^2)  -- am_conv3d_nbred
   const void* nb_x; const float* nb_scale; const float* nb_shift; int nb_act;
+  // norm + activation of the INPUT fused into the source staging (conv_rw.hip only, am_conv3d_prenorm): the kernel reads x' = the norm's
+  // input and convolves act(x' * in_scale + in_shift) on the rows that exist (inactive / out-of-volume rows stay zero) -- the
+  // normalised map is never written.  NULL: x is convolved as it is
+  const float* in_scale; const float* in_shift; int in_act;
   int B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout, Cinp, Coutp;
   int OS, GS, nclass, nunit;  // output stride (parity classes), global source stride, #classes, #units
   int ny;                     // output-channel tiles per brick (conv_igemm: folded into blockIdx.x with the classes)

@@ -108,6 +108,13 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
   }
   const int cchunk = (tid & 3) * EPC;
   const int sdst = (tid >> 2) * LR + (tid & 3) * 16;
+  // fused input norm + activation (am_conv3d_prenorm): the thread's channel chunk never changes, its 8 (scale, shift) pairs live in registers
+  const bool prenorm = a.in_scale != nullptr;
+  float isc[EPC], ish[EPC];
+#pragma unroll
+  for (int i = 0; i < EPC; ++i) { isc[i] = (prenorm && cchunk + i < a.Cin) ? a.in_scale[cchunk + i] : 1.f; ish[i] = (prenorm && cchunk + i < a.Cin) ? a.in_shift[cchunk + i] : 0.f; }
+  const float in_slope = a.in_act == AM_ACT_LRELU ? 0.01f : (a.in_act == AM_ACT_RELU6 ? 0.f : 1.f);
+  const float in_hi = a.in_act == AM_ACT_RELU6 ? 6.f : __builtin_inff();
   const size_t plane_elems = (size_t)a.Hi * a.Wi * a.Cin;
   const bool cok = cchunk < a.Cin;
   T* __restrict__ yg = (T*)a.y;
@@ -154,6 +161,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
   // Source rows travel global -> registers -> LDS; TWO register sets alternate so that the rows of stage s+2 are requested while
   // stage s computes (one stage of cover -- a few hundred to 3 500 cycles -- does not hide an HBM round trip under load).
   u32x4 stgA[NIT], stgB[NIT];
+  unsigned vmA = 0u, vmB = 0u;                           // rows of the register set that exist (bit it): the fused input transform leaves the others zero
   // staging plan of stage (brick bi, unit un) + issue of its loads into stg.  nbm: activity bits of the 27 neighbour patches.
   // `valid` = false (past the last stage): the same number of loads is issued, all out of range (zeros, no traffic) -- the
   // compiler counts vector-memory operations statically, and a CONDITIONAL prefetch makes it wait for everything in flight.
@@ -174,7 +182,8 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
       roff[it] = (unsigned)((((ez * gs * a.Hi + ey * gs) * a.Wi + ex * gs) * a.Cin + cchunk) * (int)sizeof(T));
     }
   }
-  auto plan_and_load = [&](u32x4 (&stg)[NIT], int bi_, int un_, bool valid) {
+  auto plan_and_load = [&](u32x4 (&stg)[NIT], unsigned& vm, int bi_, int un_, bool valid) {
+    vm = 0u;
     // everything that shapes the stage is wave-uniform: say so (scalar registers, scalar buffer descriptor)
     const int bi = __builtin_amdgcn_readfirstlane(valid ? bi_ : b0), un = __builtin_amdgcn_readfirstlane(valid ? un_ : 0);
     int b, q0d, q0h, q0w, pd, ph, pw, nbm;
@@ -199,6 +208,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
           const int t = relf[it] + sb;
           const int idx = ((t >> 4) & 3) * 9 + ((t >> 12) & 3) * 3 + ((t >> 20) & 3);
           const bool ok = live & (relf[it] >= 0) & (((nbm >> idx) & 1) != 0);
+          vm |= ok ? (1u << it) : 0u;
           stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? roff[it] + sbase : OOB, 0, 0));
         }
         return;
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
         ok = ok & (((nbm >> (pidx & 31)) & 1) != 0);
       }
       const unsigned off = ok ? (unsigned)(((((id - dbase) * a.Hi + ih) * a.Wi + iw) * a.Cin + cchunk) * (int)sizeof(T)) : OOB;
+      vm |= ok ? (1u << it) : 0u;
       stg[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
     }
   };
@@ -237,19 +248,30 @@ __global__ __launch_bounds__(NW * 64) void conv_rw_kernel(ConvArgs a, RwArgs r) 
     AM_RW_FIRST(un)
     int bi1 = bi, un1 = un; AM_RW_ADVANCE(bi1, un1)     // stage s+1
     int bi2 = bi1, un2 = un1; AM_RW_ADVANCE(bi2, un2)   // stage s+2
-    plan_and_load(stgA, bi, un, true);
-    plan_and_load(stgB, bi1, un1, bi1 < b1);
-#define AM_RW_STAGE(STG) \
+    plan_and_load(stgA, vmA, bi, un, true);
+    plan_and_load(stgB, vmB, bi1, un1, bi1 < b1);
+#define AM_RW_STAGE(STG, VM) \
     { \
       bi = __builtin_amdgcn_readfirstlane(bi); un = __builtin_amdgcn_readfirstlane(un); \
       const int tb = UP(u_tb, un), nt = UP(u_te, un) - tb; \
       const int EH = uni ? BH + 1 : UP(u_eh, un), EW = uni ? BW + 1 : UP(u_ew, un), nvox = (uni ? BD + 1 : UP(u_ed, un)) * EH * EW; \
+      if (prenorm) {                                      /* (uniform) x' -> act(x' * scale + shift) on the rows that exist */ \
+_Pragma("unroll") \
+        for (int it = 0; it < NIT; ++it) { \
+          float f_[EPC]; \
+          chunk_to_f<T>(STG[it], f_); \
+_Pragma("unroll") \
+          for (int e_ = 0; e_ < EPC; ++e_) { const float y_ = f_[e_] * isc[e_] + ish[e_]; const float t_ = fmaxf(y_, y_ * in_slope); f_[e_] = t_ > in_hi ? in_hi : t_; } \
+          const u32x4 n_ = f_to_chunk<T>(f_); \
+          if ((VM >> it) & 1u) STG[it] = n_; \
+        } \
+      } \
       __syncthreads(); \
 _Pragma("unroll") \
       for (int it = 0; it < NIT; ++it) \
         if ((tid >> 2) + it * RPI < nvox && !AM_DBG(a, 8)) *(u32x4*)(lds + sdst + it * RPI * LR) = STG[it]; \
       __syncthreads(); \
-      plan_and_load(STG, bi2, un2, bi2 < b1); \
+      plan_and_load(STG, VM, bi2, un2, bi2 < b1); \
       int bb[VS]; \
 _Pragma("unroll") \
       for (int j = 0; j < VS; ++j) { \
@@ -345,9 +367,9 @@ _Pragma("unroll") \
     } \
 
     while (bi < b1) {
-      AM_RW_STAGE(stgA)
+      AM_RW_STAGE(stgA, vmA)
       if (bi >= b1) break;
-      AM_RW_STAGE(stgB)
+      AM_RW_STAGE(stgB, vmB)
     }
 #undef AM_RW_STAGE
 #undef AM_RW_ADVANCE
@@ -442,6 +464,7 @@ int conv_rw_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, con
   if (sparse != (a0.in_mask.m != nullptr) || (sparse && a0.in_mask.m != a0.out_mask.m)) return 0;
   if (a0.accumulate || a0.ep_scale || a0.ep_res || a0.ep_act != AM_ACT_NONE) return 0;
   if (sparse && !active_list) return 0;
+  if (a0.in_scale && (!a0.in_shift || mode != AM_CONV_FWD)) return 0;
   RwGeo G;
   if (!rw_geometry(G, mode, dtype, ksize, stride, a0.B, a0.Do, a0.Ho, a0.Wo, a0.Cin, a0.Cout, sparse, a0.out_mask.bs, n_active)) return 0;
   if (sparse) {                                          // the source halo must stay inside the 3x3x3 patch neighbourhood

@@ -226,8 +226,13 @@ class PackCache:
 
 
 # ====================================================================================== forward
-def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
-    """One BasicResBlock (P/STUNet_head.py:96-103) -> (out, record for backward)."""
+FUSED_PRENORM = True    # tools/step_ab.py engine.FUSED_PRENORM=1,0: passes without a tape fold norm1 + LeakyReLU into conv2's source staging
+
+
+def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x, keep: bool = True):
+    """One BasicResBlock (P/STUNet_head.py:96-103) -> (out, record for backward).
+    keep=False (no tape: the EMA teacher, validation, stand-alone forwards): where the kernel exists (the thin level-0 layers, conv_rw.hip)
+    a1 = LReLU(norm1(y1)) is never written -- conv2 applies norm1 + LeakyReLU to y1 while it stages its source rows."""
     dt = pk.dtype
     bs = 4 - s
     p = f"{ENC}.{s}.{b}"
@@ -241,9 +246,14 @@ def _enc_block(W, pk, inp, mask, counts, sp, s: int, b: int, x):
                              in_mask=mask, in_bshift=bs + (1 if stride == 2 else 0), out_mask=mask, out_bshift=bs,
                              want_partials=True)
     st1 = _sparse_norm(y1, mask, bs, counts, W[f"{p}.norm1.weight"], W[f"{p}.norm1.bias"], 1e-5, pt1)
-    a1 = ops.norm_apply(y1, st1, ACT_LRELU, mask, bs)
-    y2, pt2 = ops.conv3d(CONV_FWD, a1, pk.get(W, f"{p}.conv2.weight", False, False), W[f"{p}.conv2.bias"], sp, 3, 1,
-                         in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs, want_partials=True)
+    w2 = pk.get(W, f"{p}.conv2.weight", False, False)
+    if not keep and FUSED_PRENORM and ops.conv3d_prenorm_supported(y1, w2, sp, 3, 1, mask, bs):
+        a1 = None
+        y2, pt2 = ops.conv3d_prenorm(y1, st1, ACT_LRELU, w2, W[f"{p}.conv2.bias"], sp, 3, 1, mask, bs, want_partials=True)
+    else:
+        a1 = ops.norm_apply(y1, st1, ACT_LRELU, mask, bs)
+        y2, pt2 = ops.conv3d(CONV_FWD, a1, w2, W[f"{p}.conv2.bias"], sp, 3, 1,
+                             in_mask=mask, in_bshift=bs, out_mask=mask, out_bshift=bs, want_partials=True)
     st2 = _sparse_norm(y2, mask, bs, counts, W[f"{p}.norm2.weight"], W[f"{p}.norm2.bias"], 1e-5, pt2)
     if s == 0 and first:      # 1x1 Cin=1 shortcut folded into the apply pass
         out = ops.norm_apply(y2, st2, ACT_LRELU, mask, bs, stem=(inp, W[f"{p}.conv3.weight"].view(-1), W[f"{p}.conv3.bias"]))
@@ -317,7 +327,7 @@ def encoder_forward(spec: Spec, W, pk: PackCache, inp: torch.Tensor, mask: MaskI
         if tape is not None and recompute:
             tape.enc_in.append(x)
         for b in range(spec.depth[s]):
-            x, rec_ = _enc_block(W, pk, inp, mask, counts, sp, s, b, x)
+            x, rec_ = _enc_block(W, pk, inp, mask, counts, sp, s, b, x, keep=tape is not None)
             if tape is not None and not recompute:
                 tape.enc.append(rec_)
         feats.append(x)

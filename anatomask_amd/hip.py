@@ -37,7 +37,7 @@ def declared_functions(header: str = HEADER):
 
 
 class HipLib:
-    ANSWERS = ("am_head_stencil_supported", "am_conv3d_wgrad_uses_k3", "am_version")     # entry points whose return value is an answer, not an error code: call them on ._lib
+    ANSWERS = ("am_head_stencil_supported", "am_conv3d_wgrad_uses_k3", "am_conv3d_prenorm_supported", "am_version")     # entry points whose return value is an answer, not an error code: call them on ._lib
 
     def __init__(self, path: str = LIB_PATH):
         import torch  # noqa: F401  torch's bundled HIP runtime must be the one in the process (same soname as /opt/rocm's):

@@ -261,6 +261,38 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     return (out, part) if want_partials else out
 
 
+def conv3d_prenorm_supported(x: torch.Tensor, w_packed: torch.Tensor, out_spatial, ksize: int, stride: int, mask: Optional[MaskInfo], out_bshift: int) -> bool:
+    """am_conv3d_prenorm serves this launch (bf16, Cin <= 32, k3, block-sparse with an active-patch list: conv_rw.hip)."""
+    if mask is None or x.dtype != torch.bfloat16 or _is_split(w_packed):
+        return False
+    lst, n = mask.active_list()
+    if lst is None or n <= 0:
+        return False
+    Cout, Cin = w_packed.logical
+    return hip.lib()._lib.am_conv3d_prenorm_supported(CONV_FWD, _dt(x), ksize, stride, x.shape[0], *out_spatial, Cin, Cout, 1,
+                                                      out_bshift + (1 if stride == 2 else 0), out_bshift, n) == 1
+
+
+def conv3d_prenorm(x: torch.Tensor, st: "NormStats", act: int, w_packed: torch.Tensor, bias: Optional[torch.Tensor], out_spatial, ksize: int,
+                   stride: int, mask: MaskInfo, out_bshift: int, want_partials: bool = False):
+    """conv(act(x * st.scale + st.shift)) with the norm + activation applied while the source rows are staged: the normalised map
+    never exists (passes that keep no tape).  x: the norm's INPUT, block-sparse under `mask`."""
+    B, Di, Hi, Wi, Cin = x.shape
+    Cout, Kl = w_packed.logical
+    assert Kl == Cin and w_packed.dtype == x.dtype
+    Do, Ho, Wo = out_spatial
+    lst, n = mask.active_list()
+    part = ConvPartials(CONV_FWD, ksize, stride, B, out_spatial, Cout, x.device, True, out_bshift, _dt(x), Cin, n) if want_partials else None
+    out = torch.empty(B, Do, Ho, Wo, Cout, device=x.device, dtype=x.dtype)
+    hip.lib().conv3d_prenorm(CONV_FWD, _dt(x), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(), B, Di, Hi, Wi, Cin,
+                             Do, Ho, Wo, Cout, mask.t.data_ptr(), out_bshift + (1 if stride == 2 else 0), out_bshift, mask.fd, mask.fh, mask.fw,
+                             part.t.data_ptr() if part else None, st.scale.data_ptr(), st.shift.data_ptr(), int(act), lst.data_ptr(), n,
+                             _ROWS_ADDR if part else None, _stream())
+    if part is not None:
+        part.rows = _ROWS_OUT.value
+    return (out, part) if want_partials else out
+
+
 # Deterministic weight gradients (am_conv3d_wgrad's det_workspace): per-slot partial sums + an ordered fold instead of fp32 atomics.
 DETERMINISTIC_WGRAD = False
 _DET_WS: dict = {}

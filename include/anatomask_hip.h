@@ -64,6 +64,19 @@ int am_conv3d(int mode, int dtype, int ksize, int stride, const void* x, const v
               levels whose patches are at most 4^3 voxels on the voxel-list gather kernel (rows = active voxels; conv_gather.hip) */,
               int* partial_rows_written /* NULL or (host) the number of partials rows this launch wrote (<= am_conv3d_partials_rows) */,
               void* stream);
+/* Forward convolution of act(x * in_scale + in_shift): the pooled sparse InstanceNorm + LeakyReLU in front of a SparseConv3d
+ * (P/STUNet_head.py:96-103: y = LReLU(IN(conv1 x)); conv2(y), P/encoder3D.py:12-15,138-165) folded into the consumer's source staging --
+ * the normalised map is never written.  Inactive / out-of-volume source rows read as zero (dense-conv-then-mask semantics).  For passes
+ * that keep no tape (the EMA teacher, validation, stand-alone encoder forwards).  One patch mask for input and output (in_bshift =
+ * out_bshift + 1 for stride 2).  am_conv3d_prenorm_supported -> 1 / 0 (an answer, not an error code): bf16, Cin <= 32, k3, block-sparse
+ * with an active-patch list (the resident-weight kernel of conv_rw.hip). */
+int am_conv3d_prenorm_supported(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, int sparse,
+                                int in_bshift, int out_bshift, int n_active);
+int am_conv3d_prenorm(int mode, int dtype, int ksize, int stride, const void* x, const void* w_packed, const float* bias, void* y, int B, int Di,
+                      int Hi, int Wi, int Cin, int Do, int Ho, int Wo, int Cout, const uint8_t* mask, int in_bshift, int out_bshift, int fd,
+                      int fh, int fw, float* partials /* may be NULL */, const float* in_scale, const float* in_shift, int in_act,
+                      const int32_t* active_list, int n_active, int* partial_rows_written /* (host) out, may be NULL */, void* stream);
+
 /* am_conv3d whose output y is the gradient wrt a = act(nb_x * nb_scale + nb_shift) -- the output of a norm + activation
  * (P/decoder3D.py:20-22 BatchNorm3d + ReLU6, P/STUNet_head.py:96-103 InstanceNorm3d + LeakyReLU): the launch also leaves, per
  * workgroup and channel, (sum g, sum g * nb_x) with g = y * act'(.) in `partials` [rows][Cout][2] -- the sums autograd's norm

@@ -502,6 +502,44 @@ def test_conv_k3_persistent_kernel_is_deterministic(ops):
     assert torch.equal(y1, y2) and torch.equal(p1.t[:p1.rows], p2.t[:p2.rows])
 
 
+@pytest.mark.parametrize("act", ["lrelu", "relu6", "none"])
+def test_conv_prenorm_fused_input_norm(ops, act):
+    """am_conv3d_prenorm: conv(act(x * scale + shift)) with the norm + activation applied while the resident-weight kernel stages its
+    source rows (P/STUNet_head.py:96-103: conv2(LReLU(IN(conv1 x))) at the block-sparse 32-channel level 0; the normalised map is never
+    written).  Against F.conv3d of the transformed, masked input (dense-conv-then-mask semantics of P/encoder3D.py:12-15: inactive source
+    voxels read as ZERO, not as act(shift)) and against the two-launch form (norm_apply, conv3d); the statistics rows of the output too."""
+    dtype = torch.bfloat16
+    B, C, f, bs = 2, 32, (2, 3, 2), 4
+    S = tuple(v << bs for v in f)
+    x = q(rnd(B, C, *S, seed=501), dtype)
+    w = q(rnd(C, C, 3, 3, 3, seed=502, scale=1.0 / np.sqrt(C * 27)), dtype)
+    bias = rnd(C, seed=503)
+    scale, shift = rnd(C, seed=504).abs() + 0.5, rnd(C, seed=505) * 0.5
+    mask = mk_mask(B, f, 5, seed=21)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    mo = O.upsample_mask(mask, S).float()
+    code = {"lrelu": ops.ACT_LRELU, "relu6": ops.ACT_RELU6, "none": ops.ACT_NONE}[act]
+    fn = {"lrelu": lambda t: F.leaky_relu(t, 0.01), "relu6": lambda t: torch.clamp(t, 0, 6), "none": lambda t: t}[act]
+    bc = lambda t: t.view(1, -1, 1, 1, 1)
+    a = q(fn(x * bc(scale) + bc(shift)), dtype) * mo             # what norm_apply would have stored, zero where inactive
+    ref = F.conv3d(a, w, bias, padding=1) * mo
+    st = ops.NormStats(C, DEV)
+    st.scale.copy_(scale.to(DEV)); st.shift.copy_(shift.to(DEV))
+    wp = ops.pack_weight(w.to(DEV), dtype, False, False)
+    xin = to_cl(x, dtype)
+    assert ops.conv3d_prenorm_supported(xin, wp, S, 3, 1, mi, bs)
+    y, part = ops.conv3d_prenorm(xin, st, code, wp, bias.to(DEV), S, 3, 1, mi, bs, want_partials=True)
+    close(from_cl(y), ref, TOL[dtype], f"prenorm conv ({act})", mo)
+    a_dev = ops.norm_apply(xin, st, code, mi, bs)
+    y2 = ops.conv3d(ops.CONV_FWD, a_dev, wp, bias.to(DEV), S, 3, 1, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs)
+    close(from_cl(y), from_cl(y2), 4e-3, f"prenorm conv vs norm_apply + conv ({act})", mo)      # (the same bf16-rounded operand up to fma ordering)
+    st_a, st_b = ops.NormStats(C, DEV), ops.NormStats(C, DEV)
+    part.reduce(sums=st_a.sums)
+    ops.chan_stats(y, mi, bs, st_b)
+    refs = st_b.sums.cpu().sum(0)
+    assert (st_a.sums.cpu()[0] - refs).abs().max().item() <= 1e-5 * refs.abs().max().item()
+
+
 @pytest.mark.parametrize("case", [(64, 64, (32, 32, 32), 2), (128, 64, (16, 32, 32), 4), (64, 128, (24, 16, 48), 6), (64, 64, (9, 8, 16), 64)])
 def test_conv_wgrad_k3_dense_8wave_dma_kernel(ops, case):
     """conv_wgk3.hip (round 5): the dense bf16 k3 s1 weight gradient with 64 x 64 channel tiles on the persistent 8-wave LDS-DMA kernel
