@@ -36,6 +36,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # mask ratio the figure was derived for (size -> (patch, mask_ratio, bytes, flop))
 ENC_FWD_ALGO = {"S": (48, 0.6, 36.1e6, 1.5e9), "B": (128, 0.6, 1105.3e6, 114.0e9), "L": (160, 0.7, 6135e6, 1716e9), "H": (192, 0.6, 30622e6, 14345e9)}
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
+# counter evidence of this round's tree, written by tools/pmc_k3.sh / tools/enc_traffic.py on the GPU box and committed under profiles/
+PMC_K3_JSON = os.path.join("profiles", "r05_pmc_k3.json")
+ENC_TRAFFIC_JSON = os.path.join("profiles", "r05_encoder_fwd_traffic.json")
 MFMA_BF16_PEAK = 2.5e15    # dense bf16
 
 
@@ -99,14 +102,14 @@ def dominant_kernel_roofline(B, dev, tr, x, C=64, S=128, size="B"):
     achieved = flops / t / 1e12
     algo = (2 * S ** 3 * C * 2 * B) + 27 * C * C * 2
     # HBM bytes per launch: the PMC counters of the SAME launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
-    # doubled per the gfx950 correction, counters in KB = 1024 B), as tools/pmc_k3.sh left them in profiles/r04_pmc_k3.json: measured at
+    # doubled per the gfx950 correction, counters in KB = 1024 B), as tools/pmc_k3.sh left them in profiles/r05_pmc_k3.json: measured at
     # B = 16 for 64 -> 64 @128^3 and linear in B.  No counter pass exists for the other shapes -> null; a missing file is an error, not a constant.
     traffic = src = None
     if (C, S) == (64, 128):
-        pj = os.path.join(ROOT, "profiles", "r04_pmc_k3.json")
+        pj = os.path.join(ROOT, PMC_K3_JSON)
         rec = json.load(open(pj))["conv_k3_kernel"]            # (raises if the profile was not committed)
         traffic = (rec["fetch_bytes"] + rec["write_bytes"]) * B / rec["batch"]
-        src = (f"profiles/r04_pmc_k3.json (tools/pmc_k3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this launch at B={rec['batch']}: "
+        src = (f"{PMC_K3_JSON} (tools/pmc_k3.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this launch at B={rec['batch']}: "
                f"{(rec['fetch_bytes'] + rec['write_bytes']) / rec['algorithmic_bytes']:.2f} x algorithmic, {rec['launch_us']:.0f} us under the profiler; scaled to the bench batch)")
     return {"bound": "mfma", "kernel": f"conv_k3_kernel<4,false,true> (decoder conv3 {C}->{C} @{S}^3, statistics epilogue on)", "achieved": round(achieved, 2),
             "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_BF16_PEAK, 4),
@@ -136,9 +139,17 @@ def encoder_forward_hbm(model, x, dev, size, patch, mask_ratio):
     t = time_kernel(enc_only, iters=10, warm=2)
     algo = bytes_pv * B
     gbs = algo / t / 1e9
-    return {"what": f"student sparse-encoder forward, STUNet-{size} {patch}^3 bf16, mask {mask_ratio}", "ms": round(t * 1e3, 3),
-            "algorithmic_bytes": algo, "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs * 1e9 / HBM_PEAK, 4),
-            "flop": flop_pv * B, "achieved_TFLOPs": round(flop_pv * B / t / 1e12, 2)}
+    out = {"what": f"student sparse-encoder forward, STUNet-{size} {patch}^3 bf16, mask {mask_ratio}", "ms": round(t * 1e3, 3),
+           "algorithmic_bytes": algo, "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs * 1e9 / HBM_PEAK, 4),
+           "flop": flop_pv * B, "achieved_TFLOPs": round(flop_pv * B / t / 1e12, 2)}
+    if size == "B":
+        # the same forward in COUNTED bytes: rocprofv3 FETCH_SIZE + WRITE_SIZE over its launches (tools/enc_traffic.py on this round's tree,
+        # committed under profiles/; linear in the batch).  A missing file is an error, not a constant.
+        rec = json.load(open(os.path.join(ROOT, ENC_TRAFFIC_JSON)))
+        counted = rec["counted_bytes"] * B / rec["batch"]
+        out.update(counted_bytes=counted, counted_GBps=round(counted / t / 1e9, 1), counted_frac=round(counted / t / HBM_PEAK, 4),
+                   counted_source=f"{ENC_TRAFFIC_JSON} ({rec['launches']} launches at B={rec['batch']}: {rec['counted_bytes'] / rec['algorithmic_bytes']:.2f} x the algorithmic bytes)")
+    return out
 
 
 def cpu_baseline(state_dict_cpu, spec_kw):

@@ -1,7 +1,9 @@
 """HBM traffic of the student sparse-encoder forward from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE runs of
 tools/encoder_profile.py, kernel trace only beside them; MI355X_MICROARCH.md "HBM": both counters are in KB, FETCH_SIZE reports half of
 the bytes of wide coalesced reads on gfx950 and is doubled here).
-usage: python tools/enc_traffic.py <fetch dir> <write dir> <batch> [size B|L|H] [patch] [mask ratio]"""
+usage: python tools/enc_traffic.py <fetch dir> <write dir> <batch> [size B|L|H] [patch] [mask ratio] [json out]
+(json out: {"batch", "fetch_bytes", "write_bytes", "counted_bytes", "algorithmic_bytes", "launches"} per forward -- what bench.py reads for
+`encoder_fwd_hbm.counted_bytes`)"""
 import collections
 import csv
 import glob
@@ -52,3 +54,10 @@ for k, (c, f, w) in sorted(fam.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
 print(f"| **total** | {n} | **{tot_f / 1e6:.1f}** | **{tot_w / 1e6:.1f}** |\n")
 print(f"fetched + written = {(tot_f + tot_w) / 1e9:.3f} GB per forward = {(tot_f + tot_w) / algo:.2f} x the algorithmic {algo / 1e9:.3f} GB "
       f"(SURVEY.md 8d: {per_vol / 1e6:.1f} MB per volume).")
+
+if len(sys.argv) > 7:
+    import json
+    json.dump({"size": SIZE, "patch": int(PATCH), "mask_ratio": float(MR), "batch": B, "launches": n, "fetch_bytes": tot_f, "write_bytes": tot_w,
+               "counted_bytes": tot_f + tot_w, "algorithmic_bytes": algo,
+               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/encoder_profile.py, FETCH_SIZE doubled (gfx950), KB = 1024 B; mean of the last 8 forwards"},
+              open(sys.argv[7], "w"), indent=1)

@@ -31,7 +31,7 @@ lines = ["# Counters of the dominant kernels at the bench batch (conv 64->64 k3 
          "# (FETCH_SIZE / WRITE_SIZE are in KB = 1024 B; FETCH_SIZE counts half of the bytes of wide coalesced reads on gfx950 and is doubled: MI355X_MICROARCH.md \"HBM\")", "",
          "| kernel | avg launch (`--kernel-trace --stats`) | fetched (2 x FETCH_SIZE) | written | traffic / algorithmic | matrix pipe busy | LDS array busy | LDS conflict cycles / LDS cycles | clock |", "|---|---|---|---|---|---|---|---|---|"]
 js = {}
-for sub in ("conv_k3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel"):
+for sub in ("conv_k3_kernel", "conv_igemm_kernel", "conv_wgrad_kernel", "wgrad_k3_kernel"):
     names = [k for k in st if sub in k]
     if not names:
         continue
