@@ -722,6 +722,11 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
     if (getenv("AM_CV_NORW")) goto generic;
 #endif
     a.plist = nullptr;
+    if (!in_scale && mode == AM_CONVT_FWD && !partials) {   // dense transposed convs at decoder sizes: the persistent kernel's transposed instantiation
+      const int rt = conv_k3t_launch(mode, dtype, ksize, stride, a, stream);
+      if (rt < 0) return rt;
+      if (rt == 1) return 0;
+    }
     if (!in_scale) {                               // dense k3 s1 at decoder sizes: the persistent LDS-DMA kernel (conv_k3.hip)
       const int rk = conv_k3_launch(mode, dtype, ksize, stride, a, stream);
       if (rk < 0) return rk;

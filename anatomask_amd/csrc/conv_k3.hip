@@ -71,7 +71,7 @@ template <typename P> __device__ __forceinline__ P* k3_uni_ptr(P* p) {
 }
 
 // (unit, slab) + the unit's brick / channel tile, packed (all wave-uniform: these live in SGPRs across the whole walk)
-struct Item { int u, k, c0, c1; };                  // c0 = bw | bh << 8 | bd << 16 (brick indices), c1 = b | ytile << 8
+struct Item { int u, k, c0, c1, p; };               // c0 = bw | bh << 8 | bd << 16 (brick indices), c1 = b | ytile << 8; p (transposed conv): output parity class pd << 2 | ph << 1 | pw
 #define IT_Q0W(it) (((it).c0 & 255) * KBW)
 #define IT_Q0H(it) ((((it).c0 >> 8) & 255) * KBH)
 #define IT_Q0D(it) ((((it).c0 >> 16) & 255) * KBD)
@@ -80,11 +80,21 @@ struct Item { int u, k, c0, c1; };                  // c0 = bw | bh << 8 | bd <<
 
 // EP: the fused store epilogue (eval-mode BatchNorm scale / shift, skip tensor, activation: the teacher's decoder) is its own instantiation --
 // its scale / shift registers would push the plain kernel over 256.  ST: the statistics rows (16 more registers), likewise
-template <int NS, bool EP, bool ST>
+// CT: ConvTranspose3d k4 s2 p1 (P/decoder3D.py:17 `up_sample`) on the same skeleton.  Output voxel 2 q + p of parity class p = (pd, ph, pw)
+// is a 2 x 2 x 2-tap convolution over the coarse grid -- per axis the shifts {p - 1, p} of the k3 window, kernel index 3 - 2 z + p for window
+// position z in {p, p + 1} -- so the SAME haloed 10 x 6 x 18 source brick serves all eight classes: a workgroup walks (brick, channel tile)
+// units and, inside one, the classes x slabs; a "run" is one (d, w) shift with its TWO h-taps (5 shared fragment rows, 32 MFMAs), four
+// runs per (class, slab).  With two slabs (Cin = 64) both stay resident in the two slab buffers for all eight classes: the brick is
+// fetched ONCE for 64 taps (conv_igemm.hip gives every class its own workgroup and its own copy: that launch ran at the CU's fill rate).
+// A class's 8 x 4 x 16 outputs leave as 16-byte stores two voxels apart (the other classes' voxels lie between them).
+template <int NS, bool EP, bool ST, bool CT = false>
 __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   static_assert(NS == 4 || NS == 2, "64- or 32-channel output tiles (NS = 2: the decoder's last conv, C -> C / 2 = 32 at STUNet-B; a wave then owns 8 accumulator tiles)");
   constexpr int VS = 4, NT = 16 * NS;
   constexpr int NCH = VS * NS / 2;                  // 16-byte store chunks per lane and unit
+  constexpr int NRUN = CT ? 4 : 9;                  // runs per (unit, slab) item; taps per run: 2 / 3
+  constexpr int NTR = CT ? 2 : 3;
+  static_assert(!CT || (NS == 4 && !EP && !ST), "transposed conv: 64-channel tiles, plain epilogue (bias)");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,10 +115,12 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   };
   auto advance = [&](Item& it) {
     if (it.k + 1 < a.nslab) { ++it.k; return; }
-    it.k = 0; it.u += G;
+    it.k = 0;
+    if (CT && it.p < 7) { ++it.p; return; }           // (transposed conv: the eight parity classes of the brick, then the next brick)
+    it.p = 0; it.u += G;
     if (it.u < a.nunit) decode(it);
   };
-  Item cur; cur.u = gperm; cur.k = 0;
+  Item cur; cur.u = gperm; cur.k = 0; cur.p = 0;
   if (cur.u >= a.nunit) return;
   decode(cur);
   Item nxt = cur; advance(nxt);
@@ -147,11 +159,14 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   // ---- DMA issue (weights: X waves; brick pieces: Y waves)
   auto issue_weights = [&](const Item& it, const int run, const int slot) __attribute__((always_inline)) {
     // run = zd * 3 + xw; its taps th = 0..2 are the h-shifts; X wave wq brings cout tile wq of each tap
-    const int zd = run / 3, xw = run - zd * 3;
+    // (transposed conv: run = 2 (zd - pd) + (xw - pw) over window positions z in {p, p + 1} per axis, two h-taps; kernel index 3 - 2 z + p)
+    const int pd_ = (it.p >> 2) & 1, ph_ = (it.p >> 1) & 1, pw_ = it.p & 1;
+    const int zd = CT ? pd_ + (run >> 1) : run / 3, xw = CT ? pw_ + (run & 1) : run - (run / 3) * 3;
     if (wq >= NS) return;                              // (NS = 2: waves 0, 1 bring the two cout tiles)
 #pragma unroll
-    for (int th = 0; th < 3; ++th) {
-      const int t = zd * 9 + th * 3 + xw, widx = a.flip ? 26 - t : t;
+    for (int th = 0; th < NTR; ++th) {
+      const int t = zd * 9 + th * 3 + xw;
+      const int widx = CT ? ((3 - 2 * zd + pd_) * 4 + (3 - 2 * (ph_ + th) + ph_)) * 4 + (3 - 2 * xw + pw_) : (a.flip ? 26 - t : t);
       const unsigned so = (unsigned)(widx * wtapB + ((IT_CO0(it) + (wq >> 1) * 32 + (wq & 1) * 4) * a.Cinp + it.k * 32) * 2);
 #ifdef AM_ABLATE
       if (a.dbg & 4) continue;
@@ -230,13 +245,17 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   // opens the next unit, and its 8 store instructions (+ the statistics of those values) go out one per L phase over the next unit's first
   // 8 runs -- issued back to back they drain at ~12 B/clk/CU (2 700 cycles per unit and wave half, with the other half's MFMAs waiting at
   // the barrier: 13 % of the kernel).
-  const unsigned olane = (unsigned)((r16 * a.Cout + g * 8) * 2);
-  const unsigned orow = (unsigned)(a.W * a.Cout * 2);
+  const unsigned olane = (unsigned)((r16 * (CT ? 2 : 1) * a.Cout + g * 8) * 2);      // (transposed conv: a class's voxels are two apart)
+  const unsigned orow = (unsigned)((CT ? 4 : 1) * a.W * a.Cout * 2);                 // (... and two rows of the 2 W wide fine grid)
   u32x4 pk[VS][NS / 2];
   long long pk_off = 0;                                  // element offset of the pending unit's first output voxel of this wave (wave-uniform)
-  auto finish_unit = [&](const int pc0, const int pc1) __attribute__((always_inline)) {
+  auto finish_unit = [&](const int pc0, const int pc1, const int pcls) __attribute__((always_inline)) {
     Item it; it.c0 = pc0; it.c1 = pc1;
     const int co0 = IT_CO0(it);
+    if constexpr (CT)                                      // fine voxel 2 q + p of the 2D x 2H x 2W output
+      pk_off = ((((long long)IT_B(it) * (2 * a.D) + (2 * (IT_Q0D(it) + wave) + ((pcls >> 2) & 1))) * (2 * a.H) + (2 * IT_Q0H(it) + ((pcls >> 1) & 1))) * (2 * a.W) +
+                (2 * IT_Q0W(it) + (pcls & 1))) * (long long)a.Cout + co0;
+    else
     pk_off = ((((long long)IT_B(it) * a.D + (IT_Q0D(it) + wave)) * a.H + IT_Q0H(it)) * a.W + IT_Q0W(it)) * (long long)a.Cout + co0;
     // per-channel constants from the LDS table (global loads here would put a `vmcnt` wait into this phase)
     f32x4 bia[NS], esc[NS], esh[NS];
@@ -351,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
 #define K3_STAMP(ACC)
 #endif
   int par = 0, sb = 0;                                   // weight slot of the current run, slab buffer of the current item
-  int pc0 = 0, pc1 = 0; bool have_prev = false;         // the finished unit whose epilogue is due
+  int pc0 = 0, pc1 = 0, pcls = 0; bool have_prev = false;   // the finished unit (transposed conv: and class) whose epilogue is due
   bool spend = false;                                    // its 8 stores are pending: one per L phase of this slab's runs 0..7
 #pragma unroll
   for (int i = 0; i < NS; ++i)
@@ -360,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   while (true) {
     spend = false;
     if (cur.k == 0 && have_prev) {
-      finish_unit(pc0, pc1);                             // (also zeroes the accumulators)
+      finish_unit(pc0, pc1, pcls);                       // (also zeroes the accumulators)
       spend = true;
       K3_STAMP(tE);
     }
@@ -368,32 +387,51 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
     int bxc[3];
 #pragma unroll
     for (int xw = 0; xw < 3; ++xw) bxc[xw] = bx[xw] + sb * KBRICKB;
+    // (transposed conv) does the next item's slab have to be fetched?  With two slabs both stay in the two buffers for the brick's eight
+    // classes (slab k in buffer k: sixteen items per brick keep the parity); only a new brick brings new bytes
+    const bool fetch_next = has_next && (!CT || a.nslab != 2 || nxt.p == 0);
+    const int cpd = (cur.p >> 2) & 1, cph = (cur.p >> 1) & 1, cpw = cur.p & 1;
 #pragma unroll
-    for (int run = 0; run < 9; ++run) {
-      const int zd = run / 3, xw = run % 3;
+    for (int run = 0; run < NRUN; ++run) {
+      const int zd = run / 3, xw = run % 3;              // (k3; the transposed conv's window position is runtime: class parity + run bits)
       // ---------------- L: fragments of this run from LDS, DMA issue for later runs
       u32x4 brow[VS + 2], af[3][NS];
       const int wbase = KLDS_W + par * KWSLOT + aoff;
+      if constexpr (CT) {
+        const int zq = cpd + (run >> 1), xq = cpw + (run & 1);
+        const int bsel = (xq == 0 ? bxc[0] : (xq == 1 ? bxc[1] : bxc[2])) + (zq * KPLANE + cph * KEW) * 64;
+#pragma unroll
+        for (int r = 0; r < VS + 1; ++r) brow[r] = *(const u32x4*)(lds + bsel + r * KEW * 64);
+      } else {
 #pragma unroll
       for (int r = 0; r < VS + 2; ++r) brow[r] = *(const u32x4*)(lds + bxc[xw] + (zd * KPLANE + r * KEW) * 64);
+      }
 #pragma unroll
-      for (int th = 0; th < 3; ++th)
+      for (int th = 0; th < NTR; ++th)
 #pragma unroll
         for (int i = 0; i < NS; ++i) af[th][i] = *(const u32x4*)(lds + wbase + th * (NT * 64) + i * 1024);
       // DMA issue.  X: W(run + 1) into the slot Y finished reading one slot ago (it has this phase and the M phase that follows to land),
       // then its share of the next slab (9 pieces over runs 0..7), then a deferred store.  Y: a deferred store, then its share of the next
       // slab (8 pieces over runs 0..6; retired at the end of M(7): X reads that slab two time slots later).
-      const int pk0 = run == 0 ? 0 : (run == 1 ? 1 : run + 1);          // first piece of this phase: 0 | 1 2 | 3 | 4 | ...
-      const int npx = run == 1 ? 2 : (run < 8 ? 1 : 0);                 // pieces X issues in this phase (9 in all, the last in run 7)
-      const int npy = run == 1 ? 2 : (run < 7 ? 1 : 0);                 // pieces Y issues (8 in all, the last in run 6)
+      // (transposed conv, 4 runs per item: X 3 + 3 + 3 pieces over runs 0..2, Y 4 + 4 over runs 0, 1; the 8 deferred stores two per run)
+      const int pk0 = CT ? (isX ? 3 * run : 4 * run) : (run == 0 ? 0 : (run == 1 ? 1 : run + 1));          // first piece of this phase: 0 | 1 2 | 3 | 4 | ...
+      const int npx = CT ? (run < 3 ? 3 : 0) : (run == 1 ? 2 : (run < 8 ? 1 : 0));                 // pieces X issues in this phase (9 in all, the last in run 7)
+      const int npy = CT ? (run < 2 ? 4 : 0) : (run == 1 ? 2 : (run < 7 ? 1 : 0));                 // pieces Y issues (8 in all, the last in run 6)
+      constexpr int SPR = CT ? 2 : 1;                                   // deferred stores per L phase
       if (isX) {
-        if (run < 8) issue_weights(cur, run + 1, par ^ 1);
+        if (run < NRUN - 1) issue_weights(cur, run + 1, par ^ 1);
         else if (has_next) issue_weights(nxt, 0, par ^ 1);
-        if (has_next && npx > 0) issue_pieces(nxt, sb ^ 1, pk0, pk0 + npx);
-        if (spend && run < NCH) store_chunk(run, false); // (behind the weights: the counted wait below leaves it in flight)
+        if (fetch_next && npx > 0) issue_pieces(nxt, sb ^ 1, CT ? 3 * run : pk0, (CT ? 3 * run : pk0) + npx);
+        if (spend && run * SPR < NCH) {                  // (behind the weights: the counted wait below leaves them in flight)
+#pragma unroll
+          for (int q = 0; q < SPR; ++q) store_chunk(run * SPR + q, false);
+        }
       } else {
-        if (spend && run < NCH) store_chunk(run, false);
-        if (has_next && npy > 0) issue_pieces(nxt, sb ^ 1, pk0, pk0 + npy);
+        if (spend && run * SPR < NCH) {
+#pragma unroll
+          for (int q = 0; q < SPR; ++q) store_chunk(run * SPR + q, false);
+        }
+        if (fetch_next && npy > 0) issue_pieces(nxt, sb ^ 1, CT ? 4 * run : pk0, (CT ? 4 * run : pk0) + npy);
       }
       // ONE barrier per run and wave.  Between two barriers X runs [L(n) M(n)] and Y runs [M(n - 1) L(n)]: X fetches while Y multiplies, then
       // the other way round.  What the barrier orders: every X wave's weights of run n + 1 have landed (its counted `vmcnt` wait sits in front
@@ -412,7 +450,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       if (!(a.dbg & 8))
 #endif
 #pragma unroll
-      for (int th = 0; th < 3; ++th)
+      for (int th = 0; th < NTR; ++th)
 #pragma unroll
         for (int j = 0; j < VS; ++j)
 #pragma unroll
@@ -424,13 +462,15 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       // deferred store); at the end of M(8) the whole next slab.  Y: at the end of M(7) its share of the next slab (a store issued in L(7) is
       // the youngest operation and stays in flight).
       if (isX) {
-        const int nbehind = (has_next ? npx : 0) + ((spend && run < NCH) ? 1 : 0);
+        const int nbehind = (fetch_next ? npx : 0) + ((spend && run * SPR < NCH) ? SPR : 0);
         if (nbehind == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (nbehind == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else if (nbehind == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      } else if (run == 7) {
-        if (spend && 7 < NCH) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (nbehind == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (nbehind == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      } else if (run == NRUN - 2) {                      // (Y's last pieces went out a run or more ago; the stores of this run's L phase are the youngest operations)
+        if (spend && run * SPR < NCH) { if (SPR == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       K3_STAMP(tM);
@@ -441,11 +481,11 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       par ^= 1;
     }
     sb ^= 1;
-    if (cur.k + 1 == a.nslab) { pc0 = cur.c0; pc1 = cur.c1; have_prev = true; }
+    if (cur.k + 1 == a.nslab) { pc0 = cur.c0; pc1 = cur.c1; pcls = cur.p; have_prev = true; }
     if (!has_next) break;
     cur = nxt; advance(nxt);
   }
-  finish_unit(pc0, pc1);
+  finish_unit(pc0, pc1, pcls);
 #pragma unroll
   for (int c = 0; c < NCH; ++c) store_chunk(c, true);
   if (want_stats) flush_stats((pc1 >> 8) * NT);
@@ -530,6 +570,39 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
     (void)hipFuncSetAttribute((const void*)conv_k3_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
   });
+  AM_LAUNCH(kern, dim3(G), dim3(512), KLDS, (hipStream_t)stream, a);
+  AM_CHECK_LAUNCH();
+  return 1;
+}
+
+// ConvTranspose3d k4 s2 p1 (bf16, dense): 1 = served by the persistent kernel's transposed instantiation, 0 = does not qualify
+int conv_k3t_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void* stream) {
+  if (mode != AM_CONVT_FWD || dtype != AM_DT_BF16 || ksize != 4 || stride != 2 || c.in_mask.m || c.out_mask.m) return 0;
+  if (c.accumulate || c.nb_x || c.partials || c.ep_scale || c.ep_res || c.ep_act != AM_ACT_NONE) return 0;
+  if (c.Cin % 32 || c.Cin < 64 || c.Cout % 64 || c.Di % KBD || c.Hi % KBH || c.Wi % KBW) return 0;      // (>= 2 slabs: the deferred stores of a class ride in the next one's first item)
+  if (c.Do != 2 * c.Di || c.Ho != 2 * c.Hi || c.Wo != 2 * c.Wi) return 0;
+  if (c.B > 255 || c.Di / KBD > 255 || c.Hi / KBH > 255 || c.Wi / KBW > 255) return 0;
+  if ((size_t)(KED + 1) * c.Hi * c.Wi * c.Cin * 2 >= 0x7fffff00ull || (size_t)16 * c.Wo * c.Cout * 2 >= 0x7fffff00ull) return 0;
+  int units;
+  const int G = k3_grid(c.B, c.Di, c.Hi, c.Wi, c.Cout, &units);          // units = bricks x channel tiles (the eight classes live inside a unit)
+  if (units < K3_MIN_UNITS) return 0;
+#ifdef AM_ABLATE
+  { const char* e_ = getenv("AM_CV_NOK3T"); if (e_ && atoi(e_)) return 0; }
+#endif
+  K3Args a;
+  a.x = (const bf16_t*)c.x; a.w = (const bf16_t*)c.w; a.bias = c.bias; a.y = (bf16_t*)c.y; a.partials = nullptr;
+  a.ep_scale = nullptr; a.ep_shift = nullptr; a.ep_res = nullptr; a.ep_act = AM_ACT_NONE;
+  a.B = c.B; a.D = c.Di; a.H = c.Hi; a.W = c.Wi; a.Cin = c.Cin; a.Cout = c.Cout; a.Cinp = c.Cinp; a.Coutp = c.Coutp;
+  a.nbd = c.Di / KBD; a.nbh = c.Hi / KBH; a.nbw = c.Wi / KBW; a.ny = c.Cout / 64; a.nunit = units; a.nslab = c.Cinp / 32;
+  a.flip = 0;
+  a.nt_store = (size_t)c.B * c.Do * c.Ho * c.Wo * c.Cout * 2 >= ((size_t)384 << 20);
+  a.w_bytes = (unsigned)c.w_bytes;
+#ifdef AM_ABLATE
+  { const char* e = getenv("AM_K3_DBG"); a.dbg = e ? atoi(e) : 0; }
+#endif
+  auto kern = conv_k3_kernel<4, false, false, true>;
+  static PerDeviceOnce lds_cap;
+  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
   AM_LAUNCH(kern, dim3(G), dim3(512), KLDS, (hipStream_t)stream, a);
   AM_CHECK_LAUNCH();
   return 1;

@@ -150,5 +150,6 @@ int conv_gather_rows(int mode, int dtype, int ksize, int stride, int B, int Do, 
 // does not qualify; conv_k3_rows = the partial-sum rows such a launch writes (8 per workgroup), or 0
 int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a, void* stream);
 int conv_k3_rows(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cin, int Cout, int masks);
+int conv_k3t_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void* stream);   // ConvTranspose3d k4 s2 p1 on the same kernel
 
 }  // namespace amconv

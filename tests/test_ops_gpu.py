@@ -502,6 +502,33 @@ def test_conv_k3_persistent_kernel_is_deterministic(ops):
     assert torch.equal(y1, y2) and torch.equal(p1.t[:p1.rows], p2.t[:p2.rows])
 
 
+@pytest.mark.parametrize("case", [(64, 64, (32, 32, 32), 4), (128, 64, (16, 32, 32), 8), (64, 128, (32, 16, 32), 4), (64, 64, (8, 4, 16), 255)])
+def test_conv_transpose_persistent_kernel(ops, case):
+    """ConvTranspose3d k4 s2 p1 (P/decoder3D.py:17) on the persistent 8-wave LDS-DMA kernel's transposed instantiation (conv_k3.hip, CT):
+    the eight output parity classes of a coarse brick from ONE staged copy of it.  Against F.conv_transpose3d on the same bf16-rounded
+    operands, bias included: two slabs (both resident for the eight classes), four slabs (re-fetched per class), two channel tiles, and a
+    grid of single-brick samples (every brick is a border brick on all six faces)."""
+    cin, cout, S, B = case
+    dtype = torch.bfloat16
+    x = q(rnd(B, cin, *S, seed=601), dtype)
+    w = q(rnd(cin, cout, 4, 4, 4, seed=602, scale=1.0 / np.sqrt(cin * 8)), dtype)
+    bias = rnd(cout, seed=603)
+    fine = tuple(2 * v for v in S)
+    ref = F.conv_transpose3d(x, w, bias, stride=2, padding=1)
+    y = ops.conv3d(ops.CONVT_FWD, to_cl(x, dtype), ops.pack_weight(w.to(DEV), dtype, True, False), bias.to(DEV), fine, 4, 2)
+    close(from_cl(y), ref, TOL[dtype], "convT (persistent kernel)")
+    # every parity class separately (a wrong kernel index in one class hides behind the maximum of the others)
+    got = from_cl(y)
+    for pd in range(2):
+        for ph in range(2):
+            for pw in range(2):
+                a_, b_ = got[:, :, pd::2, ph::2, pw::2], ref[:, :, pd::2, ph::2, pw::2]
+                assert (a_ - b_).abs().max().item() <= TOL[dtype] * b_.abs().max().item(), f"class {pd}{ph}{pw}"
+    # two launches: the same bits
+    y2 = ops.conv3d(ops.CONVT_FWD, to_cl(x, dtype), ops.pack_weight(w.to(DEV), dtype, True, False), bias.to(DEV), fine, 4, 2)
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("act", ["lrelu", "relu6", "none"])
 def test_conv_prenorm_fused_input_norm(ops, act):
     """am_conv3d_prenorm: conv(act(x * scale + shift)) with the norm + activation applied while the resident-weight kernel stages its

@@ -50,10 +50,10 @@ def conv3d(mode, x, w, bias, out_spatial, ksize, stride, in_mask=None, in_bshift
     return r
 
 
-def conv3d_wgrad(mode, x, dy, ksize, stride, x_mask=None, x_bshift=0, y_mask=None, y_bshift=0):
+def conv3d_wgrad(mode, x, dy, ksize, stride, x_mask=None, x_bshift=0, y_mask=None, y_bshift=0, **kwa):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = _wg(mode, x, dy, ksize, stride, x_mask, x_bshift, y_mask, y_bshift)
+    r = _wg(mode, x, dy, ksize, stride, x_mask, x_bshift, y_mask, y_bshift, **kwa)
     e1.record()
     Bq, Dx, Hx, Wx, Cx = x.shape
     _, Dy, Hy, Wy, Cy = dy.shape

@@ -48,12 +48,12 @@ def conv3d(mode, x, wp, bias, out_spatial, ksize, stride, in_mask=None, in_bshif
     return timed(lambda: _c(mode, x, wp, bias, out_spatial, ksize, stride, in_mask, in_bshift, out_mask, out_bshift, **k), key, fl)
 
 
-def conv3d_wgrad(mode, x, dy, ksize, stride, x_mask=None, x_bshift=0, y_mask=None, y_bshift=0):
+def conv3d_wgrad(mode, x, dy, ksize, stride, x_mask=None, x_bshift=0, y_mask=None, y_bshift=0, **kwa):
     taps = ksize ** 3
     nv = dy.numel() // dy.shape[-1] if mode == ops.CONV_FWD else x.numel() // x.shape[-1]
     fl = 2.0 * nv * x.shape[-1] * dy.shape[-1] * (taps if mode == ops.CONV_FWD else 8) * frac(x_mask or y_mask)
     key = f"wgrad{'T' if mode != ops.CONV_FWD else ' '} k{ksize}s{stride} {x.shape[-1]:3d}x{dy.shape[-1]:3d} dy{dy.shape[1]:3d} {'sparse' if (x_mask or y_mask) else 'dense '}"
-    return timed(lambda: _w(mode, x, dy, ksize, stride, x_mask, x_bshift, y_mask, y_bshift), key, fl)
+    return timed(lambda: _w(mode, x, dy, ksize, stride, x_mask, x_bshift, y_mask, y_bshift, **kwa), key, fl)
 
 
 ops.conv3d, ops.conv3d_wgrad = conv3d, conv3d_wgrad
