@@ -245,7 +245,16 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   // opens the next unit, and its 8 store instructions (+ the statistics of those values) go out one per L phase over the next unit's first
   // 8 runs -- issued back to back they drain at ~12 B/clk/CU (2 700 cycles per unit and wave half, with the other half's MFMAs waiting at
   // the barrier: 13 % of the kernel).
-  const unsigned olane = (unsigned)((r16 * (CT ? 2 : 1) * a.Cout + g * 8) * 2);      // (transposed conv: a class's voxels are two apart)
+  // 64-channel tiles: a voxel's 128 bytes are one cache line whose two 64-byte halves (channel groups h = 0, 1) sit in the SAME lanes'
+  // registers pk[j][0], pk[j][1] -- stored as they are, every store instruction would write HALF of 16 lines (round 4: 5.05 GB written for a
+  // 4.29 GB output).  The lanes of a 16-lane row swap halves through one DPP rotation (row_ror:8) per register, so that store h of a row
+  // writes the 8 voxels 8 h .. 8 h + 7 COMPLETELY: lane (r16, g) sends chunk 4 (r16 >> 3) + g of voxel 8 h + (r16 & 7).
+  constexpr bool FULL = NS == 4;
+  const bool lo8 = r16 < 8;
+  const unsigned olane = FULL ? (unsigned)(((r16 & 7) * (CT ? 2 : 1) * a.Cout + (r16 >> 3) * 32 + g * 8) * 2)
+                              : (unsigned)((r16 * (CT ? 2 : 1) * a.Cout + g * 8) * 2);      // (transposed conv: a class's voxels are two apart)
+  const unsigned ohalf = (unsigned)(8 * (CT ? 2 : 1) * a.Cout * 2);                      // FULL: voxels 8 .. 15 of the row (store h = 1)
+  const unsigned olane_own = (unsigned)((r16 * (CT ? 2 : 1) * a.Cout + g * 8) * 2);      // the lane's OWN voxel r16, chunk g (+ 64 h): the skip tensor is read in accumulator layout
   const unsigned orow = (unsigned)((CT ? 4 : 1) * a.W * a.Cout * 2);                 // (... and two rows of the 2 W wide fine grid)
   u32x4 pk[VS][NS / 2];
   long long pk_off = 0;                                  // element offset of the pending unit's first output voxel of this wave (wave-uniform)
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
 #pragma unroll
       for (int j = 0; j < VS; ++j)
 #pragma unroll
-        for (int h = 0; h < NS / 2; ++h) pk[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rr, olane, j * orow + h * 64, 0);
+        for (int h = 0; h < NS / 2; ++h) pk[j][h] = __builtin_amdgcn_raw_buffer_load_b128(rr, olane_own, j * orow + h * 64, 0);
     }
 #pragma unroll
     for (int j = 0; j < VS; ++j) {
@@ -311,14 +320,29 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
     if (!(a.dbg & 1))
 #endif
     {
-      if (a.nt_store) __builtin_amdgcn_raw_buffer_store_b128(pk[j][h], ry, olane, j * orow + h * 64, 2);
-      else __builtin_amdgcn_raw_buffer_store_b128(pk[j][h], ry, olane, j * orow + h * 64, 0);
+      u32x4 sv = pk[j][h];
+      unsigned so_ = (unsigned)(j * orow + h * 64);
+      if constexpr (FULL) {
+        // what the partner lane (r16 ^ 8) holds of the OTHER half: store 0 takes its h = 1 chunk of voxels 0 .. 7, store 1 its h = 0 chunk of 8 .. 15
+        const u32x4 ot = pk[j][h ^ 1];
+        u32x4 rx_;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rx_[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ot[e], 0x128, 0xF, 0xF, false);
+        const bool own = h == 0 ? lo8 : !lo8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sv[e] = own ? sv[e] : rx_[e];
+        so_ = (unsigned)(j * orow) + (h ? ohalf : 0u);
+      }
+      if (a.nt_store) __builtin_amdgcn_raw_buffer_store_b128(sv, ry, olane, so_, 2);
+      else __builtin_amdgcn_raw_buffer_store_b128(sv, ry, olane, so_, 0);
       // A 16-byte store's data registers must not be rewritten in the next cycles.  hipcc inserts the wait states only for stores whose
       // soffset is an immediate; with the row offset in an SGPR (chunks 2..5) it emits none, and the TAIL flush -- convert, store, convert
       // into the same registers -- stored corrupted values in ~7 % of those chunks (found by tools/k3_check.py: NaNs in the last unit of
       // every workgroup, rows 1 and 2 of each plane, plain instantiation only: the others have statistics code between two stores).
       // (the asm holds the data registers live across the wait states: nothing can be scheduled into them in between)
-      if (tail) asm volatile("s_nop 4" : "+v"(pk[j][h]) :: "memory");
+      // (FULL: the store's data is a temporary -- the select of own / partner words -- whose registers the next chunk's select may take at once;
+      // the transposed instantiation issues two stores back to back: the same hazard in every phase, not only in the tail)
+      if (tail || FULL) asm volatile("s_nop 4" : "+v"(sv) :: "memory");
     }
     if (want_stats) {
       // the STORED values: words 0, 1 = channels 0..3 of tile 2h (rows r), words 2, 3 = those of tile 2h + 1.  A lane keeps the tile of its
