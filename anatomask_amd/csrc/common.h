@@ -100,6 +100,18 @@ __device__ __forceinline__ void split4_bf16(const u32x4& c, unsigned (&hi)[2], u
     lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{r0, r1}), bfx2_));
   }
 }
+// eight floats -> one 16-byte MFMA fragment of their bf16 hi parts and one of their lo parts (element j in half-word j)
+__device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4& hi, u32x4& lo) {
+  typedef __attribute__((ext_vector_type(2))) float f32x2_;
+  typedef __attribute__((ext_vector_type(2))) __bf16 bfx2_;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{v[2 * i], v[2 * i + 1]}), bfx2_));
+    const float r0 = v[2 * i] - __uint_as_float(h << 16), r1 = v[2 * i + 1] - __uint_as_float(h & 0xffff0000u);
+    hi[i] = h;
+    lo[i] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_{r0, r1}), bfx2_));
+  }
+}
 // One chunk MMA of the split mode: the 64-byte LDS row of 16 fp32 channels is [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] (bf16); lane group g
 // supplies chunk g of the A row, chunk (g & 1) of the B row for b1 (hi) and chunk 2 + (g & 1) for b2 (lo):
 //   sum_g A_g . B1_g = (hiA + loA) . hiB,   sum_g A_g . B2_g = (hiA + loA) . loB

@@ -941,10 +941,14 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const float* __restr
 
 // ------------------------------------------------------------------ stem k3 on the matrix cores (bf16 storage mode)
 // The Cin = 1 stem is a [voxels x 27] x [27 x C] product: K = 27 taps padded to the 32 of one v_mfma_f32_16x16x32_bf16.  One
-// workgroup owns one ACTIVE 16^3 patch (active-patch list): the haloed 18^3 input patch is staged once into LDS as bf16 with the
+// workgroup owns one ACTIVE 16^3 patch (active-patch list): the haloed 18^3 input patch is staged once into LDS (fp32) with the
 // patch mask and the volume bounds applied, the weights live in registers as MFMA A-fragments for the whole kernel, and per
-// 16-voxel w-row a lane gathers the 8 taps of its k-group from LDS (8 two-byte reads), issues C/16 MFMAs, adds the bias and
-// stores 8 consecutive channels (16 bytes; a wave writes 1 KB runs).  The VALU form (stem_conv_fwd_kernel) spends 27 LDS reads and
+// 16-voxel w-row a lane gathers the 8 taps of its k-group from LDS (8 four-byte reads), issues 3 C/16 MFMAs, adds the bias and
+// stores 8 consecutive channels (16 bytes; a wave writes 1 KB runs).
+// The input VOLUME and the stem weights are not bf16-storage tensors (C = 1 input, fp32 master weights; oracle._qw): both enter the
+// matrix cores as hi + lo bf16 parts (w_lo x_hi + w_hi x_lo + w_hi x_hi: 16 significant bits per operand).  A plain bf16 rounding of
+// the volume (round 3-4) perturbed a smooth CT-like input by as much as its local differences, and the stem weight's gradient sat at
+// 1.7 x the ideal emulation's distance from fp32 (profiles/r05_experiments.md section 7).  The VALU form (stem_conv_fwd_kernel) spends 27 LDS reads and
 // 216 FMAs per voxel-chunk and runs at 24 TFLOP/s (450 us for 430 MB of output); this one is bound by its output stream.
 // One partials row per patch (the VALU kernel leaves one per 512-voxel brick, inactive ones included).
 template <int NS>
@@ -953,24 +957,24 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __rest
                                                              const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                              float* __restrict__ part) {
   constexpr int E = 18;                                          // haloed patch edge
-  __shared__ bf16_t xl[E * E * E + 8];
+  __shared__ float xl[E * E * E + 8];
   __shared__ float red[4 * 16 * NS * 2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   const int pk = plist[blockIdx.x];
   const int b = (pk >> 24) & 255, pd = (pk >> 16) & 255, ph = (pk >> 8) & 255, pw = pk & 255;
   const int d0 = pd * 16, h0 = ph * 16, w0 = pw * 16;
-  // ---- haloed patch -> LDS (bf16), zero outside the volume and in inactive neighbour patches
+  // ---- haloed patch -> LDS (fp32), zero outside the volume and in inactive neighbour patches
   for (int e = tid; e < E * E * E; e += 256) {
     const int ex = e % E, ey = (e / E) % E, ez = e / (E * E);
     const int id = d0 + ez - 1, ih = h0 + ey - 1, iw = w0 + ex - 1;
     float v = 0.f;
     if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && mask.active(b, id, ih, iw))
       v = x[((size_t)(b * D + id) * H + ih) * W + iw];
-    xl[e] = f2bf(v);
+    xl[e] = v;
   }
   // ---- weights -> A fragments (row R of tile i <-> channel crow(16 i + R): a lane ends up with 8 consecutive channels)
   typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
-  bfx8 af[NS];
+  bfx8 af[NS], afl[NS];                                         // hi / lo parts of the weights
   int toff[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -980,10 +984,12 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     const int ch = crow(i * 16 + r16);
-    s16x8 q;
+    float wv[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { const int t = 8 * g + j; q[j] = (short)f2bf(t < 27 ? w[ch * 27 + t] : 0.f); }
-    af[i] = __builtin_bit_cast(bfx8, q);
+    for (int j = 0; j < 8; ++j) { const int t = 8 * g + j; wv[j] = t < 27 ? w[ch * 27 + t] : 0.f; }
+    u32x4 h, l;
+    split8_bf16(wv, h, l);
+    af[i] = __builtin_bit_cast(bfx8, h); afl[i] = __builtin_bit_cast(bfx8, l);
   }
   f32x4 bia[NS];
 #pragma unroll
@@ -998,13 +1004,19 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __rest
   for (int row = wave; row < 256; row += 4) {
     const int dz = row >> 4, dy = row & 15;
     const int base = (dz * E + dy) * E + r16;                    // (d - 1 + td, h - 1 + th, w - 1 + tw) with the halo offset folded in
-    s16x8 q;
+    float xv[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) q[j] = (short)xl[base + toff[j]];
-    const bfx8 bf = __builtin_bit_cast(bfx8, q);
+    for (int j = 0; j < 8; ++j) xv[j] = xl[base + toff[j]];
+    u32x4 xh, xo;
+    split8_bf16(xv, xh, xo);
+    const bfx8 bf = __builtin_bit_cast(bfx8, xh), bfl = __builtin_bit_cast(bfx8, xo);
     f32x4 o[NS];
 #pragma unroll
-    for (int i = 0; i < NS; ++i) o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, bia[i], 0, 0, 0);
+    for (int i = 0; i < NS; ++i) {                               // small terms first
+      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[i], bf, bia[i], 0, 0, 0);
+      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfl, o[i], 0, 0, 0);
+      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, o[i], 0, 0, 0);
+    }
     const size_t vox = ((size_t)(b * D + d0 + dz) * H + h0 + dy) * W + w0 + r16;
     bf16_t* dst = y + vox * C + g * 8;
 #pragma unroll
@@ -1047,9 +1059,10 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(const float* __rest
 // dW[c][t] = sum_v dy[v][c] * xm[v + t - pad] is a [C x voxels] x [voxels x taps] product whose contraction index is the voxel:
 // M = channel, N = tap (27 taps + one column of ones that yields db, padded to 32; k1: centre tap + ones), K = 32 voxels (two
 // 16-voxel w-rows) per v_mfma_f32_16x16x32_bf16.  Persistent workgroups walk the active-patch list; per patch the haloed 18^3 input
-// patch sits in LDS as bf16 (the values the forward kernel multiplied), dy is staged one 16x16 d-plane at a time in padded rows and
+// patch sits in LDS as fp32 and enters the matrix cores as hi + lo bf16 parts (the values the forward kernel multiplied: 16
+// significant bits), dy is staged one 16x16 d-plane at a time in padded rows and
 // fetched as A-fragments with the transposing LDS read (ds_read_b64_tr_b16, as conv_wgrad.hip), the B-fragments (x at the lane's
-// tap, 8 voxels) are 8 two-byte LDS reads.  Accumulators live in registers over the whole walk; one flush of C x 28 atomics per
+// tap, 8 voxels) are 8 four-byte LDS reads split in registers.  Accumulators live in registers over the whole walk; one flush of C x 28 atomics per
 // workgroup.  The VALU form below re-stages x three times and runs at 5 TFLOP/s (1.2 ms per call at 128^3, B=8).
 __device__ __forceinline__ s16x4 tr_read16(const unsigned char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -1061,10 +1074,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
                                                               float* __restrict__ dw, float* __restrict__ db, float* __restrict__ det_ws) {
   constexpr int E = 18, C = 16 * NS, RS = 2 * C + 32;           // dy rows: C bf16 + 32 B pad (conflict-free transposing reads)
   constexpr int NTT = K == 3 ? 2 : 1, NTAP = K * K * K;
-  constexpr int XB = (E * E * E + 8) * 2;                        // bytes of the x patch (multiple of 16)
+  constexpr int XB = (E * E * E + 8) * 4;                        // bytes of the x patch (fp32; multiple of 16)
   constexpr int CPV = C / 8, NLD = CPV;                          // 16-byte chunks per voxel; loads per thread and d-plane (256 voxels)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  bf16_t* xl = (bf16_t*)lds;
+  float* xl = (float*)lds;
   unsigned char* yl = lds + XB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r16 = lane & 15;
   const int q = (lane >> 2) & 3, p = lane & 3;
@@ -1091,7 +1104,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
       float v = 0.f;
       if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W && mask.active(b, id, ih, iw))
         v = x[((size_t)(b * D + id) * H + ih) * W + iw];
-      xl[e] = f2bf(v);
+      xl[e] = v;
     }
     u32x4 ld[NLD];
     auto load_plane = [&](int dz) {
@@ -1125,16 +1138,21 @@ __global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __res
         const int xbase = (dz * E + 2 * s) * E + 4 * g;           // halo offset folded into the tap offsets
 #pragma unroll
         for (int n = 0; n < NTT; ++n) {
-          s16x8 qv;
+          float qv[8];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { qv[j] = (short)xl[xbase + toff[n] + j]; qv[4 + j] = (short)xl[xbase + toff[n] + E + j]; }
+          for (int j = 0; j < 4; ++j) { qv[j] = xl[xbase + toff[n] + j]; qv[4 + j] = xl[xbase + toff[n] + E + j]; }
           if (kind[n]) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qv[j] = kind[n] == 1 ? (short)0x3F80 : (short)0;
+            for (int j = 0; j < 8; ++j) qv[j] = kind[n] == 1 ? 1.f : 0.f;
           }
-          const bfx8 bf = __builtin_bit_cast(bfx8, qv);
+          u32x4 xh, xo;
+          split8_bf16(qv, xh, xo);
+          const bfx8 bf = __builtin_bit_cast(bfx8, xh), bfl = __builtin_bit_cast(bfx8, xo);
 #pragma unroll
-          for (int i = 0; i < NS; ++i) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+          for (int i = 0; i < NS; ++i) {
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfl, acc[i][n], 0, 0, 0);
+            acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf, acc[i][n], 0, 0, 0);
+          }
         }
       }
     }
@@ -2061,7 +2079,7 @@ int am_stem_conv_wgrad(int dtype, const float* x, const void* dy, int B, int D, 
         if (det_workspace_floats < det_row) return -6;
         if (nwg > det_workspace_floats / det_row) nwg = (int)(det_workspace_floats / det_row);
     }
-    const size_t sm = (size_t)(18 * 18 * 18 + 8) * 2 + (size_t)256 * (2 * C + 32);
+    const size_t sm = (size_t)(18 * 18 * 18 + 8) * 4 + (size_t)256 * (2 * C + 32);
 #define AM_STEM_WG(NS_, K_)                                                                                                           \
     {                                                                                                                                 \
       auto kern = stem_wgrad_mfma_kernel<NS_, K_>;                                                                                    \

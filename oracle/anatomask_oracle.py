@@ -300,7 +300,8 @@ def _q(t):
 
 
 def _qw(w, x):
-    """MFMA weight copy (bf16 in bf16 mode); Cin == 1 stem convs run on the fp32 VALU path with fp32 weights."""
+    """MFMA weight copy (bf16 in bf16 mode); the Cin == 1 stem convs see the fp32 volume and fp32 weights (on the matrix cores as
+    hi + lo bf16 parts: 16 significant bits per operand) -- neither is a bf16-storage tensor."""
     return _RoundBF16.apply(w) if (_STORAGE[0] == "bf16" and x.shape[1] > 1) else w
 
 
