@@ -27,6 +27,8 @@ BF16_LOSS, BF16_GNORM, BF16_L2 = 1e-4, 2e-2, 1.5e-4   # measured 3e-6 / 3e-5 / 1
 # further from fp32 than BF16_VS_EMU_FACTOR x the ideal bf16 emulation is (+ 0.05), and no further from the emulation than
 # BF16_PAIR_FACTOR x the emulation is from fp32 (+ 0.1) -- any two bf16 evaluations of this network differ by as much as either
 # differs from fp32 (measured medians, HIP-fp32 / emulation-fp32 / HIP-emulation: B 0.29 / 0.28 / 0.32, L 0.47 / 0.44 / 0.49, H 0.60 / 0.57 / 0.65)
+# Round 5 (STUNet-B 128^3, per tensor): HIP / emulation = 0.85 - 1.18 for all 92 tensors once the stem's volume stopped being rounded to bf16
+# (the stem weight had sat at 1.7 x = ON this bound: profiles/r05_experiments.md section 7); other summation orders move a tensor by 1 - 5 %.
 BF16_VS_EMU_FACTOR = 1.6
 F32_L2_LARGE, BF16_L2_LARGE = 8e-6, 2.4e-2     # eval-forward per-patch loss of the STUNet-L / H shapes: measured 4.9e-7 / 2.7e-6 (fp32), 1.3e-3 / 7.8e-3 (bf16)
 F32_REL_LARGE = 5e-2                    # per gradient tensor, fp32 storage, depth 2 / 3: measured 1.2e-2 (L), 1.8e-2 (H) -- the fp32 floor grows with depth
