@@ -18,7 +18,10 @@
 //     between two barriers X runs [20 reads + DMA issue, 36 MFMAs] and Y [36 MFMAs, 20 reads + DMA issue] -- a SIMD's matrix pipe always
 //     has one of its two waves feeding it.  144 accumulator registers per wave; the two halves' partial sums meet in the fp32 atomics of
 //     the flush (as the brick-walk slots' do).
-// Serves: bf16, dense operands, H % 8 == W % 16 == 0, Cx % 64 == Cy % 64 == 0, atomic (non-deterministic) accumulation; everything else,
+// CYT = 2: 32-wide cy tiles (Cy % 64 != 0: the 64 -> 32 conv in front of the projection, STUNet-H's 192 -> 96): dY rows of 64 bytes (8 pieces
+// per brick, 31 in all: four per wave), 2 dY fragments and 18 MFMAs per k-step -- the X brick is fetched for half the MFMAs, so this form
+// needs 27 B/clk/CU of DMA where the 64-wide one needs 17.
+// Serves: bf16, dense operands, H % 8 == W % 16 == 0, Cx % 64 == Cy % 32 == 0, atomic (non-deterministic) accumulation; everything else,
 // and the deterministic mode, stays on conv_wgrad.hip (am_conv3d_wgrad decides).
 #include <stdlib.h>
 #include "common.h"
@@ -29,9 +32,15 @@ namespace {
 constexpr int WMV = 128;                               // brick: 1 x 8 x 16 voxels of dY
 constexpr int WEW = 18;                                // haloed X brick: 10 x 18 voxels of ONE plane
 constexpr int WXROWS = 184;                            // 180 rows rounded up to whole 8-row pieces
-constexpr int WDYB = WMV * 128, WDXB = WXROWS * 128, WBUF = WDYB + WDXB;   // 16 384 + 23 552 = 39 936 bytes per buffer
-constexpr int WNPY = 16, WNP = 39;                     // DMA pieces per brick: 16 of dY, then 23 of X
-constexpr int WLDS = 3 * WBUF;                         // 119 808: a ring of three bricks (one contracted, two in flight)
+constexpr int WDXB = WXROWS * 128;                     // 23 552 bytes of X per buffer
+// per cy-tile count CYT (16 channels each): dY bytes, DMA pieces of dY (1 KB each) and in all, pieces per wave, buffer and ring bytes
+template <int CYT> struct WkGeo {
+  static constexpr int DYB = WMV * 32 * CYT;            // 16 384 (CYT = 4) / 8 192
+  static constexpr int NPY = 4 * CYT, NP = NPY + 23;    // 39 / 31 pieces per brick
+  static constexpr int NPW = (NP + 7) / 8;              // 5 / 4 per wave (the last wave re-issues the last piece)
+  static constexpr int BUF = DYB + WDXB;                // 39 936 / 31 744
+  static constexpr int LDS = 3 * BUF;                   // 119 808 / 95 232: a ring of three bricks (one contracted, two in flight)
+};
 
 struct Wk3Args {
   const bf16_t* x; const bf16_t* dy; float* dw;
@@ -63,12 +72,15 @@ __device__ __forceinline__ s16x4 w_tr_read(const unsigned char* p) {
 #define WK_TRR(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory")
 // fragments of k-step KS of the brick whose buffer the lane addresses point into: dY h-rows 2 KS, 2 KS + 1 (8 reads), then the X rows
 // 2 KS .. 2 KS + 3 under the three w-shifts, rows 0 and 1 first (the h-tap 0 MFMAs start on them)
-template <int KS>
-__device__ __forceinline__ void wk_read(const unsigned (&ya)[4], const unsigned (&xb)[3], s16x4 (&alo)[4], s16x4 (&ahi)[4], s16x4 (&xr)[3][4]) {
-  WK_TRR(alo[0], ya[0], KS * 4096); WK_TRR(ahi[0], ya[0], KS * 4096 + 2048);
-  WK_TRR(alo[1], ya[1], KS * 4096); WK_TRR(ahi[1], ya[1], KS * 4096 + 2048);
-  WK_TRR(alo[2], ya[2], KS * 4096); WK_TRR(ahi[2], ya[2], KS * 4096 + 2048);
-  WK_TRR(alo[3], ya[3], KS * 4096); WK_TRR(ahi[3], ya[3], KS * 4096 + 2048);
+template <int KS, int CYT>
+__device__ __forceinline__ void wk_read(const unsigned (&ya)[CYT], const unsigned (&xb)[3], s16x4 (&alo)[CYT], s16x4 (&ahi)[CYT], s16x4 (&xr)[3][4]) {
+  constexpr int HR = 512 * CYT;                          // bytes of one h-row of dY (16 voxels x 32 CYT bytes)
+  WK_TRR(alo[0], ya[0], KS * 2 * HR); WK_TRR(ahi[0], ya[0], KS * 2 * HR + HR);
+  WK_TRR(alo[1], ya[1], KS * 2 * HR); WK_TRR(ahi[1], ya[1], KS * 2 * HR + HR);
+  if constexpr (CYT == 4) {
+    WK_TRR(alo[2], ya[2], KS * 2 * HR); WK_TRR(ahi[2], ya[2], KS * 2 * HR + HR);
+    WK_TRR(alo[3], ya[3], KS * 2 * HR); WK_TRR(ahi[3], ya[3], KS * 2 * HR + HR);
+  }
   WK_TRR(xr[0][0], xb[0], (KS * 2 + 0) * 2304); WK_TRR(xr[1][0], xb[1], (KS * 2 + 0) * 2304); WK_TRR(xr[2][0], xb[2], (KS * 2 + 0) * 2304);
   WK_TRR(xr[0][1], xb[0], (KS * 2 + 1) * 2304); WK_TRR(xr[1][1], xb[1], (KS * 2 + 1) * 2304); WK_TRR(xr[2][1], xb[2], (KS * 2 + 1) * 2304);
   WK_TRR(xr[0][2], xb[0], (KS * 2 + 2) * 2304); WK_TRR(xr[1][2], xb[1], (KS * 2 + 2) * 2304); WK_TRR(xr[2][2], xb[2], (KS * 2 + 2) * 2304);
@@ -76,7 +88,10 @@ __device__ __forceinline__ void wk_read(const unsigned (&ya)[4], const unsigned 
 }
 static_assert(2304 == 18 * 128, "X brick rows");
 
+template <int CYT>
 __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
+  typedef WkGeo<CYT> G_;
+  constexpr int WDYB = G_::DYB, WNPY = G_::NPY, WNP = G_::NP, NPW = G_::NPW, WBUF = G_::BUF;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
   const int blk = blockIdx.x / (8 * nsib), rem = blockIdx.x % (8 * nsib);
   const int sib = rem >> 3, tile = sib / 3, grp = sib - tile * 3;
   const int slot = blk * 8 + (rem & 7);
-  const int cy0 = (tile / a.ncxt) * 64, cx0 = (tile % a.ncxt) * 64;
+  const int cy0 = (tile / a.ncxt) * (16 * CYT), cx0 = (tile % a.ncxt) * 64;
   const int S8 = a.split >> 3, xcd = slot & 7;
   const int ncol = a.B * a.nbh * a.nbw;
   const int c0 = (int)((long)ncol * xcd / 8), ncx = (int)((long)ncol * (xcd + 1) / 8) - c0;
@@ -139,13 +154,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
   // position l & 7).  Wave 7 has no piece 39: its k = 4 re-issues piece 38 (the same bytes to the same place), so that EVERY wave has exactly
   // five DMA operations per brick in flight and one counted wait serves all of them.
   constexpr unsigned OOB = 0x80000000u;
-  unsigned pl[5], pcode = 0u;
+  unsigned pl[NPW], pcode = 0u;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < NPW; ++k) {
     const int pi = (wave + 8 * k) < WNP ? wave + 8 * k : WNP - 1;
-    if (k < 2) {
-      const int v = 8 * pi + (lane >> 3), h = v >> 4, w = v & 15;
-      pl[k] = (unsigned)(((h * a.W + w) * a.Cy + (((lane & 7) ^ (((w >> 1) & 3) << 1)) * 8)) * 2);
+    if (k < WNPY / 8) {
+      if constexpr (CYT == 4) {
+        const int v = 8 * pi + (lane >> 3), h = v >> 4, w = v & 15;
+        pl[k] = (unsigned)(((h * a.W + w) * a.Cy + (((lane & 7) ^ (((w >> 1) & 3) << 1)) * 8)) * 2);
+      } else {                                            // 64-byte rows: 16 voxels per piece, four 16-byte chunks each; key = (w >> 2) & 1
+        const int v = 16 * pi + (lane >> 2), h = v >> 4, w = v & 15;
+        pl[k] = (unsigned)(((h * a.W + w) * a.Cy + (((lane & 3) ^ (((w >> 2) & 1) << 1)) * 8)) * 2);
+      }
     } else {
       const int rho = 8 * (pi - WNPY) + (lane >> 3), yy = rho / WEW, xx = rho - yy * WEW;
       pl[k] = (unsigned)(((yy * a.W + xx) * a.Cx + (((lane & 7) ^ (((xx >> 1) & 3) << 1)) * 8)) * 2);
@@ -154,11 +174,11 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
     }
   }
   // fragment reads: the lane's voxel of a k-step is (h = 2 ks (+1 for the second half), w = wv); transposing read of 4 voxels x 16 channels per 16 lanes
-  const int wv = 4 * g + q, keyA = (wv >> 1) & 3;
+  const int wv = 4 * g + q, keyA = CYT == 4 ? (wv >> 1) & 3 : (wv >> 2) & 1;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;     // LDS byte address of the carve (0: no static LDS)
-  unsigned ya0[4];                                      // dY fragment i (16 cy): 32-byte group i ^ keyA of the voxel's row (ring slot 0)
+  unsigned ya0[CYT];                                    // dY fragment i (16 cy): 32-byte group i ^ keyA of the voxel's row (ring slot 0)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ya0[i] = lds0 + wv * 128 + 8 * p + ((i ^ keyA) << 5);
+  for (int i = 0; i < CYT; ++i) ya0[i] = lds0 + wv * (32 * CYT) + 8 * p + ((i ^ keyA) << 5);
   unsigned xb0[3];                                      // X fragment of w-shift tw: row (h, wv + tw), 32-byte group wx ^ key(wv + tw)
 #pragma unroll
   for (int tw = 0; tw < 3; ++tw) xb0[tw] = lds0 + WDYB + (wv + tw) * 128 + 8 * p + ((wx ^ (((wv + tw) >> 1) & 3)) << 5);
@@ -170,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
 #pragma unroll
     for (int k = k0; k < k1; ++k) {
       const int pi = (wave + 8 * k) < WNP ? wave + 8 * k : WNP - 1;
-      if (k < 2) {
+      if (k < WNPY / 8) {
         unsigned vo = it_ok ? pl[k] : OOB;
 #ifdef AM_ABLATE
         if (a.dbg & 4) vo = OOB;
@@ -187,55 +207,55 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
     }
   };
 
-  f32x4 acc[9][4];
+  f32x4 acc[9][CYT];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < CYT; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   typedef __attribute__((ext_vector_type(8))) __bf16 bfx8;
 
   // X waves contract k-steps 0, 1 (h-rows 0-3) of every brick, Y waves k-steps 2, 3: the Y offset is part of the lane constants
   if (!isX) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ya0[i] += 2 * 4096;
+    for (int i = 0; i < CYT; ++i) ya0[i] += 2 * (1024 * CYT);
 #pragma unroll
     for (int tw = 0; tw < 3; ++tw) xb0[tw] += 4 * (WEW * 128);
   }
 
   // ---- prologue: bricks 0 and 1 are issued (a brick past the end: zeros); brick 0 has landed when all but this wave's five pieces of
   // brick 1 have (vmcnt retires in order)
-  issue_pieces(0, 0, 5); advance();
-  issue_pieces(1, 0, 5); advance();
-  asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  issue_pieces(0, 0, NPW); advance();
+  issue_pieces(1, 0, NPW); advance();
+  if constexpr (NPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   int cb = 0;                                            // ring slot of the brick being contracted
   for (int n = 0; n < ntot; ++n) {
     const int fb = cb >= 1 ? cb - 1 : 2;                 // ring slot (cb + 2) % 3: the one brick n - 1 has left
-    unsigned ya[4], xb[3];
+    unsigned ya[CYT], xb[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ya[i] = ya0[i] + (unsigned)(cb * WBUF);
+    for (int i = 0; i < CYT; ++i) ya[i] = ya0[i] + (unsigned)(cb * WBUF);
 #pragma unroll
     for (int tw = 0; tw < 3; ++tw) xb[tw] = xb0[tw] + (unsigned)(cb * WBUF);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       // ---------------- L: the fragments of this wave's k-step i from LDS, then its share of the DMA of brick n + 2
-      s16x4 alo[4], ahi[4], xr[3][4];
+      s16x4 alo[CYT], ahi[CYT], xr[3][4];
 #ifdef AM_ABLATE
       if (a.dbg & 16) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { alo[j] = s16x4{1, 1, 1, 1}; ahi[j] = s16x4{1, 1, 1, 1}; }
+        for (int j = 0; j < CYT; ++j) { alo[j] = s16x4{1, 1, 1, 1}; ahi[j] = s16x4{1, 1, 1, 1}; }
 #pragma unroll
         for (int tw = 0; tw < 3; ++tw)
 #pragma unroll
           for (int r = 0; r < 4; ++r) xr[tw][r] = s16x4{1, 1, 1, 1};
       } else
 #endif
-      if (i == 0) wk_read<0>(ya, xb, alo, ahi, xr); else wk_read<1>(ya, xb, alo, ahi, xr);
+      if (i == 0) wk_read<0, CYT>(ya, xb, alo, ahi, xr); else wk_read<1, CYT>(ya, xb, alo, ahi, xr);
 #ifdef AM_ABLATE
       if (!(a.dbg & 32))
 #endif
-      issue_pieces(fb, i == 0 ? 0 : 3, i == 0 ? 3 : 5);
+      issue_pieces(fb, i == 0 ? 0 : NPW - 2, i == 0 ? NPW - 2 : NPW);
       // ONE barrier per k-step and wave, X behind its MFMAs, Y in front of them: between two barriers X runs [L(n) M(n)] and Y
       // [M(n - 1) L(n)] -- X fetches while Y multiplies, then the other way round; the program order (L, then M) is the same for both.
       // What the barriers order: brick n + 1 (DMA'd during brick n - 1's two intervals) has landed -- in front of the barrier that ends
@@ -244,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
       // behind which the DMA of brick n + 2 starts to overwrite that ring slot.  The DMA runs two bricks ahead: with one brick of
       // lookahead every brick ended on the full latency of its last pieces (the launch took the SUM of its MFMA and DMA times).
       if (!isX) {
-        if (i == 1) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        if (i == 1) { if constexpr (NPW == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef AM_ABLATE
         if (!(a.dbg & 64))
@@ -255,11 +275,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
       // dY fragments + X rows 0, 1 have landed (reads return in order: 6 may still be out)
-      asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]), "+v"(ahi[3]),
-                   "+v"(xr[0][0]), "+v"(xr[1][0]), "+v"(xr[2][0]), "+v"(xr[0][1]), "+v"(xr[1][1]), "+v"(xr[2][1]) :: "memory");
-      bfx8 af[4];
+      if constexpr (CYT == 4)
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(alo[0]), "+v"(alo[1]), "+v"(alo[2]), "+v"(alo[3]), "+v"(ahi[0]), "+v"(ahi[1]), "+v"(ahi[2]), "+v"(ahi[3]),
+                     "+v"(xr[0][0]), "+v"(xr[1][0]), "+v"(xr[2][0]), "+v"(xr[0][1]), "+v"(xr[1][1]), "+v"(xr[2][1]) :: "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(alo[0]), "+v"(alo[1]), "+v"(ahi[0]), "+v"(ahi[1]),
+                     "+v"(xr[0][0]), "+v"(xr[1][0]), "+v"(xr[2][0]), "+v"(xr[0][1]), "+v"(xr[1][1]), "+v"(xr[2][1]) :: "memory");
+      bfx8 af[CYT];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < CYT; ++j)
         af[j] = __builtin_bit_cast(bfx8, s16x8{alo[j][0], alo[j][1], alo[j][2], alo[j][3], ahi[j][0], ahi[j][1], ahi[j][2], ahi[j][3]});
 #ifdef AM_ABLATE
       if (!(a.dbg & 2))
@@ -267,19 +291,26 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
 #pragma unroll
       for (int t = 0; t < 9; ++t) {                      // tap (th, tw) = (t / 3, t % 3): X rows h + th, h + th + 1
         // (tied to the accumulators of the previous h-tap as well: the wait stays BEHIND those MFMAs instead of being hoisted to the top)
+        if constexpr (CYT == 4) {
         if (t == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xr[0][2]), "+v"(xr[1][2]), "+v"(xr[2][2]), "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),
                                  "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]) :: "memory");
         if (t == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0][3]), "+v"(xr[1][3]), "+v"(xr[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]),
                                  "+v"(acc[4][0]), "+v"(acc[4][1]), "+v"(acc[4][2]), "+v"(acc[4][3]), "+v"(acc[5][0]), "+v"(acc[5][1]), "+v"(acc[5][2]), "+v"(acc[5][3]) :: "memory");
+        } else {
+        if (t == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xr[0][2]), "+v"(xr[1][2]), "+v"(xr[2][2]), "+v"(acc[0][0]), "+v"(acc[0][1]),
+                                 "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]) :: "memory");
+        if (t == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[0][3]), "+v"(xr[1][3]), "+v"(xr[2][3]), "+v"(acc[3][0]), "+v"(acc[3][1]),
+                                 "+v"(acc[4][0]), "+v"(acc[4][1]), "+v"(acc[5][0]), "+v"(acc[5][1]) :: "memory");
+        }
         const s16x4 lo = xr[t % 3][t / 3], hi = xr[t % 3][t / 3 + 1];
         const bfx8 bf = __builtin_bit_cast(bfx8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bf, acc[t][j], 0, 0, 0);
+        for (int j = 0; j < CYT; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j], bf, acc[t][j], 0, 0, 0);
       }
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       if (isX) {
-        if (i == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if (i == 1) { if constexpr (NPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 #ifdef AM_ABLATE
         if (!(a.dbg & 64))
 #endif
@@ -300,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_k3_kernel(Wk3Args a) {
   for (int t = 0; t < 9; ++t) {
     float* dst = a.dw + ((size_t)(9 * grp + t) * a.Cy + cy0) * a.Cx + cx;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < CYT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(dst + (size_t)(16 * i + 4 * g + r) * a.Cx, acc[t][i][r]);
   }
@@ -312,7 +343,7 @@ namespace amconv {
 
 // shapes this kernel serves (bf16, dense, k3 s1 are the caller's part of the condition)
 bool conv_wgk3_qualifies(int B, int D, int H, int W, int Cx, int Cy) {
-  if (Cx % 64 || Cy % 64 || H % 8 || W % 16 || B < 1 || D < 1) return false;
+  if (Cx % 64 || Cy % 32 || H % 8 || W % 16 || B < 1 || D < 1) return false;
   if ((size_t)(D + 2) * H * W * (Cx > Cy ? Cx : Cy) * 2 >= 0x7fffff00ull) return false;   // 32-bit byte offsets inside a sample (+ the halo plane)
   const int ncol = B * (H / 8) * (W / 16);
   return ncol >= 8 && (long)ncol * D >= 8 * 64;            // at least one column per XCD and 64 bricks per slot (a slot flushes 2 x 147 KB of atomics)
@@ -332,7 +363,8 @@ int conv_wgk3_launch(const void* x, const void* dy, float* dw, int B, int D, int
   Wk3Args a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw;
   a.B = B; a.D = D; a.H = H; a.W = W; a.Cx = Cx; a.Cy = Cy; a.nbh = nbh; a.nbw = nbw;
-  a.ncxt = Cx / 64; a.ntile = (Cy / 64) * a.ncxt;
+  const bool wide = Cy % 64 == 0;                          // 64-wide cy tiles; else 32-wide ones (Cy = 32, 96)
+  a.ncxt = Cx / 64; a.ntile = (wide ? Cy / 64 : Cy / 32) * a.ncxt;
   const int nsib = 3 * a.ntile;
   // slots per XCD: whole rounds of the resident set with the fewest idle CUs (siblings come in groups of nsib), fewer rounds preferred
   int s8 = 0; double best = 0.0;
@@ -368,8 +400,13 @@ int conv_wgk3_launch(const void* x, const void* dy, float* dw, int B, int D, int
   { const char* e_ = getenv("AM_WGK3_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
 #endif
   static PerDeviceOnce lds_cap;
-  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)wgrad_k3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
-  AM_LAUNCH(wgrad_k3_kernel, dim3((unsigned)(a.split * nsib)), dim3(512), WLDS, (hipStream_t)stream, a);
+  lds_cap.run([&](int) {
+    (void)hipFuncSetAttribute((const void*)wgrad_k3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wgrad_k3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+  });
+  if (wide) AM_LAUNCH(wgrad_k3_kernel<4>, dim3((unsigned)(a.split * nsib)), dim3(512), WkGeo<4>::LDS, (hipStream_t)stream, a);
+  else AM_LAUNCH(wgrad_k3_kernel<2>, dim3((unsigned)(a.split * nsib)), dim3(512), WkGeo<2>::LDS, (hipStream_t)stream, a);
   AM_CHECK_LAUNCH();
   return 1;
 }

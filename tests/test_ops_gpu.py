@@ -567,7 +567,8 @@ def test_conv_prenorm_fused_input_norm(ops, act):
     assert (st_a.sums.cpu()[0] - refs).abs().max().item() <= 1e-5 * refs.abs().max().item()
 
 
-@pytest.mark.parametrize("case", [(64, 64, (32, 32, 32), 2), (128, 64, (16, 32, 32), 4), (64, 128, (24, 16, 48), 6), (64, 64, (9, 8, 16), 64)])
+@pytest.mark.parametrize("case", [(64, 64, (32, 32, 32), 2), (128, 64, (16, 32, 32), 4), (64, 128, (24, 16, 48), 6), (64, 64, (9, 8, 16), 64),
+                                  (64, 32, (32, 32, 32), 2), (192, 96, (16, 16, 32), 8), (64, 32, (9, 8, 16), 64)])   # 32-wide cy tiles (Cout = 32, 96)
 def test_conv_wgrad_k3_dense_8wave_dma_kernel(ops, case):
     """conv_wgk3.hip (round 5): the dense bf16 k3 s1 weight gradient with 64 x 64 channel tiles on the persistent 8-wave LDS-DMA kernel
     (both operands by DMA into swizzled unpadded rows, transposing fragment reads, the two waves of a SIMD in antiphase) against
