@@ -661,7 +661,9 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
   // 32 slots of 4 bricks each = 3 rounds of mostly atomics, 213 us for 80 us of work).  tools/ab_minb.sh, same box: the batch-4 step 36.3 ms
   // without the rule, 35.6 / 35.3 / 35.1 / 36.3 with 16 / 32 / 64 / 128; batch 16, STUNet-L, STUNet-H unchanged
   {
-    int minb = 64;
+    // (one-tap launches -- the 1x1 stride-2 shortcuts -- flush 16 KB per slot and tile, and a brick of theirs is one load latency, not 2.4 us
+    // of MFMAs: 64 bricks in a row were 0.2 ms for 1 GFLOP at ANY batch size; 8 bricks per slot there)
+    int minb = NTAP * a.ngroup >= 8 ? 64 : 8;
 #ifdef AM_ABLATE
     { const char* e_ = getenv("AM_WG_MINB"); if (e_) minb = atoi(e_); }
 #endif
