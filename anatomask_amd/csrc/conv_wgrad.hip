@@ -670,6 +670,14 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
     if (minb > 0 && sizeof(T) == 2) {                  // (bf16 launches: with the exact-f32 MFMA a brick is 16 x the work and the flush does not show)
       int capb = nbrick / minb / 8 * 8;
       if (capb < 8) capb = 8;
+      // the tiles alone are a whole round of the chip (STUNet-B's 512 -> 512 transposed conv: 8 x 8 tiles x 8 parity groups): more slots are
+      // more ROUNDS of the same bricks plus a [taps][64][64] flush each -- 8 slots of 2 bricks flushed 8 x 67 MB for 68 GFLOP at batch 4
+      // (0.42 ms at 162 TFLOP/s).  No XCD needs a slot of its own there (the live slots rotate with the tile index in the kernel).
+      bool tile_round = tiles >= cap * 8;
+#ifdef AM_ABLATE
+      { const char* e_ = getenv("AM_WG_TILECAP"); if (e_ && !atoi(e_)) tile_round = false; }
+#endif
+      if (tile_round) { capb = nbrick / minb; if (capb < 1) capb = 1; }
       if (split > capb) split = capb;
     }
   }
