@@ -678,6 +678,17 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
       { const char* e_ = getenv("AM_WG_TILECAP"); if (e_ && !atoi(e_)) tile_round = false; }
 #endif
       if (tile_round) { capb = nbrick / minb; if (capb < 1) capb = 1; }
+      else {
+        // ... and the other way round: a launch whose slots x tiles stay UNDER one round of the chip leaves CUs idle while the few workgroups walk
+        // long rows of bricks (128 -> 128 @32^3 block-sparse at batch 4: 8 slots x 12 tiles = 96 workgroups of 100 bricks, 0.31 ms at 152
+        // TFLOP/s): up to one round of slots there, walks of >= 16 bricks
+        int fill = cap * 8 / tiles / 8 * 8, cap16 = nbrick / 16 / 8 * 8;
+#ifdef AM_ABLATE
+        { const char* e_ = getenv("AM_WG_FILL"); if (e_ && !atoi(e_)) fill = 0; }
+#endif
+        if (fill > cap16) fill = cap16;
+        if (capb < fill) capb = fill;
+      }
       if (split > capb) split = capb;
     }
   }
