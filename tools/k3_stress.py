@@ -57,7 +57,7 @@ for (B, D, H, W, ci, co, dgrad, stats, fused) in [(2, 64, 64, 64, 64, 64, False,
     del x, first, out
 # round 5: the 32-channel output tile and the transposed instantiation (two / four slabs; two channel tiles), and the 8-wave weight gradient
 for (B, D, H, W, ci, co, kind) in [(4, 32, 32, 64, 64, 32, "k3"), (4, 32, 32, 32, 64, 64, "ct"), (8, 16, 32, 32, 128, 64, "ct"), (4, 32, 16, 32, 64, 128, "ct"),
-                                   (2, 64, 64, 64, 64, 64, "wg")]:
+                                   (2, 64, 64, 64, 64, 64, "wg"), (2, 64, 64, 64, 64, 32, "wg"), (4, 32, 32, 32, 192, 96, "wg")]:   # (32-wide cy tiles)
     x = torch.randn(B, D, H, W, ci, device=dev).to(torch.bfloat16)
     if kind == "k3":
         w = (torch.randn(co, ci, 3, 3, 3, device=dev) / (27 * ci) ** 0.5).to(torch.bfloat16).float()
