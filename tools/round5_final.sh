@@ -1,6 +1,6 @@
 #!/bin/bash
 # everything profiles/r05_* is made of, ONE gpurun call (same box): bash tools/round5_final.sh r05_z
-tag=${1:-r05_z}
+tag=${1:-r05_zz}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
@@ -17,6 +17,7 @@ cp $out/encoder_fwd_traffic.json profiles/r05_encoder_fwd_traffic.json
 # ---- tests, smoke, bench
 timeout 2400 python3 -m pytest tests -m gpu -q -p no:cacheprovider > $out/pytest.txt 2>&1; echo "pytest rc $?" >> $out/pytest.txt
 grep -n "passed\|failed\|FAILED" $out/pytest.txt | tail -8
+timeout 900 python3 tools/k3_stress.py 24 2>&1 | grep -v amdgpu.ids > $out/k3_stress.txt; tail -1 $out/k3_stress.txt
 timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $out/smoke.txt 2>&1; tail -1 $out/smoke.txt
 timeout 900 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err; head -c 400 $out/bench.json; echo
 timeout 900 python3 bench.py --size L --patch 160 --mask-ratio 0.7 --batch 4 --steps 8 --warmup 3 --no-h2d > $out/bench_stunet_L_160_m07_b4.json 2> $out/bench_L.err; head -c 300 $out/bench_stunet_L_160_m07_b4.json; echo
