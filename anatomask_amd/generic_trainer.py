@@ -70,6 +70,14 @@ class GenericTrainer:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(seed + (dist.get_rank(process_group) if self.distributed else 0))
         self.exchange_log: List[int] = []                             # bytes of every collective of the last step
+        # parameters that never receive a gradient (levels the decoder never reads, unused mask tokens): torch.optim.AdamW skips a parameter
+        # whose .grad is None -- no weight decay, no state (P/pretrain_AntoMask.py:437-440) -- and so does this trainer: the first backward
+        # runs with .grad = None everywhere, what is still None afterwards is dead for good (the graph is static), and the fused pass covers
+        # the live ranges of the flat buffer only; the teacher's dead entries still take timm's EMA step (decay * t + (1 - decay) * s).
+        # Buffers: broadcast once at construction and then per rank, as the reference's DDP(broadcast_buffers=False) leaves them.
+        self._live_ranges: Optional[List[tuple]] = None
+        self._dead_ranges: List[tuple] = []
+        self.dead_parameters: List[str] = []
 
     @staticmethod
     def _flatten(params, dev):
@@ -138,20 +146,28 @@ class GenericTrainer:
             mask = mask1
         # 4. student forward + loss (:429-430), 5. backward (:435) into the flat gradient buffer
         self.gflat.zero_()
+        first = self._live_ranges is None
         for (_, p), g in zip(self._params, self._gviews):
-            p.grad = g
+            p.grad = None if first else g
         inpp, recc = m(inp_bchwd, active_b1ff=mask)
         loss, l2m = m.forward_loss(inpp, recc, mask)
         loss.backward()
         del inpp, recc
+        if first:
+            self._discover_live()
         self._exchange()
         # 6. clip + AdamW + EMA (:437-440) in one pass over the flat buffers
         with torch.no_grad():
             decay = self.teacher.decay if ema_decay is None else ema_decay
             ops.sumsq(self.gflat, self.sumsq)
             self.step_count += 1
-            ops.adamw_ema(self.flat, self.gflat, self.m, self.v, self.tflat if self.self_distill else None, self.n, self.lr if lr is None else lr,
-                          self.betas, self.eps, self.wd, self.step_count, self.sumsq, self.clip, decay, self.gnorm, grad_scale=self.grad_scale)
+            for a, b in self._live_ranges:
+                ops.adamw_ema(self.flat[a:b], self.gflat[a:b], self.m[a:b], self.v[a:b], self.tflat[a:b] if self.self_distill else None, b - a,
+                              self.lr if lr is None else lr, self.betas, self.eps, self.wd, self.step_count, self.sumsq, self.clip, decay, self.gnorm,
+                              grad_scale=self.grad_scale)
+            if self.self_distill:
+                for a, b in self._dead_ranges:
+                    ops.ema(self.tflat[a:b], self.flat[a:b], decay)
             if self.self_distill:                                      # timm's ModelEma: every state_dict entry, buffers included
                 for e, s in self._fbufs:
                     if e.is_contiguous() and s.is_contiguous() and e.dtype == s.dtype == torch.float32:
@@ -164,6 +180,26 @@ class GenericTrainer:
             m.weights_changed()
         return {"loss": loss.detach().reshape(1), "grad_norm": self.gnorm, "mask": mask, "recon_loss": recon, "rec_loss": l2m.detach()}
 
+    def _discover_live(self):
+        """after the FIRST backward (run with .grad = None): parameters autograd left without a gradient are dead; the others' gradients move
+        into their views of the flat buffer, which autograd accumulates into from now on"""
+        spans, o = [], 0
+        for (n, p), g in zip(self._params, self._gviews):
+            num = (p.numel() + 3) // 4 * 4
+            live = p.grad is not None
+            if live:
+                g.copy_(p.grad)
+            else:
+                self.dead_parameters.append(n)
+            p.grad = g
+            if spans and spans[-1][2] == live:
+                spans[-1][1] = o + num
+            else:
+                spans.append([o, o + num, live])
+            o += num
+        self._live_ranges = [(a, b) for a, b, live in spans if live]
+        self._dead_ranges = [(a, b) for a, b, live in spans if not live]
+
     def set_epoch(self, i: int):
         """per-epoch EMA decay ramp (P/pretrain_AntoMask.py:383-386)."""
         from .modules import ema_decay_for_epoch
@@ -172,7 +208,21 @@ class GenericTrainer:
     # ------------------------------------------------------------------ checkpoint (same keys as the reference's torch.save, P/pretrain_AntoMask.py:472-479)
     def state_dict(self) -> dict:
         return {"model": self.model.state_dict(), "state_dict_ema": self.teacher.ema.state_dict(), "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone(),
-                "step": self.step_count, "generator": self.gen.get_state()}
+                "step": self.step_count, "generator": self.gen.get_state(), "dead_parameters": list(self.dead_parameters),
+                "live_ranges": None if self._live_ranges is None else [list(r) for r in self._live_ranges]}
+
+    def save(self, path: str, epoch: int = 0, extra: Optional[dict] = None):
+        """one file, tensors + plain containers only: `load` reads it with torch's restricted unpickler (weights_only=True)"""
+        sd = self.state_dict()
+        sd = {k: ({n: t.detach().cpu() for n, t in v.items()} if isinstance(v, dict) else (v.detach().cpu() if torch.is_tensor(v) else v)) for k, v in sd.items()}
+        sd["current_epoch"] = int(epoch)
+        sd["extra"] = dict(extra or {})
+        torch.save(sd, path)
+
+    def load(self, path: str) -> dict:
+        sd = torch.load(path, map_location="cpu", weights_only=True)      # never unpickles code
+        self.load_state_dict(sd)
+        return {"current_epoch": int(sd.get("current_epoch", 0)), "extra": sd.get("extra", {})}
 
     def load_state_dict(self, sd: dict):
         self.model.load_state_dict(sd["model"]); self.teacher.ema.load_state_dict(sd["state_dict_ema"])
@@ -185,5 +235,15 @@ class GenericTrainer:
             o += (p.numel() + 3) // 4 * 4
         self.m.copy_(sd["exp_avg"]); self.v.copy_(sd["exp_avg_sq"])
         self.step_count = int(sd["step"])
-        self.gen.set_state(sd["generator"])
+        self.gen.set_state(sd["generator"].cpu() if torch.is_tensor(sd["generator"]) else sd["generator"])
+        if sd.get("live_ranges") is not None:                          # (a file written before the first step has none: the next step discovers them)
+            self.dead_parameters = list(sd.get("dead_parameters", []))
+            self._live_ranges = [tuple(r) for r in sd["live_ranges"]]
+            live, self._dead_ranges, o = sorted(self._live_ranges), [], 0
+            for a, b in live:
+                if a > o:
+                    self._dead_ranges.append((o, a))
+                o = b
+            if o < self.n:
+                self._dead_ranges.append((o, self.n))
         self.model.weights_changed(); self.teacher.ema.weights_changed()

@@ -81,6 +81,19 @@ def test_generic_trainer_matches_the_unfused_driver_loop(self_distill):
             d = (a - b).abs().flatten()
             flips += int((d > 0.3 * lr).sum()); tot_el += d.numel()
     assert flips / tot_el < 5e-3, flips / tot_el
+    # parameters without a gradient: torch.optim.AdamW skipped them (no decay, no state) -- so did the fused pass: the same set, bit-identical
+    # to the initial weights on both routes (before round 5 the fused pass decayed them by lr * wd per step)
+    none_ref = sorted(n for n, p in model.named_parameters() if p.requires_grad and p.grad is None)
+    assert sorted(tr.dead_parameters) == none_ref, (tr.dead_parameters, none_ref)
+    sd_init = build().state_dict()
+    for n in none_ref:
+        assert torch.equal(m2.state_dict()[n], sd_init[n]) and torch.equal(model.state_dict()[n], sd_init[n]), n
+    o = 0
+    for (n, p) in tr._params:                                                        # ... and no Adam state
+        num = (p.numel() + 3) // 4 * 4
+        if n in none_ref:
+            assert float(tr.m[o:o + num].abs().max()) == 0.0 and float(tr.v[o:o + num].abs().max()) == 0.0, n
+        o += num
     if self_distill:
         worst = 0.0
         for (k, a), (_, b) in zip(ema.ema.state_dict().items(), tr.teacher.ema.state_dict().items()):
@@ -103,13 +116,22 @@ def test_generic_trainer_refuses_stunet_and_resumes_bit_exactly():
     x = draws(0)[0]
     a.step(x, epoch=10)
     sd = copy.deepcopy(a.state_dict())
-    o1 = [a.step(draws(s)[0], epoch=10) for s in (1, 2)]
-    b = GenericTrainer(build(), **kw)
-    b.load_state_dict(sd)
-    o2 = [b.step(draws(s)[0], epoch=10) for s in (1, 2)]
-    for p, q in zip(o1, o2):
-        assert torch.equal(p["mask"], q["mask"])                                     # the generator state travelled
-        assert abs(p["loss"].item() - q["loss"].item()) <= 1e-5 * abs(p["loss"].item())
+    import os
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:                                        # ... and through a FILE (restricted unpickler on the way back)
+        a.save(os.path.join(td, "generic.pt"), epoch=10, extra={"note": "x"})
+        o1 = [a.step(draws(s)[0], epoch=10) for s in (1, 2)]
+        b = GenericTrainer(build(), **kw)
+        b.load_state_dict(sd)
+        c = GenericTrainer(build(), **kw)
+        info = c.load(os.path.join(td, "generic.pt"))
+    assert info == {"current_epoch": 10, "extra": {"note": "x"}}
+    assert c.dead_parameters == a.dead_parameters and c._live_ranges == a._live_ranges and c.step_count == 1
+    for t in (b, c):
+        o2 = [t.step(draws(s)[0], epoch=10) for s in (1, 2)]
+        for p, q in zip(o1, o2):
+            assert torch.equal(p["mask"], q["mask"])                                 # the generator state travelled
+            assert abs(p["loss"].item() - q["loss"].item()) <= 1e-5 * abs(p["loss"].item())
 
 
 def test_generic_trainer_two_ranks_on_one_gpu_stay_in_sync():
