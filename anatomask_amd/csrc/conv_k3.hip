@@ -530,7 +530,7 @@ namespace amconv {
 
 // rows of partial sums a launch of this kernel writes (8 per workgroup), or 0 when the shape does not qualify
 static int k3_grid(int B, int D, int H, int W, int Cout, int* units) {
-  const int nb = B * (D / KBD) * (H / KBH) * (W / KBW), ny = Cout == 32 ? 1 : Cout / 64;
+  const int nb = B * (D / KBD) * (H / KBH) * (W / KBW), ny = Cout % 64 ? Cout / 32 : Cout / 64;      // (32-channel tiles for Cout = 32, 96, 160)
   *units = nb * ny;
   int cus = 256;
   static int cached = 0;
@@ -543,7 +543,7 @@ static int k3_grid(int B, int D, int H, int W, int Cout, int* units) {
 
 static bool k3_qualifies(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cin, int Cout, bool masks) {
   if (dtype != AM_DT_BF16 || ksize != 3 || stride != 1 || (mode != AM_CONV_FWD && mode != AM_CONV_DGRAD) || masks) return false;
-  if (Cin % 32 || (Cout % 64 && Cout != 32) || D % KBD || H % KBH || W % KBW) return false;
+  if (Cin % 32 || Cout % 32 || D % KBD || H % KBH || W % KBW) return false;
   // `Item` packs the sample index and the three brick indices into 8-bit fields (IT_B / IT_Q0*): larger launches go to conv_igemm.hip
   if (B > 255 || D / KBD > 255 || H / KBH > 255 || W / KBW > 255) return false;
   return true;
@@ -567,13 +567,13 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
   if (units < K3_MIN_UNITS) return 0;
 #ifdef AM_ABLATE
   if (getenv("AM_CV_NOK3")) return 0;
-  { const char* e_ = getenv("AM_K3_NO32"); if (e_ && atoi(e_) && c.Cout == 32) return 0; }
+  { const char* e_ = getenv("AM_K3_NO32"); if (e_ && atoi(e_) && c.Cout % 64) return 0; }
 #endif
   K3Args a;
   a.x = (const bf16_t*)c.x; a.w = (const bf16_t*)c.w; a.bias = c.bias; a.y = (bf16_t*)c.y; a.partials = c.partials;
   a.ep_scale = c.ep_scale; a.ep_shift = c.ep_shift; a.ep_res = (const bf16_t*)c.ep_res; a.ep_act = c.ep_act;
   a.B = c.B; a.D = c.Di; a.H = c.Hi; a.W = c.Wi; a.Cin = c.Cin; a.Cout = c.Cout; a.Cinp = c.Cinp; a.Coutp = c.Coutp;
-  a.nbd = c.Di / KBD; a.nbh = c.Hi / KBH; a.nbw = c.Wi / KBW; a.ny = c.Cout == 32 ? 1 : c.Cout / 64; a.nunit = units; a.nslab = c.Cinp / 32;
+  a.nbd = c.Di / KBD; a.nbh = c.Hi / KBH; a.nbw = c.Wi / KBW; a.ny = c.Cout % 64 ? c.Cout / 32 : c.Cout / 64; a.nunit = units; a.nslab = c.Cinp / 32;
   a.flip = mode == AM_CONV_DGRAD;
   a.nt_store = (size_t)c.B * c.Do * c.Ho * c.Wo * c.Cout * 2 >= ((size_t)384 << 20);
   a.w_bytes = (unsigned)c.w_bytes;
@@ -583,7 +583,7 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
   const bool ep = a.ep_scale || a.ep_res || a.ep_act != AM_ACT_NONE;
   if (ep && a.partials) return 0;                  // (no caller fuses a store epilogue AND asks for statistics: conv_igemm.hip serves it)
   auto kern = ep ? conv_k3_kernel<4, true, false> : (a.partials ? conv_k3_kernel<4, false, true> : conv_k3_kernel<4, false, false>);
-  if (c.Cout == 32) kern = ep ? conv_k3_kernel<2, true, false> : (a.partials ? conv_k3_kernel<2, false, true> : conv_k3_kernel<2, false, false>);
+  if (c.Cout % 64) kern = ep ? conv_k3_kernel<2, true, false> : (a.partials ? conv_k3_kernel<2, false, true> : conv_k3_kernel<2, false, false>);
   static PerDeviceOnce lds_cap;
   lds_cap.run([&](int) {
     (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
