@@ -29,7 +29,8 @@ BF16_LOSS, BF16_GNORM, BF16_L2 = 1e-4, 2e-2, 1.5e-4   # measured 3e-6 / 3e-5 / 1
 # differs from fp32 (measured medians, HIP-fp32 / emulation-fp32 / HIP-emulation: B 0.29 / 0.28 / 0.32, L 0.47 / 0.44 / 0.49, H 0.60 / 0.57 / 0.65)
 # Round 5 (STUNet-B 128^3, per tensor): HIP / emulation = 0.85 - 1.18 for all 92 tensors once the stem's volume stopped being rounded to bf16
 # (the stem weight had sat at 1.7 x = ON this bound: profiles/r05_experiments.md section 7); other summation orders move a tensor by 1 - 5 %.
-BF16_VS_EMU_FACTOR = 1.6
+BF16_VS_EMU_FACTOR = 1.45             # round 5, measured per-tensor ratios HIP / emulation (tests print them): rel-L2 0.79 .. 1.19 (B / L / H), .. 1.35 (recipe shape, a 64-element bias); (1 - cos) up to 1.38 / 1.81 (bound: 1.45^2 = 2.1)
+BF16_FULL_SIZE_FACTOR = 1.6            # full-size L / H steps against the reduced-patch emulation's worst tensor (another patch size: not the same tensors)
 F32_L2_LARGE, BF16_L2_LARGE = 8e-6, 2.4e-2     # eval-forward per-patch loss of the STUNet-L / H shapes: measured 4.9e-7 / 2.7e-6 (fp32), 1.3e-3 / 7.8e-3 (bf16)
 F32_REL_LARGE = 5e-2                    # per gradient tensor, fp32 storage, depth 2 / 3: measured 1.2e-2 (L), 1.8e-2 (H) -- the fp32 floor grows with depth
 BF16_PAIR_FACTOR = 1.6
@@ -88,6 +89,9 @@ def _check_bf16_rows(rows_vs_fp32, emu_grads, model, fp32_grads, what):
         emu_vs_fp32[k] = (float((a - w).norm() / w.norm()), float((a * w).sum() / (a.norm() * w.norm() + 1e-300)))
     print(f"{what}: ideal bf16 emulation vs fp32: rel-L2 median {np.median([v[0] for v in emu_vs_fp32.values()]):.3e} "
           f"max {max(v[0] for v in emu_vs_fp32.values()):.3e}; min cos {min(v[1] for v in emu_vs_fp32.values()):.5f}")
+    ratios = [(rel / emu_vs_fp32[k][0], (1 - cos) / (1 - emu_vs_fp32[k][1] + 1e-12), k) for k, n_el, rel, cos in rows_vs_fp32 if n_el >= 64 and emu_vs_fp32[k][0] > 0.02]
+    print(f"{what}: HIP / emulation per tensor (distance from fp32, tensors the emulation moves by > 2 %): rel-L2 ratio {min(r[0] for r in ratios):.2f} .. "
+          f"{max(r[0] for r in ratios):.2f} (worst: {max(ratios)[2]}), (1 - cos) ratio up to {max(r[1] for r in ratios):.2f}")
     for k, n_el, rel, cos in rows_vs_fp32:
         if n_el >= 64:
             e_rel, e_cos = emu_vs_fp32[k]
@@ -415,7 +419,7 @@ def _bf16_vs_fp32_storage_full_size(size, patch, mask_ratio, recompute, seed):
     med, worst = float(np.median([r[1] for r in rows])), max(rows, key=lambda r: r[1])
     print(f"   {len(rows)} gradient tensors: rel-L2 median {med:.3f} (ideal emulation at the reduced patch {FULL_MEDIAN[size]}), worst {worst[0]} {worst[1]:.3f}, min cos {min(r[2] for r in rows):.4f}")
     assert med <= 1.25 * FULL_MEDIAN[size], med
-    assert worst[1] <= BF16_VS_EMU_FACTOR * FULL_WORST[size] + 0.05, worst
+    assert worst[1] <= BF16_FULL_SIZE_FACTOR * FULL_WORST[size] + 0.05, worst
 
 
 def test_config4_stunet_l_160_mask07_bf16_vs_fp32_storage_full_size():
