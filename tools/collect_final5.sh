@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/collect_final5.sh TAG  -- copy what tools/round5_final.sh left under gpurun_out/TAG into profiles/TAG_* (the judged copies)
-tag=${1:-r05_zz}
+tag=${1:-r05_final}
 src=gpurun_out/$tag
 cd "$(dirname "$0")/.."
 cp $src/bench.json profiles/${tag}_bench.json

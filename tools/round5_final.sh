@@ -1,6 +1,6 @@
 #!/bin/bash
 # everything profiles/r05_* is made of, ONE gpurun call (same box): bash tools/round5_final.sh r05_z
-tag=${1:-r05_zz}
+tag=${1:-r05_final}
 root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/$tag
 mkdir -p $out
