@@ -689,7 +689,17 @@ int launch(WgArgs& a, size_t maxvox, int tiles, int nbrick, int det_slots, hipSt
         if (fill > cap16) fill = cap16;
         if (capb < fill) capb = fill;
       }
-      if (split > capb) split = capb;
+      if (split > capb) {
+        // keep the capped count on whole rounds of the resident set (32 -> 32 @128^3 block-sparse at batch 4: 200 slots x 3 tiles = 600
+        // workgroups = 1.17 rounds ran as two; 168 slots = 504 workgroups run as one)
+        int aligned = 0;
+        if (!tile_round)
+          for (int R = 1; R <= 16; ++R) { const int s8 = cap * R / tiles; if (s8 * 8 > capb) break; if (s8 >= 1) aligned = s8 * 8; }
+#ifdef AM_ABLATE
+        { const char* e_ = getenv("AM_WG_ALIGN"); if (e_ && !atoi(e_)) aligned = 0; }
+#endif
+        split = aligned ? aligned : capb;
+      }
     }
   }
   if (split > nbrick) split = nbrick;

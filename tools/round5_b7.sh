@@ -1,0 +1,27 @@
+#!/bin/bash
+tag=${1:-r05_b7}
+root=${GRAFT_REPO_ROOT:-$PWD}
+out=$root/gpurun_out/$tag
+mkdir -p $out
+cd $root
+python3 -m anatomask_amd.build --ablate > $out/build_ablate.txt 2>&1
+L=anatomask_amd/libanatomask_hip_ablate.so
+timeout 900 python3 -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad or large_model" > $out/pytest.txt 2>&1; tail -2 $out/pytest.txt
+for tc in 1 0 1 0; do
+echo "== AM_WG_ALIGN=$tc"
+AM_WG_ALIGN=$tc timeout 300 python3 tools/with_lib.py $L tools/conv_census.py 4 2>&1 | grep -v amdgpu > $out/census_b4_$tc.txt; grep "total" $out/census_b4_$tc.txt
+AM_WG_ALIGN=$tc timeout 300 python3 tools/with_lib.py $L tools/step_run.py 4 40 1 2>&1 | grep ms/step
+AM_WG_ALIGN=$tc timeout 300 python3 tools/with_lib.py $L tools/step_run.py 16 12 1 2>&1 | grep ms/step
+done
+python3 - <<'PY'
+import re
+def load(f):
+    d={}
+    for l in open(f):
+        m=re.match(r"(.+?)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+(\d+)\s*$",l)
+        if m: d[m.group(1).strip()]=float(m.group(3))
+    return d
+a=load("gpurun_out/r05_b7/census_b4_1.txt"); b=load("gpurun_out/r05_b7/census_b4_0.txt")
+for k in a:
+    if k in b and k.startswith("wgrad") and abs(a[k]-b[k])>0.012: print(f"{k:45s} aligned {a[k]:.3f}  capped {b[k]:.3f}")
+PY
