@@ -116,7 +116,7 @@ int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const void* x, c
                     gather form does not apply to this launch) */,
                     void* stream);
 /* 1 / 0 (an answer, not an error code): am_conv3d_wgrad serves this launch on the 8-wave LDS-DMA kernel of conv_wgk3.hip (dense bf16 k3 s1,
- * H % 8 == W % 16 == 0, Cx % 64 == Cy % 64 == 0, >= 512 bricks, atomic accumulation) rather than on conv_wgrad.hip's brick walk.  Same x / dy
+ * H % 8 == W % 16 == 0, Cx % 64 == 0, Cy % 32 == 0 (64- or 32-wide cy tiles), >= 512 bricks, atomic accumulation) rather than on conv_wgrad.hip's brick walk.  Same x / dy
  * geometry arguments as am_conv3d_wgrad (D, H, W of dY = of X). */
 int am_conv3d_wgrad_uses_k3(int mode, int dtype, int ksize, int stride, int B, int D, int H, int W, int Cx, int Cy, int has_masks,
                             int deterministic);
