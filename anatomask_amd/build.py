@@ -6,6 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libanatomask_hip.so")
+AB_DIR = os.path.join(os.path.dirname(HERE), "build_ab")      # the tools-only -DAM_ABLATE variant and its objects: never next to the product library
 SOURCES = ["conv_igemm.hip", "conv_k3.hip", "conv_rw.hip", "conv_gather.hip", "conv_wgrad.hip", "conv_wgk3.hip", "stream_ops.hip", "step_ops.hip", "head_ops.hip", "aug_ops.hip", "layer_ops.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
@@ -38,18 +39,20 @@ def _stale(target, deps):
 
 
 def build(force: bool = False, verbose: bool = True, ablate: bool = False) -> str:
-    """ablate=True: the tools-only variant libanatomask_hip_ablate.so (-DAM_ABLATE: timing-ablation switches read from the
+    """ablate=True: the tools-only variant build_ab/libanatomask_hip_ablate.so (-DAM_ABLATE: timing-ablation switches read from the
     environment, results wrong on purpose); the product library never contains them."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     sfx = "_ablate" if ablate else ""
-    out = OUT.replace(".so", sfx + ".so")
+    out = os.path.join(AB_DIR, "libanatomask_hip_ablate.so") if ablate else OUT
+    objdir = AB_DIR if ablate else CSRC
+    os.makedirs(objdir, exist_ok=True)
     flags = FLAGS + (["-DAM_ABLATE"] if ablate else [])
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_plan.h"), os.path.join(os.path.dirname(HERE), "include", "anatomask_hip.h")]
     objs = []
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(CSRC, s.replace(".hip", sfx + ".o"))
+        obj = os.path.join(objdir, s.replace(".hip", sfx + ".o"))
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             cmd = [hipcc, *flags, "-c", src, "-o", obj]

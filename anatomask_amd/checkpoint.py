@@ -93,11 +93,18 @@ def read_checkpoint(path: str) -> Dict:
     except pickle.UnpicklingError as first:
         import numpy as np
         import warnings
-        allow = [np._core.multiarray._reconstruct, np.ndarray, np.dtype, type(np.dtype(np.uint32))]
+        # numpy 2.x spells the module `numpy._core`, numpy 1.x `numpy.core`: a format-2 file names whichever its WRITER had, so the
+        # function is registered under both spellings ((callable, "module.name") tuples are torch's form for that)
+        core = getattr(np, "_core", None) or getattr(np, "core", None)
+        rec = getattr(getattr(core, "multiarray", None), "_reconstruct", None)
+        if rec is None:
+            raise first
+        allow = [(rec, "numpy._core.multiarray._reconstruct"), (rec, "numpy.core.multiarray._reconstruct"), np.ndarray, np.dtype,
+                 type(np.dtype(np.uint32))]
         try:
             with torch.serialization.safe_globals(allow):
                 ck = torch.load(path, map_location="cpu", weights_only=True)
-        except pickle.UnpicklingError:
+        except Exception:                                  # (whatever the second attempt dies of, the file's real problem is the first error)
             raise first
         if not isinstance(ck, dict) or int(ck.get("anatomask_amd_version", 0)) >= FORMAT_VERSION:
             raise first

@@ -183,3 +183,14 @@ struct PerDeviceOnce {
 // an API call inside an entry point that promises "0 or a hipError_t": its failure is the entry point's return value
 #define AM_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define AM_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+// The kernel-selection stages (conv_rw / conv_gather / conv_k3 / conv_k3t / conv_wgk3 _launch) answer 1 = served, 0 = the shape does not
+// qualify.  hipErrorInvalidValue IS 1 (what a rejected launch configuration returns), so a failure inside a stage is -(1000 + hipError_t):
+// never mistaken for "served", and distinct from the entry points' small negative argument errors.
+#define AM_STAGE_ERR(e) (-(1000 + (int)(e)))
+#define AM_CHECK_LAUNCH_STAGE() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return AM_STAGE_ERR(e_); } while (0)
+// opt a kernel in to 160 KB of dynamic LDS once per device; a refused opt-in is the stage's (sticky) failure, not a silent fall-through
+#define AM_LDS_OPTIN_STAGE(kern) do { \
+    static PerDeviceOnce once_; static int err_ = 0; \
+    once_.run([&](int) { hipError_t e_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                         if (e_ != hipSuccess) err_ = (int)e_; (void)hipGetLastError(); }); \
+    if (err_) return AM_STAGE_ERR(err_); } while (0)

@@ -317,12 +317,11 @@ template <int NS, int KSL>
 int ga_launch(ConvArgs& a, GaArgs& r, hipStream_t st) {
   auto kern = conv_gather_kernel<NS, 2, KSL>;
   constexpr size_t lds = (size_t)2 * 16 * NS * (KSL * 64 + 16);
-  static PerDeviceOnce lds_cap;
-  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  AM_LDS_OPTIN_STAGE(kern);
   r.nkg = a.Cin / (32 * KSL);
   dim3 grid((unsigned)(((r.ntile + 7) / 8) * 8 * r.ny * r.ncls), 1, 1);
   AM_LAUNCH(kern, grid, dim3(256), lds, st, a, r);
-  AM_CHECK_LAUNCH();
+  AM_CHECK_LAUNCH_STAGE();
   return 1;
 }
 

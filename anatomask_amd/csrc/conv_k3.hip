@@ -584,18 +584,18 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
   if (ep && a.partials) return 0;                  // (no caller fuses a store epilogue AND asks for statistics: conv_igemm.hip serves it)
   auto kern = ep ? conv_k3_kernel<4, true, false> : (a.partials ? conv_k3_kernel<4, false, true> : conv_k3_kernel<4, false, false>);
   if (c.Cout % 64) kern = ep ? conv_k3_kernel<2, true, false> : (a.partials ? conv_k3_kernel<2, false, true> : conv_k3_kernel<2, false, false>);
-  static PerDeviceOnce lds_cap;
-  lds_cap.run([&](int) {
-    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<4, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<2, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)conv_k3_kernel<2, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-  });
+  {
+    static PerDeviceOnce lds_cap; static int optin_err = 0;
+    lds_cap.run([&](int) {
+      const void* ks[6] = {(const void*)conv_k3_kernel<4, true, false>, (const void*)conv_k3_kernel<4, false, true>, (const void*)conv_k3_kernel<4, false, false>,
+                           (const void*)conv_k3_kernel<2, true, false>, (const void*)conv_k3_kernel<2, false, true>, (const void*)conv_k3_kernel<2, false, false>};
+      for (const void* kp : ks) { hipError_t e_ = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e_ != hipSuccess) optin_err = (int)e_; }
+      (void)hipGetLastError();
+    });
+    if (optin_err) return AM_STAGE_ERR(optin_err);
+  }
   AM_LAUNCH(kern, dim3(G), dim3(512), KLDS, (hipStream_t)stream, a);
-  AM_CHECK_LAUNCH();
+  AM_CHECK_LAUNCH_STAGE();
   return 1;
 }
 
@@ -625,10 +625,9 @@ int conv_k3t_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, voi
   { const char* e = getenv("AM_K3_DBG"); a.dbg = e ? atoi(e) : 0; }
 #endif
   auto kern = conv_k3_kernel<4, false, false, true>;
-  static PerDeviceOnce lds_cap;
-  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  AM_LDS_OPTIN_STAGE(kern);
   AM_LAUNCH(kern, dim3(G), dim3(512), KLDS, (hipStream_t)stream, a);
-  AM_CHECK_LAUNCH();
+  AM_CHECK_LAUNCH_STAGE();
   return 1;
 }
 

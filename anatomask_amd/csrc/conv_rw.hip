@@ -441,11 +441,40 @@ bool rw_geometry(RwGeo& G, int mode, int dtype, int k, int stride, int B, int Do
 template <int NW, int BD, int BH, int BW, int NS, int NIT, bool HR, int LR>
 int rw_launch(ConvArgs& a, RwArgs& r, const RwGeo& G, size_t lds, hipStream_t st) {
   auto kern = conv_rw_kernel<NW, BD, BH, BW, NS, NIT, HR, LR>;
-  static PerDeviceOnce lds_cap;
-  lds_cap.run([&](int) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); (void)hipGetLastError(); });
+  AM_LDS_OPTIN_STAGE(kern);
   dim3 grid(G.nwg, (a.Cout + 16 * NS - 1) / (16 * NS), 1);
   AM_LAUNCH(kern, grid, dim3(NW * 64), lds, st, a, r);
-  AM_CHECK_LAUNCH();
+  AM_CHECK_LAUNCH_STAGE();
+  return 1;
+}
+
+// EVERY acceptance condition of the resident-weight kernel that follows from the shape alone: the geometry, the tap plan (h-run order for
+// the 8x4x16 brick), the LDS footprint (brick + all taps' weights + the workgroup's brick table, which grows with n_active: level 0 of
+// STUNet-B 128^3 stops fitting above ~4864 active patches) and the staging iteration count.  conv_rw_rows and am_conv3d_prenorm_supported
+// PREDICT with it what conv_rw_launch will do, so they cannot disagree with the launch.  P.a must hold the caller's arguments (or be default).
+struct RwFit { size_t lds; int ntaps; };
+constexpr int RW_LR = 96;                                // conflict-free AND additive row stride (the generic kernel's 80 B is 2-way conflicted: it must fit two workgroups per CU)
+
+static int rw_fit(RwGeo& G, Plan& P, RwFit& F, int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout,
+                  bool sparse, int out_bshift, int n_active) {
+  if (!rw_geometry(G, mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, sparse, out_bshift, n_active)) return 0;
+  P.bd = G.bd; P.bh = G.bh; P.bw = G.bw; P.nt_tile = G.nt_tile;
+  const int rc = build_plan(P, mode, ksize, stride);
+  if (rc) return rc;
+  ConvArgs& a = P.a;
+  if (G.hr && !a.hreuse) return 0;
+  F.ntaps = a.tap_begin[a.nunit];
+  size_t mxv = 0;
+  for (int c = 0; c < a.nunit; ++c) { const size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
+  size_t brick = mxv * RW_LR;
+  if (brick < 8192) brick = 8192;                        // the statistics fold reuses the head of the brick
+  a.w_lds_off = (int)brick;
+  const int chunk = (G.nbrick + G.nwg - 1) / G.nwg;      // bricks per workgroup -> 32-byte rows of its brick table
+  F.lds = brick + (size_t)F.ntaps * G.nt_tile * ROWB + (size_t)chunk * 32;
+  if (F.lds > 160 * 1024) return 0;
+  const int nit = (int)((mxv * 4 + G.nw * 64 - 1) / (G.nw * 64));
+  // 8x4x16 brick, haloed 10x6x18 = 1080 rows -> 9 staging iterations of 128 rows; 4x8x8 brick, sub-lattice sub-bricks of <= 5x9x9 = 405 rows -> 7 of 64
+  if (nit > (G.hr ? 9 : 7)) return 0;
   return 1;
 }
 
@@ -455,8 +484,8 @@ namespace amconv {
 
 int conv_rw_rows(int mode, int dtype, int ksize, int stride, int B, int Do, int Ho, int Wo, int Cin, int Cout, int out_sparse, int out_bshift,
                  int n_active) {
-  RwGeo G;
-  return rw_geometry(G, mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse != 0, out_bshift, n_active) ? G.nwg : 0;
+  RwGeo G; Plan P; RwFit F;
+  return rw_fit(G, P, F, mode, dtype, ksize, stride, B, Do, Ho, Wo, Cin, Cout, out_sparse != 0, out_bshift, n_active) == 1 ? G.nwg : 0;
 }
 
 int conv_rw_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, const int* active_list, int n_active, void* stream) {
@@ -465,40 +494,21 @@ int conv_rw_launch(int mode, int dtype, int ksize, int stride, ConvArgs& a0, con
   if (a0.accumulate || a0.ep_scale || a0.ep_res || a0.ep_act != AM_ACT_NONE) return 0;
   if (sparse && !active_list) return 0;
   if (a0.in_scale && (!a0.in_shift || mode != AM_CONV_FWD)) return 0;
-  RwGeo G;
-  if (!rw_geometry(G, mode, dtype, ksize, stride, a0.B, a0.Do, a0.Ho, a0.Wo, a0.Cin, a0.Cout, sparse, a0.out_mask.bs, n_active)) return 0;
   if (sparse) {                                          // the source halo must stay inside the 3x3x3 patch neighbourhood
     const int in_patch = 1 << a0.in_mask.bs;
     if (in_patch < 4 || (in_patch != (1 << a0.out_mask.bs) * (mode == AM_CONV_FWD ? stride : 1))) return 0;
   }
-  Plan P;
+  RwGeo G; Plan P; RwFit F;
   P.a = a0;
-  P.bd = G.bd; P.bh = G.bh; P.bw = G.bw; P.nt_tile = G.nt_tile;
-  const int rc = build_plan(P, mode, ksize, stride);
-  if (rc) return rc;
+  const int fit = rw_fit(G, P, F, mode, dtype, ksize, stride, a0.B, a0.Do, a0.Ho, a0.Wo, a0.Cin, a0.Cout, sparse, a0.out_mask.bs, n_active);
+  if (fit != 1) return fit;
   ConvArgs& a = P.a;
-  if (G.hr && !a.hreuse) return 0;
-  int ntaps = a.tap_begin[a.nunit];
-  size_t mxv = 0;
-  for (int c = 0; c < a.nunit; ++c) { const size_t v = (size_t)a.ed[c] * a.eh[c] * a.ew[c]; if (v > mxv) mxv = v; }
-  constexpr int LR = 96;                                 // conflict-free AND additive row stride (the generic kernel's 80 B is 2-way conflicted: it must fit two workgroups per CU)
-  size_t brick = mxv * LR;
-  if (brick < 8192) brick = 8192;                        // the statistics fold reuses the head of the brick
-  a.w_lds_off = (int)brick;
-  const int chunk = (G.nbrick + G.nwg - 1) / G.nwg;      // bricks per workgroup -> 32-byte rows of its brick table
-  const size_t lds = brick + (size_t)ntaps * G.nt_tile * ROWB + (size_t)chunk * 32;
-  if (lds > 160 * 1024) return 0;
-  const int nit = (int)((mxv * 4 + G.nw * 64 - 1) / (G.nw * 64));
   a.nbd = a.Do / G.bd; a.nbh = a.Ho / G.bh; a.nbw = a.Wo / G.bw;
   RwArgs r;
-  r.plist = sparse ? active_list : nullptr; r.nbrick = G.nbrick; r.pbd = G.pbd; r.pbh = G.pbh; r.pbw = G.pbw; r.pq = G.pq; r.ntaps = ntaps;
+  r.plist = sparse ? active_list : nullptr; r.nbrick = G.nbrick; r.pbd = G.pbd; r.pbh = G.pbh; r.pbw = G.pbw; r.pq = G.pq; r.ntaps = F.ntaps;
   hipStream_t st = (hipStream_t)stream;
-  if (G.hr) {                                            // 8x4x16 brick, haloed 10x6x18 = 1080 rows -> 9 staging iterations of 128 rows
-    if (nit > 9) return 0;
-    return rw_launch<8, 8, 4, 16, 2, 9, true, LR>(a, r, G, lds, st);
-  }
-  if (nit > 7) return 0;                                 // 4x8x8 brick, sub-lattice sub-bricks of <= 5x9x9 = 405 rows -> 7 iterations of 64 rows
-  return G.nt_tile == 32 ? rw_launch<4, 4, 8, 8, 2, 7, false, LR>(a, r, G, lds, st) : rw_launch<4, 4, 8, 8, 4, 7, false, LR>(a, r, G, lds, st);
+  if (G.hr) return rw_launch<8, 8, 4, 16, 2, 9, true, RW_LR>(a, r, G, F.lds, st);
+  return G.nt_tile == 32 ? rw_launch<4, 4, 8, 8, 2, 7, false, RW_LR>(a, r, G, F.lds, st) : rw_launch<4, 4, 8, 8, 4, 7, false, RW_LR>(a, r, G, F.lds, st);
 }
 
 }  // namespace amconv

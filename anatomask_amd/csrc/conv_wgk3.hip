@@ -59,9 +59,6 @@ template <typename P> __device__ __forceinline__ P* w_uni_ptr(P* p) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
   return (P*)(((unsigned long long)hi << 32) | lo);
 }
-__device__ __forceinline__ s16x4 w_tr_read(const unsigned char* p) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
-}
 #define WK_LDSP(off) ((__attribute__((address_space(3))) void*)(lds + (off)))
 
 // The transposing reads are issued as inline assembly: behind an LDS-DMA the compiler puts `s_waitcnt vmcnt(0)` in front of every
@@ -349,7 +346,7 @@ bool conv_wgk3_qualifies(int B, int D, int H, int W, int Cx, int Cy) {
   return ncol >= 8 && (long)ncol * D >= 8 * 64;            // at least one column per XCD and 64 bricks per slot (a slot flushes 2 x 147 KB of atomics)
 }
 
-// 1: the launch was served; 0: the shape does not qualify (the caller goes on to conv_wgrad.hip); < 0 / hipError_t: failure
+// 1: the launch was served; 0: the shape does not qualify (the caller goes on to conv_wgrad.hip); < 0: failure (AM_STAGE_ERR)
 int conv_wgk3_launch(const void* x, const void* dy, float* dw, int B, int D, int H, int W, int Cx, int Cy, void* stream) {
   if (!conv_wgk3_qualifies(B, D, H, W, Cx, Cy)) return 0;
   const int nbh = H / 8, nbw = W / 16, ncol = B * nbh * nbw;
@@ -357,8 +354,10 @@ int conv_wgk3_launch(const void* x, const void* dy, float* dw, int B, int D, int
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WG_NOK3"); if (e_ && atoi(e_)) return 0; }
 #endif
-  static int cus_cached = 0;
-  if (!cus_cached) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); cus_cached = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; (void)hipGetLastError(); }
+  static PerDeviceOnce cu_once; static int cus_of[64];     // per device (ordinal & 63, as PerDeviceOnce keys it): the slot count follows the device that launches
+  int dev_ = 0; (void)hipGetDevice(&dev_);
+  cu_once.run([&](int d) { hipDeviceProp_t pr; cus_of[d & 63] = (hipGetDeviceProperties(&pr, d) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; (void)hipGetLastError(); });
+  const int cus_cached = cus_of[dev_ & 63] > 0 ? cus_of[dev_ & 63] : 256;
   const int cap = cus_cached / 8 > 0 ? cus_cached / 8 : 1;   // resident workgroups per XCD: one per CU
   Wk3Args a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.dw = dw;
@@ -399,15 +398,11 @@ int conv_wgk3_launch(const void* x, const void* dy, float* dw, int B, int D, int
 #ifdef AM_ABLATE
   { const char* e_ = getenv("AM_WGK3_DBG"); a.dbg = e_ ? atoi(e_) : 0; }
 #endif
-  static PerDeviceOnce lds_cap;
-  lds_cap.run([&](int) {
-    (void)hipFuncSetAttribute((const void*)wgrad_k3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)wgrad_k3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-  });
+  AM_LDS_OPTIN_STAGE(wgrad_k3_kernel<4>);
+  AM_LDS_OPTIN_STAGE(wgrad_k3_kernel<2>);
   if (wide) AM_LAUNCH(wgrad_k3_kernel<4>, dim3((unsigned)(a.split * nsib)), dim3(512), WkGeo<4>::LDS, (hipStream_t)stream, a);
   else AM_LAUNCH(wgrad_k3_kernel<2>, dim3((unsigned)(a.split * nsib)), dim3(512), WkGeo<2>::LDS, (hipStream_t)stream, a);
-  AM_CHECK_LAUNCH();
+  AM_CHECK_LAUNCH_STAGE();
   return 1;
 }
 

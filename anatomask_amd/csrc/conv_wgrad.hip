@@ -912,7 +912,8 @@ extern "C" int am_conv3d_wgrad(int mode, int dtype, int ksize, int stride, const
   const bool bf = dtype == AM_DT_BF16;
   if (bf && mode == AM_CONV_FWD && ksize == 3 && stride == 1 && !x_mask && !y_mask && !det_workspace && Dx == Dy && Hx == Hy && Wx == Wy) {
     const int rc = amconv::conv_wgk3_launch(x, dy, dw_packed, B, Dy, Hy, Wy, Cx, Cy, stream);
-    if (rc != 0) return rc == 1 ? 0 : rc;
+    if (rc < 0) return rc;                                 // (a failed launch: never "served", never a silent fall-through)
+    if (rc == 1) return 0;
   }
   // units: taps that share the dY operand AND one dense X sub-brick
   //   conv stride 1: one unit per d-tap (9 taps, no d-halo);  ConvT: the 8 output parities (8 taps each);

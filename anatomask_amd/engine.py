@@ -185,8 +185,9 @@ class PackCache:
     The first step packs each weight when it is first used; from then on the packed copies persist and ONE batched launch
     (`am_pack_weights_batched`) rebuilds all of them after every optimizer / EMA update (84 launches -> 1)."""
 
-    def __init__(self, dtype, f32_split: bool = False):
+    def __init__(self, dtype, f32_split: bool = False, deterministic: bool = False):
         self.dtype = dtype
+        self.deterministic = bool(deterministic)      # weight gradients as ordered per-slot folds instead of fp32 atomics (SparK.deterministic_wgrad)
         self.f32_split = bool(dtype == torch.float32 and f32_split)      # fp32 storage: products from bf16 hi / lo splits (ops.py)
         self.store: Dict[Tuple[str, bool], torch.Tensor] = {}
         self.src: Dict[Tuple[str, bool], torch.Tensor] = {}
@@ -475,7 +476,7 @@ def _join_side(dev):
 
 def _wgrad_into(pk: PackCache, G, name, mode, x, dy, k, stride, transposed=False, **masks):
     def run():
-        dwp = ops.conv3d_wgrad(mode, x, dy, k, stride, f32_split=pk.f32_split, **masks)
+        dwp = ops.conv3d_wgrad(mode, x, dy, k, stride, f32_split=pk.f32_split, deterministic=pk.deterministic, **masks)
         ops.unpack_grad(dwp, G[name], transposed, accumulate=True)
     _on_side(x.device, (x, dy), run)
 
@@ -531,7 +532,7 @@ def decoder_backward(spec: Spec, W, G, pk: PackCache, tape: Tape, drec: torch.Te
     g = None
     if not fused_head:
         g = ops.proj_bwd(tape.last, drec, W["dense_decoder.proj.weight"].view(-1), G["dense_decoder.proj.weight"].view(-1),
-                         G["dense_decoder.proj.bias"])
+                         G["dense_decoder.proj.bias"], deterministic=pk.deterministic)
         if after_group:
             after_group("proj")
     # ---- decoder, fine -> coarse.  g = grad wrt block output (= grad wrt to_dec[i+1] too)
@@ -597,8 +598,8 @@ def _enc_block_backward(W, G, pk: PackCache, inp: torch.Tensor, mask: MaskInfo, 
                             G[f"{p}.norm1.weight"], G[f"{p}.norm1.bias"], dxsum=G[f"{p}.conv1.bias"], reduced=red1)
     stride = t["stride"]
     if s == 0 and t["first"]:                        # Cin = 1 stem: weight/bias gradients only
-        ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None)
-        ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), None)
+        ops.stem_conv_wgrad(inp, dy1, 3, mask, bs, G[f"{p}.conv1.weight"].view(-1, 27), None, deterministic=pk.deterministic)
+        ops.stem_conv_wgrad(inp, dpre, 1, mask, bs, G[f"{p}.conv3.weight"].view(-1, 1), None, deterministic=pk.deterministic)
         return None
     bsx = bs + (1 if stride == 2 else 0)
     spx = tuple(x.shape[1:4])

@@ -441,6 +441,8 @@ class SparK(nn.Module):
         # fp32 storage only: matrix products from bf16 hi / lo splits (AM_DT_F32S) instead of the exact fp32 matrix instruction; a property
         # of THIS model (its PackCache marks every packed weight copy with it), see set_f32_split
         self.f32_split = bool(ops.DEFAULT_F32_SPLIT)
+        # weight gradients as ordered per-slot folds instead of fp32 atomics (am_conv3d_wgrad's det_workspace); a property of THIS model too
+        self.deterministic_wgrad = False
         self._flat: Optional[torch.Tensor] = None
         self._after_group = None
         # Any encoder other than this package's STUNet (a dense backbone rewritten by the sparse layer zoo, SparseEncoder.__init__) runs
@@ -515,14 +517,22 @@ class SparK(nn.Module):
             o += b.numel()
         self._iflat, self._n_ibuf = iflat, o
         self._flat, self._gflat, self._bflat, self._live_end, self._offs = flat, gflat, bflat, offs["live_end"], offs
-        self._pack = engine.PackCache(self.compute_dtype, self.f32_split)
+        self._pack = engine.PackCache(self.compute_dtype, self.f32_split, self.deterministic_wgrad)
+
+    def set_deterministic_wgrad(self, flag: bool):
+        """True: the convolution / stem / projection weight gradients of THIS model's backward are per-slot partial sums folded in a fixed
+        order (bit-reproducible, +3 % step time); False: fp32 atomics.  No process-wide switch."""
+        self.deterministic_wgrad = bool(flag)
+        if self._flat is not None and not self._generic:
+            self._pack.deterministic = self.deterministic_wgrad
+        return self
 
     def set_f32_split(self, flag: bool):
         """fp32-storage model: True = products from bf16 hi / lo splits of both operands with fp32 accumulation (16 significant bits per
         operand, 4x the matrix rate), False = the exact fp32 matrix instruction (parity mode).  The packed weight copies are re-made."""
         self.f32_split = bool(flag)
         if self._flat is not None and not self._generic:
-            self._pack = engine.PackCache(self.compute_dtype, self.f32_split)
+            self._pack = engine.PackCache(self.compute_dtype, self.f32_split, self.deterministic_wgrad)
         return self
 
     def _apply(self, fn, *a, **k):               # .to()/.cuda() replace parameter storage: re-flatten lazily

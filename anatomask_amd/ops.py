@@ -294,7 +294,13 @@ def conv3d_prenorm(x: torch.Tensor, st: "NormStats", act: int, w_packed: torch.T
 
 
 # Deterministic weight gradients (am_conv3d_wgrad's det_workspace): per-slot partial sums + an ordered fold instead of fp32 atomics.
+# A property of a MODEL (SparK.deterministic_wgrad -> its PackCache -> the `deterministic` argument of the three gradient ops below);
+# DETERMINISTIC_WGRAD is only what a direct caller of these ops gets when it passes deterministic=None (tests, tools).
 DETERMINISTIC_WGRAD = False
+
+
+def _det(flag) -> bool:
+    return DETERMINISTIC_WGRAD if flag is None else bool(flag)
 _DET_WS: dict = {}
 
 
@@ -314,14 +320,14 @@ GATHER_WGRAD = True      # (tools: same-process A/B of the gather-form weight gr
 
 def conv3d_wgrad(mode: int, x: torch.Tensor, dy: torch.Tensor, ksize: int, stride: int,
                  x_mask: Optional[MaskInfo] = None, x_bshift: int = 0, y_mask: Optional[MaskInfo] = None,
-                 y_bshift: int = 0, f32_split: bool = False) -> torch.Tensor:
+                 y_bshift: int = 0, f32_split: bool = False, deterministic: Optional[bool] = None) -> torch.Tensor:
     B, Dx, Hx, Wx, Cx = x.shape
     _, Dy, Hy, Wy, Cy = dy.shape
     taps = ksize ** 3
     dw = torch.zeros(taps, Cy, Cx, device=x.device, dtype=torch.float32)
     mk = x_mask or y_mask
     mp, fd, fh, fw = _mk(mk)
-    ws = _det_workspace(x.device, taps * Cy * Cx) if DETERMINISTIC_WGRAD else None
+    ws = _det_workspace(x.device, taps * Cy * Cx) if _det(deterministic) else None
 
     al = _al(y_mask)
     # levels with 1- / 2-voxel patches: the gather form (K-major copies of the active voxels + plain GEMMs) needs scratch
@@ -379,10 +385,10 @@ def stem_conv_fwd(x_b1: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tens
 
 
 def stem_conv_wgrad(x_b1: torch.Tensor, dy: torch.Tensor, ksize: int, mask: Optional[MaskInfo], bshift: int,
-                    dw_accum: torch.Tensor, db_accum: Optional[torch.Tensor]):
+                    dw_accum: torch.Tensor, db_accum: Optional[torch.Tensor], deterministic: Optional[bool] = None):
     B, D, H, W, Cc = dy.shape
     mp, fd, fh, fw = _mk(mask)
-    ws = _det_workspace(dy.device, 1024 * Cc * (ksize ** 3 + 1) // 8) if (DETERMINISTIC_WGRAD and dy.dtype == torch.bfloat16) else None
+    ws = _det_workspace(dy.device, 1024 * Cc * (ksize ** 3 + 1) // 8) if (_det(deterministic) and dy.dtype == torch.bfloat16) else None
     hip.lib().stem_conv_wgrad(_dt(dy), x_b1.data_ptr(), dy.data_ptr(), B, D, H, W, Cc, ksize, mp, bshift, fd, fh, fw,
                               dw_accum.data_ptr(), _p(db_accum), *_al(mask), _p(ws), ws.numel() if ws is not None else 0, _stream())
 
@@ -574,10 +580,11 @@ def proj_norm_bwd(x: torch.Tensor, st: "NormStats", drec: torch.Tensor, w: torch
     return dx
 
 
-def proj_bwd(x: torch.Tensor, drec: torch.Tensor, w: torch.Tensor, dw_accum: torch.Tensor, db_accum: torch.Tensor) -> torch.Tensor:
+def proj_bwd(x: torch.Tensor, drec: torch.Tensor, w: torch.Tensor, dw_accum: torch.Tensor, db_accum: torch.Tensor,
+             deterministic: Optional[bool] = None) -> torch.Tensor:
     B, D, H, W, Cc = x.shape
     dx = torch.empty_like(x)
-    ws = _det_workspace(x.device, 4096 * (Cc + 1) // 8) if DETERMINISTIC_WGRAD else None
+    ws = _det_workspace(x.device, 4096 * (Cc + 1) // 8) if _det(deterministic) else None
     hip.lib().proj_bwd(_dt(x), x.data_ptr(), drec.data_ptr(), B * D * H * W, Cc, w.data_ptr(), dx.data_ptr(), dw_accum.data_ptr(),
                        db_accum.data_ptr(), _p(ws), ws.numel() if ws is not None else 0, _stream())
     return dx

@@ -53,12 +53,11 @@ class AnatoMaskTrainer:
         self.f32_split = bool(f32_split) or bool(getattr(model, "f32_split", False))
         model.set_f32_split(self.f32_split)
         self._capturing, self._graph, self._graph_key = False, None, None
-        if deterministic_wgrad:
-            # convolution weight gradients as per-slot partial sums folded in a fixed order instead of fp32 atomics (am_conv3d_wgrad's
-            # det_workspace; +3 % step time).  Process-wide, like torch.use_deterministic_algorithms.  The per-channel norm statistics
-            # keep their fp64 atomics (order-dependent at the 1e-16 level).
-            from . import ops
-            ops.DETERMINISTIC_WGRAD = True
+        # convolution weight gradients as per-slot partial sums folded in a fixed order instead of fp32 atomics (am_conv3d_wgrad's
+        # det_workspace; +3 % step time).  A property of the MODEL (SparK.deterministic_wgrad -> its PackCache), like f32_split: nothing
+        # process-wide is touched.  The per-channel norm statistics keep their fp64 atomics (order-dependent at the 1e-16 level).
+        self.deterministic_wgrad = bool(deterministic_wgrad) or bool(getattr(model, "deterministic_wgrad", False))
+        model.set_deterministic_wgrad(self.deterministic_wgrad)
         self.self_distill = self_distill      # False: plain SparK step (P/spark3D.py:98-146, P/pretrain.py): random mask, no teacher
         model._ensure_flat()
         model.train()
@@ -322,7 +321,8 @@ class AnatoMaskTrainer:
         # 5. backward (:435) with overlapped gradient exchange
         with _Range(tr_, "anatomask.backward"):
             m._gflat.zero_()
-            self._exchange_begin()
+            if self.distributed and not self._capturing:          # (the timeline's timing events exist only where an exchange does; never under capture)
+                self._exchange_begin()
             engine.backward(spec, m._W, m._G, m._pack, x, mi, tape, drec, self._after_group if self.distributed else None, join_before_hook=False)
             del tape
         with _Range(tr_, "anatomask.exchange_wait"):

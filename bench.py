@@ -265,7 +265,7 @@ def ranks_report(world, rank, dist, dev, per_ms, dt_local):
         ident = f"host-pid{os.getpid()}"
     mine = {"rank": rank, "device": ident, "window_s": round(dt_local, 4), "step_ms_median": round(sorted(per_ms)[len(per_ms) // 2], 3),
             "step_ms_min": round(min(per_ms), 3), "step_ms_max": round(max(per_ms), 3)}
-    if world == 1:
+    if dist is None:
         return [mine]
     got = [None] * world
     dist.all_gather_object(got, mine)
@@ -274,9 +274,10 @@ def ranks_report(world, rank, dist, dev, per_ms, dt_local):
 
 def timed_window(step, steps, world, dist, dev):
     """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides (wall clock, MAX over ranks), with a HIP event
-    after every step for the per-step distribution.  dev None: host-only ranks (the gloo dry run), no device calls."""
+    after every step for the per-step distribution.  dev None: host-only ranks (the gloo dry run), no device calls.
+    dist None: no process group (the plain N = 1 run); a process group of ONE rank (AM_BENCH_FORCE_DIST) runs every collective."""
     gpu = dev is not None
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     if gpu:
         torch.cuda.synchronize()
@@ -289,14 +290,14 @@ def timed_window(step, steps, world, dist, dev):
         out = step()
         if gpu:
             evs[i + 1].record()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     if gpu:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps)) if gpu else [dt / steps * 1e3] * steps
     timed_window.local_s = dt                               # this rank's own clock (ranks_report)
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([dt], device=dev if gpu else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -397,8 +398,19 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    # AM_BENCH_FORCE_DIST=1 (set by a launcher BEFORE this process touches the GPU: tests/test_e2e_gpu.py::test_bench_rank_body_rccl_world1): the
+    # N > 1 rank body -- RCCL process group, barriers, MAX-over-ranks clock, the gradient exchange, the exchange-off window, exchange_report,
+    # ranks_report's all_gather_object -- with a world of ONE rank, so that every line of it has run on a GPU before an 8-GPU node runs it
+    dist_on = world > 1 or (os.environ.get("AM_BENCH_FORCE_DIST") == "1" and launch.launched())
+    if dist_on:
+        # a collective that hangs (a rank that died, a link that never came up) must END the job: RCCL's watchdog aborts the process once a
+        # collective is older than `timeout` (TORCH_NCCL_ASYNC_ERROR_HANDLING=1, torch's default, tears the process down), the launcher
+        # then kills the other ranks and exits non-zero -- instead of ten silent minutes at a barrier
+        import datetime
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get("AM_BENCH_COLLECTIVE_TIMEOUT_S", "240"))))
+    else:
+        dist = None
 
     kw = M.STUNET_CONFIGS[a.size]
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
@@ -449,7 +461,7 @@ def main():
         del feed, host
 
     # ---- exposed communication: the same window with the gradient exchange switched off (N > 1)
-    if world > 1:
+    if dist_on:
         tr.distributed = False
         for _ in range(2):
             tr.step(x, epoch=500)
@@ -459,13 +471,17 @@ def main():
         if rank == 0:
             res["exchange"] = exchange_report(tr, model._live_end, world, dt, dtn, a.steps, "rccl")
 
+    # every collective of the job is behind us: the ranks part HERE (barrier, then the process group goes), and rank 0 measures the
+    # roofline / encoder figures alone -- no rank waits at a barrier while another one benchmarks kernels
+    if dist_on:
+        dist.barrier()
+        tr.distributed = False
+        dist.destroy_process_group()
     if rank == 0 and not a.no_roofline and a.dtype == "bf16":
         res["roofline"] = dominant_kernel_roofline(a.batch, dev, tr if world == 1 else None, x, C=kw["width"] // 8, S=a.patch, size=a.size)
         enc = encoder_forward_hbm(model, x, dev, a.size, a.patch, a.mask_ratio)
         if enc is not None:
             res["encoder_fwd_hbm"] = enc
-    if world > 1:
-        dist.barrier()
     if rank == 0:
         del tr, model, x
         torch.cuda.empty_cache()
@@ -477,8 +493,6 @@ def main():
             except Exception as e:                                   # e.g. host OOM: report, do not fail the bench
                 res["cpu_baseline"] = {"value": None, "unit": "volumes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -12,7 +12,8 @@
  *    per patch edge is "block-sparse": kernels read inactive voxels as 0 and never rely on what is
  *    stored there.  mask == NULL means dense.
  *  - every function is asynchronous on `stream`, never allocates, never synchronises, returns 0 or
- *    a negative argument error / positive hipError_t.
+ *    a negative argument error / positive hipError_t; -(1000 + hipError_t) = a launch that failed inside one of
+ *    the convolution's kernel-selection stages (never reported as success, never a silent fall-through).
  *  - packed conv weights: [tap][rows_p][K_p] in the compute dtype, rows = channels of the tensor WRITTEN,
  *    K = channels of the tensor READ, tap = (td*k + th)*k + tw of the original kernel; rows/K are zero-padded
  *    to whole MFMA tiles (am_packed_dims) so the inner loop carries no bounds logic.

@@ -1,6 +1,6 @@
 """Not a test (pytest does not collect it): how much of the bf16-storage distance from fp32 is SUMMATION-ORDER noise?
 
-    python tools/with_lib.py anatomask_amd/libanatomask_hip_ablate.so tests/probe_bf16_order_noise.py TAG      (tools build; the AM_* switches
+    python tools/with_lib.py build_ab/libanatomask_hip_ablate.so tests/probe_bf16_order_noise.py TAG      (tools build; the AM_* switches
     select older kernels for single layers = the same function in another summation order)
 
 Runs the step of test_config2_stunet_b_128_bf16_step_vs_oracle, prints the per-tensor distances from the fp32 oracle for the worst tensors and

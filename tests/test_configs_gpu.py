@@ -212,6 +212,149 @@ def test_config2_stunet_b_128_fp32_storage_step_vs_oracle(f32_split):
         assert float(np.median([r_[2] for r_ in rows])) <= 1.2e-2 and sum(r_[2] > F32_REL for r_ in rows) <= 3
 
 
+# ------------------------------------------------------------------ N steps at the headline configuration
+# north_star: "reconstruction loss and encoder weights after N steps must match the reference PyTorch CPU path" (P/pretrain_AntoMask.py:418-441).
+# N = 3 full AnatoMask steps of STUNet-B at 128^3, B = 1, epoch 500 of 999 (len_loss = 76 of the 307 masked patches are the teacher's hardest:
+# the hard-mask branch of generate_mask is INSIDE every compared step), a fresh volume per step, the two random draws teacher-forced,
+# against oracle.train_step.  Every compared step runs the persistent LDS-DMA kernels (conv_k3, its ConvT instantiation, wgrad_k3) that
+# carry 70 % of a step; steps 2 and 3 run them on UPDATED weights with a teacher that is no longer the student.
+NS_N, NS_EPOCH, NS_TOTAL, NS_LR, NS_DECAY = 3, 500, 999, 1e-4, 0.999
+
+
+def _ns_draws(cfg):
+    g = torch.Generator().manual_seed(23)
+    return [(O.smooth_volume(1, cfg.input_size, 100 + s), O.random_mask(cfg, 1, g), torch.rand(1, cfg.L, generator=g)) for s in range(NS_N)]
+
+
+def _ns_run_oracle(cfg, W0, draws, forced_masks=None):
+    """N oracle steps; forced_masks: the student masks of another run, handed to the sampler as keys (0 = visible, ties by id)."""
+    st = O.StepState(cfg, W0)
+    outs, snap1 = [], None
+    for s, (x, mask1, keys) in enumerate(draws):
+        if forced_masks is not None:
+            keys = 1.0 - forced_masks[s].reshape(1, cfg.L).float()
+        outs.append(O.train_step(st, x, mask1, keys, NS_EPOCH, NS_TOTAL, NS_LR, NS_DECAY))
+        if s == 0:
+            snap1 = ({k: v.clone() for k, v in st.student.items()}, {k: v.clone() for k, v in st.teacher.items()})
+    return st, outs, snap1
+
+
+@functools.lru_cache(maxsize=None)
+def _oracle_nsteps_b128():
+    cfg = O.Config.stunet_b((128, 128, 128), 0.6)
+    assert O.len_loss_for(cfg, NS_EPOCH, NS_TOTAL) == 76
+    W0 = O.seeded_state(cfg, 5)
+    draws = _ns_draws(cfg)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    st, outs, snap1 = _ns_run_oracle(cfg, W0, draws)
+    return cfg, W0, draws, st, outs, snap1
+
+
+@functools.lru_cache(maxsize=None)
+def _oracle_nsteps_b128_bf16_emulation():
+    """the same N steps under oracle.storage("bf16") (the IDEAL bf16-storage evaluation), on the fp32 run's student masks."""
+    cfg, W0, draws, st, outs, _ = _oracle_nsteps_b128()
+    with O.storage("bf16"):
+        ste, oute, _ = _ns_run_oracle(cfg, W0, draws, forced_masks=[o["mask"] for o in outs])
+    return ste, oute
+
+
+def _delta_rows(state, W0, ref_state, keys):
+    """per tensor: (name, numel, relative L2 error of the update, cosine, the same error relative to the tensor's own norm)."""
+    rows = []
+    for k in keys:
+        dw = (ref_state[k].double() - W0[k].double()).reshape(-1)
+        if float(dw.norm()) < 1e-12:
+            continue
+        dg = (state[k].double().cpu() - W0[k].double()).reshape(-1)
+        e = float((dg - dw).norm() / dw.norm())
+        rows.append((k, dw.numel(), e, float((dg * dw).sum() / (dg.norm() * dw.norm() + 1e-300)), float(dg.norm()) * e / (float(W0[k].norm()) + 1e-30)))
+    return rows
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32s", "bf16"])
+def test_config2_n_steps_vs_oracle(mode):
+    from anatomask_amd.trainer import AnatoMaskTrainer
+    from tests.test_oracle_golden import NSTEP_UPDATE_MEDIAN, NSTEP_WEIGHT_MAX, NSTEP_WEIGHT_MEDIAN, STEP1_FLIPPED, STEP1_UPDATE_MEDIAN
+    cfg, W0, draws, st, outs, snap1 = _oracle_nsteps_b128()
+    bf = mode == "bf16"
+    m = _build(cfg, W0, dtype=torch.bfloat16 if bf else torch.float32)
+    tr = AnatoMaskTrainer(m, lr=NS_LR, ema_decay=NS_DECAY, total_epochs=NS_TOTAL + 1, distributed=False, f32_split=mode == "f32s")
+    trainable = [k for k in O.trainable_keys(cfg) if not _ANALYTIC_ZERO.search(k)]
+    bn_stats = [k for k in W0 if k.endswith(("running_mean", "running_var"))]
+    hsnap1 = None
+    for s, (x, mask1, keys) in enumerate(draws):
+        o = outs[s]
+        if bf:      # bf16 storage: the student trains on the fp32 run's mask (a 5e-5 difference of the teacher's loss may swap a hard patch)
+            keys = 1.0 - o["mask"].reshape(1, cfg.L).float()
+        out = tr.step(x.to(DEV), epoch=NS_EPOCH, mask1=mask1, keys=keys)
+        torch.cuda.synchronize()
+        same = torch.equal(out["mask"].view(1, -1).bool().cpu(), o["mask"].view(1, -1))
+        rec_h, rec_o = out["recon_loss"].cpu().numpy(), o["recon_loss"].numpy()
+        l2 = np.abs(rec_h - rec_o).max() / rec_o.max()
+        rl_h, rl_o = out["rec_loss"].cpu().numpy(), o["rec_loss"].numpy()
+        print(f"STUNet-B 128^3 {mode} step {s + 1}/{NS_N} (epoch {NS_EPOCH}, 76 hard patches): loss {out['loss'].item():.7f} / {o['loss']:.7f}  "
+              f"grad-norm {out['grad_norm'].item():.6f} / {o['grad_norm']:.6f}  teacher-l2 rel err {l2:.2e}  student per-patch rel err "
+              f"{np.abs(rl_h - rl_o).max() / rl_o.max():.2e}  mask equal {same}")
+        assert same, f"sampler mask diverged at step {s + 1}"
+        hard_o = np.argsort(rec_o, axis=1)[:, cfg.L - 76:]
+        assert not out["mask"].view(1, -1).bool().cpu().numpy()[0, hard_o[0]].any()
+        rel = abs(out["loss"].item() - o["loss"]) / o["loss"]
+        if bf:
+            assert l2 < (BF16_L2 if s == 0 else 4 * BF16_L2) and rel < 2e-3 and abs(out["grad_norm"].item() / o["grad_norm"] - 1) < 0.15
+            assert np.abs(rl_h - rl_o).max() < 3e-2 * rl_o.max()
+        else:
+            # (the tiny fixture's bounds, tests/test_e2e_gpu.py::test_trainer_n_steps_fp32_matches_reference: the trajectories decorrelate step by step)
+            assert rel < (3e-4 if s < 2 else 1e-3), (s, rel)
+            assert abs(out["grad_norm"].item() / o["grad_norm"] - 1) < (1e-3 if s == 0 else 4e-2), s
+            assert l2 < (2e-5 if mode == "f32s" else F32_L2) * (1 if s == 0 else 50)
+        if s == 0:
+            hsnap1 = ({k: v.detach().float().cpu().clone() for k, v in m.state_dict().items()},
+                      {k: v.detach().float().cpu().clone() for k, v in tr.teacher.ema.state_dict().items()})
+    fsd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    esd = {k: v.detach().float().cpu() for k, v in tr.teacher.ema.state_dict().items()}
+    assert all(torch.isfinite(v).all() for v in fsd.values())
+    for k in W0:                                           # integer buffers: exact, student and EMA
+        if k.endswith("num_batches_tracked"):
+            assert int(fsd[k]) == int(st.student[k]) == NS_N and int(esd[k]) == int(st.teacher[k]), k
+    # ---- strict after ONE step (pins clip / AdamW / EMA at full size): Adam's first update is lr * sign(g)
+    r1, r1e = _delta_rows(hsnap1[0], W0, snap1[0], trainable), _delta_rows(hsnap1[1], W0, snap1[1], trainable)
+    med1 = float(np.median([r[2] for r in r1]))
+    flipped = lambda hs, os_: sum(int(((hs[k].double() - os_[k].double()).abs() > 0.1 * (os_[k].double() - W0[k].double()).abs().max()).sum()) for k in trainable) / sum(W0[k].numel() for k in trainable)
+    f1, f1e = flipped(hsnap1[0], snap1[0]), flipped(hsnap1[1], snap1[1])
+    print(f"   first update vs oracle: median rel {med1:.2e}, elements off by > 10 % of the largest update: student {f1:.2e}, EMA {f1e:.2e}")
+    if not bf:
+        assert med1 < 30 * STEP1_UPDATE_MEDIAN          # (full size: ~100x more near-zero gradient elements per tensor than the 8..128-channel fixture; measured value printed)
+        assert f1 <= 10 * STEP1_FLIPPED and f1e <= 10 * STEP1_FLIPPED
+    # ---- after N steps: encoder / decoder weight updates, EMA, BatchNorm running statistics
+    rows, rows_e = _delta_rows(fsd, W0, st.student, trainable), _delta_rows(esd, W0, st.teacher, trainable)
+    enc = [r for r in rows if r[0].startswith(O.ENC)]
+    med, mx = float(np.median([r[2] for r in rows])), max(rows, key=lambda r: r[2])
+    wmed, wmx = float(np.median([r[4] for r in rows])), max(r[4] for r in rows)
+    print(f"   N-step update error vs oracle ({len(rows)} tensors, {len(enc)} of the encoder): median {med:.3f} (encoder {np.median([r[2] for r in enc]):.3f}) max {mx[2]:.3f} ({mx[0]}); "
+          f"weight-level median {wmed:.2e} max {wmx:.2e}; EMA median {np.median([r[2] for r in rows_e]):.3f}; min cos {min(r[3] for r in rows):.3f}")
+    bn = _delta_rows(fsd, W0, st.student, bn_stats)
+    bn_e = _delta_rows(esd, W0, st.teacher, bn_stats)
+    print(f"   BatchNorm running statistics after N steps ({len(bn)} buffers): update error max {max(r[2] for r in bn):.2e}, EMA copy max {max(r[2] for r in bn_e):.2e}")
+    if bf:
+        ste, oute = _oracle_nsteps_b128_bf16_emulation()
+        for s in range(NS_N):
+            assert torch.equal(oute[s]["mask"], outs[s]["mask"]), "the emulation's forced mask differs (a hard patch inside the forced visible set)"
+        ide = _delta_rows(ste.student, W0, st.student, trainable)
+        imed, imx = float(np.median([r[2] for r in ide])), max(r[2] for r in ide)
+        iw, iwx = float(np.median([r[4] for r in ide])), max(r[4] for r in ide)
+        print(f"   ideal bf16-storage emulation of the same N steps vs fp32 oracle: median {imed:.3f} max {imx:.3f}; weight-level median {iw:.2e} max {iwx:.2e}")
+        assert med < 1.3 * imed and mx[2] < 1.5 * imx and wmed < 1.3 * iw and wmx < 1.5 * iwx, (med, imed, mx, imx)
+        assert max(r[2] for r in bn) < 5e-2
+    else:
+        assert med < NSTEP_UPDATE_MEDIAN and wmed < NSTEP_WEIGHT_MEDIAN and wmx < NSTEP_WEIGHT_MAX, (med, wmed, wmx)
+        assert float(np.median([r[2] for r in rows_e])) < NSTEP_UPDATE_MEDIAN
+        for k, n_el, e, c, _ in rows + rows_e:
+            if n_el >= 64:
+                assert e < 0.9 and c > 0.5, (k, n_el, e, c)
+        assert max(r[2] for r in bn) < 5e-3 and max(r[2] for r in bn_e) < 5e-3
+
+
 @functools.lru_cache(maxsize=None)
 def _oracle_step_recipe():
     """ONE fp32 CPU oracle step of the reference's SHIPPED recipe shape: STUNet-B, input (112, 112, 128) (P/pretrain_AntoMask.py:188,209),

@@ -603,6 +603,40 @@ def test_two_ranks_on_one_gpu_stay_in_sync():
     assert r.stdout.count("mean-of-gradients ok: True") == 2, r.stdout[-2000:]
 
 
+def test_bench_rank_body_rccl_world1():
+    """bench.py's N > 1 rank body on the GPU BEFORE an 8-GPU node runs it: `torchrun --nproc-per-node 1` with
+    AM_BENCH_FORCE_DIST=1 (set by the launcher's environment, i.e. before the rank touches the GPU) makes the one rank take every
+    world > 1 branch over RCCL: init_process_group("nccl") with the collective timeout, the broadcast of parameters and buffers, the
+    barriers and the MAX-over-ranks clock of the timed window, the overlapped gradient exchange on the comm stream, the exchange-off
+    window, exchange_report with the per-collective timeline, ranks_report's all_gather_object on the nccl backend, the barrier +
+    destroy_process_group BEFORE the roofline section.  Ref: P/pretrain_AnatoMask_DDP.py:200,239-240,409-410,484."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from tests.test_launch import _check_timeline
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", AM_BENCH_FORCE_DIST="1", AM_BENCH_COLLECTIVE_TIMEOUT_S="120")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                        "--batch", "2", "--no-cpu-baseline", "--no-secondary", "--no-h2d"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["value"] > 0 and out["config"]["parallelism"] == "dp1"
+    ex = out["exchange"]
+    assert ex["backend"] == "rccl" and ex["ranks"] == 1 and ex["gradient_bytes_per_step"] > 200e6            # STUNet-B: 53 M live parameters
+    assert ex["collectives_per_step"] >= 4 and ex["largest_collective_bytes"] <= 64 << 20
+    assert ex["first_collective_after_tag"].startswith("dec")                                              # the exchange starts inside backward
+    _check_timeline(ex)
+    print("bench.py rank body over RCCL (world 1): %.2f ms/step, %.2f without the exchange, %d collectives, last step exposed %.3f ms"
+          % (out["ms_per_step"], ex["ms_per_step_without_exchange"], ex["collectives_per_step"], ex["exposed_ms_last_step"]))
+    assert "roofline" in out and out["roofline"]["frac"] > 0.2                                             # (measured after the process group was destroyed)
+
+
 def test_nonfinite_step_is_skipped_on_the_device_and_latched():
     """P/pretrain_AntoMask.py:441-446 checks `loss.item()` after every step.  Here the check is on the device (am_adamw_ema `guard`): a NaN
     volume at step k must leave weights, Adam moments, EMA teacher and BatchNorm buffers (running statistics AND num_batches_tracked) of

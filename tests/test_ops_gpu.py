@@ -567,6 +567,49 @@ def test_conv_prenorm_fused_input_norm(ops, act):
     assert (st_a.sums.cpu()[0] - refs).abs().max().item() <= 1e-5 * refs.abs().max().item()
 
 
+@pytest.mark.parametrize("n_active", [4800, 5000])
+def test_conv_prenorm_predicate_matches_launch_at_large_active_counts(ops, n_active):
+    """am_conv3d_prenorm_supported must PREDICT am_conv3d_prenorm: the resident-weight kernel keeps a brick table of its
+    workgroup in LDS that grows with the number of active patches, and at level 0 (16^3 patches, 32 channels) brick + weights + table
+    stop fitting 160 KB above 4864 active patches (STUNet-B 128^3 mask 0.6 from batch 24 on).  Below: the fused launch is taken and
+    equals norm_apply + conv3d.  Above: the predicate says no (the engine then runs the two-launch form, which every other kernel
+    serves) -- it used to say yes and the launch failed with -7 inside the teacher's forward."""
+    dtype = torch.bfloat16
+    B, C, f, bs = 20, 32, (8, 8, 8), 4
+    S = tuple(v << bs for v in f)
+    g = torch.Generator().manual_seed(n_active)
+    idx = torch.randperm(B * 512, generator=g)[:n_active]
+    mask = torch.zeros(B * 512, dtype=torch.bool).scatter_(0, idx, True).view(B, 1, *f)
+    mi = ops.MaskInfo.from_bool(mask, DEV)
+    assert mi.active_list()[1] == n_active
+    x = (torch.randn(B, *S, C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 0.5).to(dtype)
+    w = q(rnd(C, C, 3, 3, 3, seed=602, scale=1.0 / np.sqrt(C * 27)), dtype)
+    wp = ops.pack_weight(w.to(DEV), dtype, False, False)
+    st = ops.NormStats(C, DEV)
+    st.scale.copy_((rnd(C, seed=604).abs() + 0.5).to(DEV)); st.shift.copy_((rnd(C, seed=605) * 0.5).to(DEV))
+    ok = ops.conv3d_prenorm_supported(x, wp, S, 3, 1, mi, bs)
+    assert ok == (n_active <= 4864), (n_active, ok)
+    a_dev = ops.norm_apply(x, st, ops.ACT_LRELU, mi, bs)
+    y2, part2 = ops.conv3d(ops.CONV_FWD, a_dev, wp, None, S, 3, 1, in_mask=mi, in_bshift=bs, out_mask=mi, out_bshift=bs, want_partials=True)
+    torch.cuda.synchronize()
+    if ok:
+        y, part = ops.conv3d_prenorm(x, st, ops.ACT_LRELU, wp, None, S, 3, 1, mi, bs, want_partials=True)
+        lst = mi.active_list()[0][:n_active].cpu().tolist()      # b << 24 | pd << 16 | ph << 8 | pw
+        # compare on the active patches (what a kernel leaves at inactive voxels is unspecified)
+        for k in range(0, n_active, 97):
+            v = lst[k]
+            b_, pd, ph, pw = v >> 24, (v >> 16) & 255, (v >> 8) & 255, v & 255
+            pick = lambda t: t[b_, pd * 16:pd * 16 + 16, ph * 16:ph * 16 + 16, pw * 16:pw * 16 + 16].float()
+            d = (pick(y) - pick(y2)).abs().max().item()
+            assert d <= 4e-3 * pick(y2).abs().max().item() + 1e-3, (k, d)
+    else:
+        with pytest.raises(RuntimeError):                 # the launch itself still refuses (-7): the predicate is what the engine asks
+            ops.conv3d_prenorm(x, st, ops.ACT_LRELU, wp, None, S, 3, 1, mi, bs, want_partials=True)
+    s2 = ops.NormStats(C, DEV)
+    part2.reduce(sums=s2.sums)
+    assert torch.isfinite(s2.sums).all() and float(s2.sums.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("case", [(64, 64, (32, 32, 32), 2), (128, 64, (16, 32, 32), 4), (64, 128, (24, 16, 48), 6), (64, 64, (9, 8, 16), 64),
                                   (64, 32, (32, 32, 32), 2), (192, 96, (16, 16, 32), 8), (64, 32, (9, 8, 16), 64)])   # 32-wide cy tiles (Cout = 32, 96)
 def test_conv_wgrad_k3_dense_8wave_dma_kernel(ops, case):

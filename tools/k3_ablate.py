@@ -1,4 +1,4 @@
-"""Timing ablation of conv_k3_kernel (tools build only: python tools/with_lib.py anatomask_amd/libanatomask_hip_ablate.so tools/k3_ablate.py [B]).
+"""Timing ablation of conv_k3_kernel (tools build only: python tools/with_lib.py build_ab/libanatomask_hip_ablate.so tools/k3_ablate.py [B]).
 AM_K3_DBG bits: 1 no stores, 2 no brick DMA, 4 no weight DMA, 8 no MFMAs.  Results are wrong on purpose; only the time is read."""
 import os
 import sys

@@ -1,5 +1,5 @@
 """Isolated rates of the dense / block-sparse norm kernels on the tensors of the STUNet-B step (B=16, bf16), same process A/B of the
-workgroup-count targets (ablation build: python tools/with_lib.py anatomask_amd/libanatomask_hip_ablate.so tools/norm_bench.py)."""
+workgroup-count targets (ablation build: python tools/with_lib.py build_ab/libanatomask_hip_ablate.so tools/norm_bench.py)."""
 import os
 import sys
 

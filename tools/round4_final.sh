@@ -14,11 +14,11 @@ timeout 900 python3 bench.py --size H --patch 192 --batch 2 --recompute --steps 
 timeout 600 python3 tools/conv_census.py 16 > $out/conv_census.txt 2>&1; tail -1 $out/conv_census.txt
 AM_CENSUS_SIZE=L AM_CENSUS_PATCH=160 AM_CENSUS_MASK=0.7 timeout 600 python3 tools/conv_census.py 4 > $out/conv_census_stunet_L_160_m07_b4.txt 2>&1; tail -1 $out/conv_census_stunet_L_160_m07_b4.txt
 AM_CENSUS_SIZE=H AM_CENSUS_PATCH=192 AM_CENSUS_RECOMPUTE=1 timeout 600 python3 tools/conv_census.py 2 > $out/conv_census_stunet_H_192_recompute_b2.txt 2>&1; tail -1 $out/conv_census_stunet_H_192_recompute_b2.txt
-TARGETS=512,1024,2048,4096 timeout 300 python3 tools/with_lib.py anatomask_amd/libanatomask_hip_ablate.so tools/norm_bench.py 16 > $out/norm_bench_b16.txt 2>&1
+TARGETS=512,1024,2048,4096 timeout 300 python3 tools/with_lib.py build_ab/libanatomask_hip_ablate.so tools/norm_bench.py 16 > $out/norm_bench_b16.txt 2>&1
 timeout 300 python3 tools/phase_times.py 16 > $out/phase_times_b16.txt 2>&1
 timeout 600 python3 tools/batch_cliff.py 16 24 32 > $out/batch_cliff.txt 2>&1
 timeout 300 python3 tools/conv_shapes_bench.py 16 > $out/conv_shapes_b16.txt 2>&1
-timeout 300 python3 tools/with_lib.py anatomask_amd/libanatomask_hip_ablate.so tools/k3_ablate.py 16 > $out/k3_ablate_b16.txt 2>&1
+timeout 300 python3 tools/with_lib.py build_ab/libanatomask_hip_ablate.so tools/k3_ablate.py 16 > $out/k3_ablate_b16.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/step -- python3 $root/tools/step_run.py 16 20 1 > $out/step.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/step_iso -- python3 $root/tools/step_run.py 16 20 0 > $out/step_iso.log 2>&1

@@ -5,7 +5,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
 python3 -m anatomask_amd.build --ablate > $out/build_ablate.txt 2>&1
-L=anatomask_amd/libanatomask_hip_ablate.so
+L=build_ab/libanatomask_hip_ablate.so
 timeout 900 python3 -m pytest tests/test_ops_gpu.py -m gpu -q -p no:cacheprovider -k "wgrad or large_model" > $out/pytest.txt 2>&1; tail -2 $out/pytest.txt
 for tc in 1 0; do
 echo "== AM_WG_FILL=$tc"

@@ -6,7 +6,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
 python3 -m anatomask_amd.build --ablate > $out/build_ablate.txt 2>&1
-L=anatomask_amd/libanatomask_hip_ablate.so
+L=build_ab/libanatomask_hip_ablate.so
 for rep in 1 2; do for nok in 0 1; do for side in 1 0; do
   AM_WG_NOK3=$nok timeout 200 python3 tools/with_lib.py $L tools/step_run.py 16 8 $side 2>&1 | grep -v amdgpu.ids | sed "s/^/nok3=$nok /"
 done; done; done > $out/step_matrix.txt

@@ -5,7 +5,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
 python3 -m anatomask_amd.build --ablate > $out/build_ablate.txt 2>&1
-L=anatomask_amd/libanatomask_hip_ablate.so
+L=build_ab/libanatomask_hip_ablate.so
 run() { t=$1; shift; env "$@" timeout 600 python3 tools/with_lib.py $L tests/probe_bf16_order_noise.py $t 2>&1 | grep "^\[" | cut -c1-700; }
 run new AM_NONE=1
 run new2 AM_NONE=1

@@ -6,7 +6,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd $root
 python3 -m anatomask_amd.build --ablate > $out/build_ablate.txt 2>&1; tail -1 $out/build_ablate.txt
-L=anatomask_amd/libanatomask_hip_ablate.so
+L=build_ab/libanatomask_hip_ablate.so
 for d in ${WGK3_DBGS:-0 1 2 4 6 7}; do AM_WGK3_DBG=$d timeout 120 python3 tools/with_lib.py $L tools/wgk3_probe.py 2>&1 | grep -v amdgpu.ids; done > $out/wgk3_ablate.txt
 for s8 in ${WGK3_S8S:-}; do AM_WGK3_S8=$s8 timeout 120 python3 tools/with_lib.py $L tools/wgk3_probe.py 2>&1 | grep -v amdgpu.ids | sed "s/^/s8=$s8 /"; done >> $out/wgk3_ablate.txt
 AM_WG_NOK3=1 timeout 120 python3 tools/with_lib.py $L tools/wgk3_probe.py 2>&1 | grep -v amdgpu.ids >> $out/wgk3_ablate.txt

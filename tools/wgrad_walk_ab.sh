@@ -5,7 +5,7 @@ root=${GRAFT_REPO_ROOT:-$PWD}
 out=$root/gpurun_out/walk
 mkdir -p $out
 cd $root
-alt=$root/anatomask_amd/libanatomask_hip_ablate.so    # bound explicitly through tools/with_lib.py (the product loader reads no environment)
+alt=$root/build_ab/libanatomask_hip_ablate.so    # bound explicitly through tools/with_lib.py (the product loader reads no environment)
 for b in 2 16; do
   for w in 0 1; do for pl in 0 1; do
     echo "== B=$b walk=$w plane=$pl"; AM_CB_BATCH=$b AM_WG_WALK=$w AM_WG_PLANE=$pl python3 tools/with_lib.py $alt tools/conv_bench.py wgrad 20
