@@ -280,7 +280,9 @@ def test_config2_n_steps_vs_oracle(mode):
     bf = mode == "bf16"
     m = _build(cfg, W0, dtype=torch.bfloat16 if bf else torch.float32)
     tr = AnatoMaskTrainer(m, lr=NS_LR, ema_decay=NS_DECAY, total_epochs=NS_TOTAL + 1, distributed=False, f32_split=mode == "f32s")
-    trainable = [k for k in O.trainable_keys(cfg) if not _ANALYTIC_ZERO.search(k)]
+    # (tensors the oracle's first step moved: the dead densify[4] branch has grad = None in the reference and is never stepped)
+    trainable = [k for k in O.trainable_keys(cfg) if not _ANALYTIC_ZERO.search(k) and not torch.equal(snap1[0][k], W0[k])]
+    assert len(trainable) == 92
     bn_stats = [k for k in W0 if k.endswith(("running_mean", "running_var"))]
     hsnap1 = None
     for s, (x, mask1, keys) in enumerate(draws):
@@ -324,8 +326,10 @@ def test_config2_n_steps_vs_oracle(mode):
     f1, f1e = flipped(hsnap1[0], snap1[0]), flipped(hsnap1[1], snap1[1])
     print(f"   first update vs oracle: median rel {med1:.2e}, elements off by > 10 % of the largest update: student {f1:.2e}, EMA {f1e:.2e}")
     if not bf:
-        assert med1 < 30 * STEP1_UPDATE_MEDIAN          # (full size: ~100x more near-zero gradient elements per tensor than the 8..128-channel fixture; measured value printed)
-        assert f1 <= 10 * STEP1_FLIPPED and f1e <= 10 * STEP1_FLIPPED
+        # (full size: far more elements whose gradient is float noise than in the 8..128-channel fixture, and Adam's first update is
+        # lr * sign(g) for them too: measured median 1.1e-2, 3.7e-3 of the elements off by > 10 % of the largest update)
+        # the split products perturb the gradients at 2^-17 instead of 2^-24: measured median 7.4e-2, 6.0e-3 of the elements.  Bounds <= 3 x measured.
+        assert med1 < (0.2 if mode == "f32s" else 30 * STEP1_UPDATE_MEDIAN) and f1 <= 4 * STEP1_FLIPPED and f1e <= 4 * STEP1_FLIPPED
     # ---- after N steps: encoder / decoder weight updates, EMA, BatchNorm running statistics
     rows, rows_e = _delta_rows(fsd, W0, st.student, trainable), _delta_rows(esd, W0, st.teacher, trainable)
     enc = [r for r in rows if r[0].startswith(O.ENC)]
