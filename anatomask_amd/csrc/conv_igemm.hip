@@ -705,6 +705,8 @@ static int conv3d_impl(int mode, int dtype, int ksize, int stride, const void* x
   if (ep_scale && !ep_shift) return -1;
   Plan P;
   ConvArgs& a = P.a;
+  a.stats_sum_only = (accumulate & AM_CONV_PARTIALS_SUM_ONLY) ? 1 : 0;      // (a hint: every kernel but conv_k3's fills both columns anyway)
+  accumulate &= 1;
   a.nb_x = nb_x; a.nb_scale = nb_scale; a.nb_shift = nb_shift; a.nb_act = nb_act;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_act = in_act;
   // ---- thin layers with everything resident in LDS: conv_rw.hip ----

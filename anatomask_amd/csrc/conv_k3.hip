@@ -87,7 +87,10 @@ struct Item { int u, k, c0, c1, p; };               // c0 = bw | bh << 8 | bd <<
 // runs per (class, slab).  With two slabs (Cin = 64) both stay resident in the two slab buffers for all eight classes: the brick is
 // fetched ONCE for 64 taps (conv_igemm.hip gives every class its own workgroup and its own copy: that launch ran at the CU's fill rate).
 // A class's 8 x 4 x 16 outputs leave as 16-byte stores two voxels apart (the other classes' voxels lie between them).
-template <int NS, bool EP, bool ST, bool CT = false>
+// S1 (with ST): the caller reads only the SUM column of the statistics rows (the data gradient whose per-channel sum is the bias gradient of
+// the transposed conv in front, P/decoder3D.py:17): the sum-of-squares half of the epilogue (a multiply, a DPP exchange and an add per stored
+// value, 8 registers) is not compiled in; that column is written as zero.
+template <int NS, bool EP, bool ST, bool CT = false, bool S1 = false>
 __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   static_assert(NS == 4 || NS == 2, "64- or 32-channel output tiles (NS = 2: the decoder's last conv, C -> C / 2 = 32 at STUNet-B; a wave then owns 8 accumulator tiles)");
   constexpr int VS = 4, NT = 16 * NS;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   constexpr int NRUN = CT ? 4 : 9;                  // runs per (unit, slab) item; taps per run: 2 / 3
   constexpr int NTR = CT ? 2 : 3;
   static_assert(!CT || (NS == 4 && !EP && !ST), "transposed conv: 64-channel tiles, plain epilogue (bias)");
+  static_assert(!S1 || (ST && NS == 4 && !CT), "sum-only statistics: a variant of the statistics instantiation");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
         float s1 = f1[h][r], s2 = f2[h][r];
         // sum over the 8 lanes of the 16-lane row that have this lane's parity: xor 2, rotate by 4, rotate by 8
         K3_DPP_ADD(s1, 0x4E); K3_DPP_ADD(s1, 0x124); K3_DPP_ADD(s1, 0x128);
-        K3_DPP_ADD(s2, 0x4E); K3_DPP_ADD(s2, 0x124); K3_DPP_ADD(s2, 0x128);
+        if constexpr (!S1) { K3_DPP_ADD(s2, 0x4E); K3_DPP_ADD(s2, 0x124); K3_DPP_ADD(s2, 0x128); }
         const int c = co0 + h * 32 + g * 8 + (r16 & 1) * 4 + r;     // (even lane: tile 2h, odd lane: tile 2h + 1)
         if (r16 < 2) { part[c * 2] = s1; part[c * 2 + 1] = s2; }
       }
@@ -356,10 +360,13 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
         for (int e = 0; e < 2; ++e) {
           const int r = 2 * q + e;
           const float keep = __uint_as_float(e ? (kw & 0xffff0000u) : (kw << 16)), give = __uint_as_float(e ? (gw & 0xffff0000u) : (gw << 16));
-          f1[h][r] += keep; f2[h][r] += keep * keep;
+          f1[h][r] += keep;
           f1[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
-          const float g2 = give * give;
-          f2[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, g2), 0xB1, 0xF, 0xF, true));
+          if constexpr (!S1) {
+            f2[h][r] += keep * keep;
+            const float g2 = give * give;
+            f2[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, g2), 0xB1, 0xF, 0xF, true));
+          }
         }
       }
     }
@@ -584,11 +591,13 @@ int conv_k3_launch(int mode, int dtype, int ksize, int stride, ConvArgs& c, void
   if (ep && a.partials) return 0;                  // (no caller fuses a store epilogue AND asks for statistics: conv_igemm.hip serves it)
   auto kern = ep ? conv_k3_kernel<4, true, false> : (a.partials ? conv_k3_kernel<4, false, true> : conv_k3_kernel<4, false, false>);
   if (c.Cout % 64) kern = ep ? conv_k3_kernel<2, true, false> : (a.partials ? conv_k3_kernel<2, false, true> : conv_k3_kernel<2, false, false>);
+  else if (a.partials && !ep && c.stats_sum_only) kern = conv_k3_kernel<4, false, true, false, true>;      // (the rows' sum-of-squares column stays zero)
   {
     static PerDeviceOnce lds_cap; static int optin_err = 0;
     lds_cap.run([&](int) {
-      const void* ks[6] = {(const void*)conv_k3_kernel<4, true, false>, (const void*)conv_k3_kernel<4, false, true>, (const void*)conv_k3_kernel<4, false, false>,
-                           (const void*)conv_k3_kernel<2, true, false>, (const void*)conv_k3_kernel<2, false, true>, (const void*)conv_k3_kernel<2, false, false>};
+      const void* ks[7] = {(const void*)conv_k3_kernel<4, true, false>, (const void*)conv_k3_kernel<4, false, true>, (const void*)conv_k3_kernel<4, false, false>,
+                           (const void*)conv_k3_kernel<2, true, false>, (const void*)conv_k3_kernel<2, false, true>, (const void*)conv_k3_kernel<2, false, false>,
+                           (const void*)conv_k3_kernel<4, false, true, false, true>};
       for (const void* kp : ks) { hipError_t e_ = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e_ != hipSuccess) optin_err = (int)e_; }
       (void)hipGetLastError();
     });

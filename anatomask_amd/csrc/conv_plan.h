@@ -31,6 +31,7 @@ struct ConvArgs {
   int w_lds_off;              // byte offset of the weight-group buffers inside dynamic LDS
   MaskView in_mask, out_mask;
   int accumulate;
+  int stats_sum_only;         // am_conv3d's accumulate bit 1: the caller reads only the SUM column of `partials` (conv_k3.hip has a cheaper epilogue for it)
   int brick_in_patch;         // block-sparse output and the q-brick lies inside one patch: one mask lookup decides the whole brick
   const int* plist;           // ... and the active-patch list is at hand: the grid enumerates the LIVE bricks only (patch = plist[i / bpp], brick i % bpp
   int pbd, pbh, pbw, nlive;   //   of its pbd x pbh x pbw bricks); nlive = n_active * bpp.  nullptr: every brick of the q grid, empty ones exit

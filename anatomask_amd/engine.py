@@ -511,7 +511,8 @@ def _dec_block_backward(W, G, pk: PackCache, t: dict, g: Optional[torch.Tensor],
         _wgrad_into(pk, G, f"{q}.conv.3.weight", CONV_FWD, t["r"], dc2, 3, 1)
         dc1 = ops.norm_backward(dr, None, t["c1"], t["st1"], W[f"{q}.conv.1.weight"], ACT_RELU6, None, 0,
                                 G[f"{q}.conv.1.weight"], G[f"{q}.conv.1.bias"], reduced=red1)
-    du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True)
+    # (only the per-channel SUM of du is read -- the transposed conv's bias gradient --: the cheaper statistics epilogue)
+    du, ptu = ops.conv3d(CONV_DGRAD, dc1, pk.get(W, f"{q}.conv.0.weight", False, True), None, so, 3, 1, want_partials=True, partials_sum_only=True)
     ptu.finalize(None, sum_accum=G[f"{q}.up_sample.bias"])  # ConvT bias gradient = per-channel sum of du
     _wgrad_into(pk, G, f"{q}.conv.0.weight", CONV_FWD, t["u"], dc1, 3, 1)
     si = tuple(t["xin"].shape[1:4])

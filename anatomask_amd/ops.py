@@ -218,8 +218,9 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
            out_mask: Optional[MaskInfo] = None, out_bshift: int = 0, out: Optional[torch.Tensor] = None,
            accumulate: bool = False, want_partials: bool = False, ep_scale: Optional[torch.Tensor] = None,
            ep_shift: Optional[torch.Tensor] = None, ep_res: Optional[torch.Tensor] = None, ep_act: int = 0,
-           norm_bwd: Optional[tuple] = None):
-    """ep_*: fused store epilogue y = act(conv * scale + shift + res) (eval-mode BatchNorm / skip add / activation).
+           norm_bwd: Optional[tuple] = None, partials_sum_only: bool = False):
+    """partials_sum_only (with want_partials): only the per-channel SUM of the rows will be read (AM_CONV_PARTIALS_SUM_ONLY).
+    ep_*: fused store epilogue y = act(conv * scale + shift + res) (eval-mode BatchNorm / skip add / activation).
     norm_bwd = (x_pre, st, act): the output is the gradient wrt act(norm(x_pre)); the launch also leaves the norm-backward sums in
     its partial rows (am_conv3d_nbred) -> returns (out, rows) for norm_backward(..., reduced=rows).  bf16 only."""
     B, Di, Hi, Wi, Cin = x.shape
@@ -253,7 +254,8 @@ def conv3d(mode: int, x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[to
     hip.lib().conv3d(mode, _dtc(x, split), ksize, stride, x.data_ptr(), w_packed.data_ptr(), _p(bias), out.data_ptr(),
                      B, Di, Hi, Wi, Cin, Do, Ho, Wo, Cout,
                      in_mask.t.data_ptr() if in_mask else None, in_bshift,
-                     out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw, int(accumulate),
+                     out_mask.t.data_ptr() if out_mask else None, out_bshift, fd, fh, fw,
+                     int(accumulate) | (2 if (partials_sum_only and part is not None) else 0),
                      part.t.data_ptr() if part else None, _p(ep_scale), _p(ep_shift),
                      ep_res.data_ptr() if ep_res is not None else None, int(ep_act), alp, aln, _ROWS_ADDR if part else None, _stream())
     if part is not None:

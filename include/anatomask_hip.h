@@ -32,6 +32,9 @@ extern "C" {
  * point takes AM_DT_F32 for such tensors.  4x the rate of the exact-fp32 mode; 16 significant bits per operand. */
 #define AM_DT_F32S 2
 
+/* am_conv3d `accumulate`: bit 0 = add into y (the k1 s2 shortcut's data gradient); bit 1 = with `partials`, the caller reads only their SUM
+ * column (a bias gradient = per-channel sum of the output): a kernel may then leave the sum-of-squares column zero. */
+#define AM_CONV_PARTIALS_SUM_ONLY 2
 #define AM_CONV_FWD 0     /* y[o]  = sum_t x[o*stride + t - k/2] W_t        (k = 1|3, stride 1|2)            */
 #define AM_CONV_DGRAD 1   /* dx[i] = sum_t dy[(i + k/2 - t)/stride] W_t^T   (data gradient of AM_CONV_FWD)   */
 #define AM_CONVT_FWD 2    /* y[o]  = sum_t x[(o + 1 - t)/2] W_t             (ConvTranspose3d k4 s2 p1)       */

@@ -449,6 +449,17 @@ def test_conv_k3_persistent_kernel_fwd_dgrad_stats(ops, case):
     # data gradient (the weight tap index is mirrored, the packed weight transposed)
     dx = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), ops.pack_weight(wd, dtype, False, True), None, S, 3, 1)
     close(from_cl(dx), xr.grad, TOL[dtype], "conv_k3 dgrad")
+    # ... with the SUM-ONLY statistics epilogue (AM_CONV_PARTIALS_SUM_ONLY: what the decoder's backward asks for -- the transposed conv's bias
+    # gradient is the per-channel sum of this data gradient): same output bits, same sums as the full epilogue's, sum-of-squares column zero
+    if cin % 64 == 0:
+        dx2, p2 = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), ops.pack_weight(wd, dtype, False, True), None, S, 3, 1, want_partials=True, partials_sum_only=True)
+        dx3, p3 = ops.conv3d(ops.CONV_DGRAD, to_cl(dy, dtype), ops.pack_weight(wd, dtype, False, True), None, S, 3, 1, want_partials=True)
+        assert torch.equal(dx2, dx) and torch.equal(dx3, dx) and p2.rows == p3.rows
+        assert torch.equal(p2.t[:p2.rows, :, 0], p3.t[:p3.rows, :, 0]) and float(p2.t[:p2.rows, :, 1].abs().max()) == 0.0 and float(p3.t[:p3.rows, :, 1].abs().max()) > 0.0
+        acc = torch.zeros(cin, device=DEV)
+        p2.finalize(None, sum_accum=acc)
+        ref = from_cl(dx).double().sum(dim=(0, 2, 3, 4))
+        assert (acc.cpu().double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-3
 
 
 def test_conv_k3_sample_index_beyond_the_packed_field(ops):
