@@ -316,6 +316,34 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       }
     }
   };
+  // statistics of half a chunk (words q and 2 + q of the 16 stored bytes): words 0, 1 = channels 0..3 of tile 2h (rows r), words 2, 3 = those of
+  // tile 2h + 1.  A lane keeps the tile of its parity and gives the other one to its pair lane (quad_perm [1, 0, 3, 2]).  Bitwise selects on the
+  // packed words (v_bfi_b32): a `odd ? v[4 + r] : v[r]` on the unpacked vector becomes a dynamic element index -- an 8-way compare / select chain.
+  auto stats_half = [&](const int c, const int q) __attribute__((always_inline)) {
+    const int j = c / (NS / 2), h = c % (NS / 2);
+    const u32x4 wv = pk[j][h];
+    const unsigned kw = (wv[2 + q] & oddm) | (wv[q] & ~oddm), gw = (wv[q] & oddm) | (wv[2 + q] & ~oddm);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int r = 2 * q + e;
+      const float keep = __uint_as_float(e ? (kw & 0xffff0000u) : (kw << 16)), give = __uint_as_float(e ? (gw & 0xffff0000u) : (gw << 16));
+      f1[h][r] += keep;
+      f1[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+      if constexpr (!S1) {
+        f2[h][r] += keep * keep;
+        const float g2 = give * give;
+        f2[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, g2), 0xB1, 0xF, 0xF, true));
+      }
+    }
+  };
+  // Units of two or more slabs do the statistics of a finished unit as 16 half-chunk pieces, one per L phase over the next unit's first 16
+  // runs, instead of one whole chunk behind each of the 8 deferred stores (the L phases that carry a store are the long ones).  Same-box A/B
+  // (profiles/r06_experiments.md): 64 -> 64 @128^3 with statistics 5.755 -> 5.713 ms; -DAM_K3_NO_SPREAD_STATS builds the old placement.
+#ifdef AM_K3_NO_SPREAD_STATS
+  constexpr bool spread_stats = false;
+#else
+  const bool spread_stats = ST && !CT && NCH == 8 && a.nslab >= 2;
+#endif
   // chunk c = (NS / 2) j + h of the pending unit: one 16-byte store per lane (+ the statistics of the stored values)
   auto store_chunk = [&](const int c, const bool tail) __attribute__((always_inline)) {
     const int j = c / (NS / 2), h = c % (NS / 2);
@@ -348,28 +376,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
       // the transposed instantiation issues two stores back to back: the same hazard in every phase, not only in the tail)
       if (tail || FULL) asm volatile("s_nop 4" : "+v"(sv) :: "memory");
     }
-    if (want_stats) {
-      // the STORED values: words 0, 1 = channels 0..3 of tile 2h (rows r), words 2, 3 = those of tile 2h + 1.  A lane keeps the tile of its
-      // parity and gives the other one to its pair lane (quad_perm [1, 0, 3, 2]).  Bitwise selects on the packed words (v_bfi_b32): a
-      // `odd ? v[4 + r] : v[r]` on the unpacked vector becomes a dynamic element index -- an 8-way compare / select chain per value.
-      const u32x4 wv = pk[j][h];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const unsigned kw = (wv[2 + q] & oddm) | (wv[q] & ~oddm), gw = (wv[q] & oddm) | (wv[2 + q] & ~oddm);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int r = 2 * q + e;
-          const float keep = __uint_as_float(e ? (kw & 0xffff0000u) : (kw << 16)), give = __uint_as_float(e ? (gw & 0xffff0000u) : (gw << 16));
-          f1[h][r] += keep;
-          f1[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
-          if constexpr (!S1) {
-            f2[h][r] += keep * keep;
-            const float g2 = give * give;
-            f2[h][r] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, g2), 0xB1, 0xF, 0xF, true));
-          }
-        }
-      }
-    }
+    if (want_stats && (tail || !spread_stats)) { stats_half(c, 0); stats_half(c, 1); }
   };
 
   // ---- prologue: this wave's statistics row starts at zero; first weights run and first slab
@@ -403,6 +410,7 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
   int par = 0, sb = 0;                                   // weight slot of the current run, slab buffer of the current item
   int pc0 = 0, pc1 = 0, pcls = 0; bool have_prev = false;   // the finished unit (transposed conv: and class) whose epilogue is due
   bool spend = false;                                    // its 8 stores are pending: one per L phase of this slab's runs 0..7
+  bool pend_stats = false;                               // (AM_K3_SPREAD_STATS) its statistics are pending: half a chunk per L phase of the first two slabs' runs
 #pragma unroll
   for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -411,9 +419,9 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
     spend = false;
     if (cur.k == 0 && have_prev) {
       finish_unit(pc0, pc1, pcls);                       // (also zeroes the accumulators)
-      spend = true;
+      spend = true; pend_stats = true;
       K3_STAMP(tE);
-    }
+    } else if (cur.k >= 2) pend_stats = false;
     const bool has_next = nxt.u < a.nunit;
     int bxc[3];
 #pragma unroll
@@ -463,6 +471,12 @@ __global__ __launch_bounds__(512, 2) void conv_k3_kernel(K3Args a) {
           for (int q = 0; q < SPR; ++q) store_chunk(run * SPR + q, false);
         }
         if (fetch_next && npy > 0) issue_pieces(nxt, sb ^ 1, CT ? 4 * run : pk0, (CT ? 4 * run : pk0) + npy);
+      }
+      if (spread_stats && want_stats && pend_stats) {
+        // (k3: 9 runs per slab; half-chunks 0..8 in the first slab, 9..15 in the second.  `run` is a constant of the unrolled loop: each branch
+        // indexes the register arrays with compile-time values)
+        if (cur.k == 0) stats_half(run >> 1, run & 1);
+        else if (cur.k == 1 && 9 + run < 16) stats_half((9 + run) >> 1, (9 + run) & 1);
       }
       // ONE barrier per run and wave.  Between two barriers X runs [L(n) M(n)] and Y runs [M(n - 1) L(n)]: X fetches while Y multiplies, then
       // the other way round.  What the barrier orders: every X wave's weights of run n + 1 have landed (its counted `vmcnt` wait sits in front

@@ -37,8 +37,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ENC_FWD_ALGO = {"S": (48, 0.6, 36.1e6, 1.5e9), "B": (128, 0.6, 1105.3e6, 114.0e9), "L": (160, 0.7, 6135e6, 1716e9), "H": (192, 0.6, 30622e6, 14345e9)}
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy ceiling)
 # counter evidence of this round's tree, written by tools/pmc_k3.sh / tools/enc_traffic.py on the GPU box and committed under profiles/
-PMC_K3_JSON = os.path.join("profiles", "r05_pmc_k3.json")
-ENC_TRAFFIC_JSON = os.path.join("profiles", "r05_encoder_fwd_traffic.json")
+PMC_K3_JSON = os.path.join("profiles", "r06_pmc_k3.json")
+ENC_TRAFFIC_JSON = os.path.join("profiles", "r06_encoder_fwd_traffic.json")
 MFMA_BF16_PEAK = 2.5e15    # dense bf16
 
 
@@ -56,7 +56,7 @@ def time_kernel(fn, iters=20, warm=3):
 
 
 def dominant_kernel_roofline(B, dev, tr, x, C=64, S=128, size="B"):
-    """The dominant kernel of the step (profiles/r04_*_step_kernel_stats_b16.csv: conv_k3_kernel, the persistent 8-wave LDS-DMA kernel of
+    """The dominant kernel of the step (profiles/r06_final_step_kernel_stats_b16_isolated.csv: conv_k3_kernel, the persistent 8-wave LDS-DMA kernel of
     the dense k3 s1 convolutions) on its largest instance: the first conv of the last decoder block, C -> C at S^3 (P/decoder3D.py:20;
     C = width / 8: 64 for STUNet-B, 128 for L, 192 for H), launched as the training step launches it: WITH the statistics epilogue
     (`want_partials=True`: the student's BatchNorm reads its sums from the conv).  Bound: MFMA (AI ~ 1700 flop/B at C = 64).
@@ -102,7 +102,7 @@ def dominant_kernel_roofline(B, dev, tr, x, C=64, S=128, size="B"):
     achieved = flops / t / 1e12
     algo = (2 * S ** 3 * C * 2 * B) + 27 * C * C * 2
     # HBM bytes per launch: the PMC counters of the SAME launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE
-    # doubled per the gfx950 correction, counters in KB = 1024 B), as tools/pmc_k3.sh left them in profiles/r05_pmc_k3.json: measured at
+    # doubled per the gfx950 correction, counters in KB = 1024 B), as tools/pmc_k3.sh left them in profiles/r06_pmc_k3.json: measured at
     # B = 16 for 64 -> 64 @128^3 and linear in B.  No counter pass exists for the other shapes -> null; a missing file is an error, not a constant.
     traffic = src = None
     if (C, S) == (64, 128):

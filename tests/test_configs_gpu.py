@@ -240,9 +240,9 @@ def _ns_run_oracle(cfg, W0, draws, forced_masks=None):
 
 
 @functools.lru_cache(maxsize=None)
-def _oracle_nsteps_b128():
-    cfg = O.Config.stunet_b((128, 128, 128), 0.6)
-    assert O.len_loss_for(cfg, NS_EPOCH, NS_TOTAL) == 76
+def _oracle_nsteps_b128(shape=(128, 128, 128)):
+    cfg = O.Config.stunet_b(shape, 0.6)
+    assert O.len_loss_for(cfg, NS_EPOCH, NS_TOTAL) == {512: 76, 392: 58}[cfg.L]
     W0 = O.seeded_state(cfg, 5)
     draws = _ns_draws(cfg)
     torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -272,11 +272,16 @@ def _delta_rows(state, W0, ref_state, keys):
     return rows
 
 
-@pytest.mark.parametrize("mode", ["f32", "f32s", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "f32s", "bf16", "f32-recipe"])
 def test_config2_n_steps_vs_oracle(mode):
+    """mode "f32-recipe": the same three steps on the reference's SHIPPED recipe shape 112 x 112 x 128 (P/pretrain_AntoMask.py:188,209: 392
+    patches, 58 of the 235 masked ones hard; the ragged 28^3 / 14^3 / 7^3 grids take the tail branches of the brick kernels), exact fp32."""
     from anatomask_amd.trainer import AnatoMaskTrainer
     from tests.test_oracle_golden import NSTEP_UPDATE_MEDIAN, NSTEP_WEIGHT_MAX, NSTEP_WEIGHT_MEDIAN, STEP1_FLIPPED, STEP1_UPDATE_MEDIAN
-    cfg, W0, draws, st, outs, snap1 = _oracle_nsteps_b128()
+    recipe = mode == "f32-recipe"
+    cfg, W0, draws, st, outs, snap1 = _oracle_nsteps_b128((112, 112, 128)) if recipe else _oracle_nsteps_b128()
+    mode = "f32" if recipe else mode
+    n_hard = O.len_loss_for(cfg, NS_EPOCH, NS_TOTAL)
     bf = mode == "bf16"
     m = _build(cfg, W0, dtype=torch.bfloat16 if bf else torch.float32)
     tr = AnatoMaskTrainer(m, lr=NS_LR, ema_decay=NS_DECAY, total_epochs=NS_TOTAL + 1, distributed=False, f32_split=mode == "f32s")
@@ -295,11 +300,11 @@ def test_config2_n_steps_vs_oracle(mode):
         rec_h, rec_o = out["recon_loss"].cpu().numpy(), o["recon_loss"].numpy()
         l2 = np.abs(rec_h - rec_o).max() / rec_o.max()
         rl_h, rl_o = out["rec_loss"].cpu().numpy(), o["rec_loss"].numpy()
-        print(f"STUNet-B 128^3 {mode} step {s + 1}/{NS_N} (epoch {NS_EPOCH}, 76 hard patches): loss {out['loss'].item():.7f} / {o['loss']:.7f}  "
+        print(f"STUNet-B {'x'.join(map(str, cfg.input_size))} {mode} step {s + 1}/{NS_N} (epoch {NS_EPOCH}, {n_hard} hard patches): loss {out['loss'].item():.7f} / {o['loss']:.7f}  "
               f"grad-norm {out['grad_norm'].item():.6f} / {o['grad_norm']:.6f}  teacher-l2 rel err {l2:.2e}  student per-patch rel err "
               f"{np.abs(rl_h - rl_o).max() / rl_o.max():.2e}  mask equal {same}")
         assert same, f"sampler mask diverged at step {s + 1}"
-        hard_o = np.argsort(rec_o, axis=1)[:, cfg.L - 76:]
+        hard_o = np.argsort(rec_o, axis=1)[:, cfg.L - n_hard:]
         assert not out["mask"].view(1, -1).bool().cpu().numpy()[0, hard_o[0]].any()
         rel = abs(out["loss"].item() - o["loss"]) / o["loss"]
         if bf:
